@@ -1,0 +1,71 @@
+/*
+ * indicasr.h -- C ABI of libindicasr_hip.so: hand-written HIP/CDNA4 (gfx950) kernels for the
+ * Conformer hybrid RNNT-CTC + continual-learning training step of FrozenWolf-Cyber/Indic-CL-ASR.
+ *
+ * Conventions (SURVEY.md §8b "C ABI the replacement exports"):
+ *   - plain C symbols, plain pointers and sizes; every pointer is a DEVICE pointer unless it says host;
+ *   - the CALLER owns every buffer including the workspace (size from the pure ia_*_workspace_bytes());
+ *   - kernels are enqueued on `stream` (a hipStream_t passed as void*), never synchronise, never allocate;
+ *   - no global mutable state: re-entrant across streams, one host thread per process as in the reference;
+ *   - return IA_OK (0) or a negative ia_status; mirrors the reference's RNNTStatus SUCCESS / INVALID_VALUE
+ *     (NeMo/nemo/collections/asr/parts/numba/rnnt_loss/utils/global_constants.py:66-68), which its Python
+ *     side turns into RuntimeError (rnnt.py:84-85,115-116) -- ours does the same in _lib.py.
+ *
+ * Reference paths cited below: K/ = NeMo/nemo/collections/asr/parts/numba/rnnt_loss/,
+ *                              A/ = NeMo/nemo/collections/asr/, R/ = repository root of the reference.
+ */
+#ifndef INDICASR_H
+#define INDICASR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* ia_stream_t; /* hipStream_t */
+
+enum ia_status {
+    IA_OK = 0,
+    IA_INVALID_VALUE = -1,      /* bad dims / null pointer / misaligned buffer */
+    IA_WORKSPACE_TOO_SMALL = -2,
+    IA_LAUNCH_FAILED = -3,      /* hipGetLastError() != hipSuccess after enqueue */
+    IA_UNSUPPORTED = -4,        /* size outside what the kernels were built for (documented per entry) */
+};
+
+/* Library / build identification. Returns a static string such as "indicasr-hip gfx950 r1". */
+const char* ia_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * RNNT (transducer) loss, fused log-softmax front end + alpha/beta wavefront + fused gradient.
+ * Replaces: GPURNNT.compute_cost_and_score  K/utils/cuda_utils/gpu_rnnt.py:125-231  and its five Numba
+ *           kernels (reduce_max/reduce_exp K/utils/cuda_utils/reduce.py:299-360, compute_alphas/betas/grad
+ *           K/utils/cuda_utils/gpu_rnnt_kernel.py:73-407, compute_costs_data K/utils/rnnt_helper.py:106-116),
+ *           reached from rnnt_loss_gpu K/rnnt.py:138-236 and _RNNTNumba.forward K/rnnt_pytorch.py:40-91.
+ *
+ * logits  [B,T,U1,V] f32 contiguous, 16-byte aligned (raw joint output, NOT log-softmaxed: GPU semantics)
+ * labels  [B,U1-1] i64;  act_lens [B] i64 (1..T);  label_lens [B] i64 (0..U1-1)
+ * costs   [B] f32 out:  -(log-likelihood)*(1+fastemit)
+ * grads   [B,T,U1,V] f32 out, d(cost_b)/d(logits); zero outside each utterance's valid lattice.
+ *         May be NULL (forward/score only) and MAY ALIAS `logits` (in-place).
+ * clamp   <= 0 disables gradient clamping (reference: clamp > 0.0 enables, gpu_rnnt_kernel.py:399-403).
+ * Limits: U1 <= 1024 (IA_UNSUPPORTED beyond).
+ * Workspace: ia_rnnt_workspace_bytes(B,T,U1) bytes, 256-byte aligned.
+ */
+size_t ia_rnnt_workspace_bytes(int B, int T, int U1);
+int ia_rnnt_loss(const float* logits, const int64_t* labels, const int64_t* act_lens, const int64_t* label_lens,
+                 int B, int T, int U1, int V, int blank, float fastemit_lambda, float clamp,
+                 float* costs, float* grads, void* workspace, size_t workspace_bytes, ia_stream_t stream);
+/* Test/debug helper: copies the forward/backward variables left in `workspace` by ia_rnnt_loss into
+ * dense [B,T,U1] f32 tensors (zero outside the valid lattice), the layout of the reference's
+ * alphas/betas workspace (gpu_rnnt.py:267-293) that its kernel tests compare
+ * (NeMo/tests/collections/asr/numba/rnnt_loss/utils/test_gpu_rnnt_kernel.py:52-188). */
+int ia_rnnt_export_alphas_betas(const void* workspace, size_t workspace_bytes, const int64_t* act_lens,
+                                const int64_t* label_lens, int B, int T, int U1, float* alphas, float* betas,
+                                ia_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INDICASR_H */

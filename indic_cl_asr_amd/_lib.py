@@ -1,0 +1,69 @@
+"""ctypes binding of libindicasr_hip.so (the C ABI declared in include/indicasr.h).
+
+The product path has NO fallback: if the shared object is missing or a symbol is absent,
+importing/using an op raises.  Status codes are turned into exceptions the way the reference turns
+RNNTStatus into RuntimeError (NeMo/nemo/collections/asr/parts/numba/rnnt_loss/rnnt.py:84-85,115-116).
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libindicasr_hip.so")
+
+IA_OK = 0
+_STATUS = {-1: "IA_INVALID_VALUE", -2: "IA_WORKSPACE_TOO_SMALL", -3: "IA_LAUNCH_FAILED", -4: "IA_UNSUPPORTED"}
+
+_c = ctypes
+_vp, _i, _f, _sz = _c.c_void_p, _c.c_int, _c.c_float, _c.c_size_t
+_i64 = _c.c_int64
+
+# name -> (restype, argtypes); must list every symbol include/indicasr.h declares (tests/test_abi.py checks)
+SIGNATURES = {
+    "ia_version": (_c.c_char_p, []),
+    "ia_rnnt_workspace_bytes": (_sz, [_i, _i, _i]),
+    "ia_rnnt_loss": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _sz, _vp]),
+    "ia_rnnt_export_alphas_betas": (_i, [_vp, _sz, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def build(verbose=False):
+    """Compile every .hip under csrc/ for gfx950 into libindicasr_hip.so (in-tree)."""
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc")], stdout=out)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension is the product path and has no fallback. "
+                "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C indic_cl_asr_amd/csrc`.")
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if the symbol is absent
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(status, what):
+    if status != IA_OK:
+        raise RuntimeError(f"{what} failed with status {status} ({_STATUS.get(status, 'unknown')})")
+
+
+def version():
+    return lib().ia_version().decode()
+
+
+def stream_ptr():
+    """Raw hipStream_t of torch's current stream (kernels are enqueued there, never synchronised)."""
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
