@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py -- utterances/sec of one Conformer-M hybrid RNNT-CTC + EWC training step on MI355X (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" = zero_grad -> training_step (features, SpecAugment, Conformer encoder, prediction net, fused joint+RNNT
+loss per sub-batch, CTC head+loss) -> EWC penalty pre-loaded into .grad -> backward -> RCCL gradient all-reduce
+(N>1) -> fused AdamW, on a synthetic batch already resident in HBM (audio 0.1*N(0,1), lengths
+U(0.6,1)*L with one full-length item, 7 tokens/s, language 'hi', seed 1234).  Workload at N=1 = BASELINE
+configs[1]: Conformer-medium (d=256, 16 layers), EWC, bs=32 per GPU, 15 s utterances, bf16 projections, encoder
+layers <= 12 frozen as in the reference's config.yaml.  Weak scaling: every rank processes its own 32 utterances.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline      the HBM-bound RNNT gradient kernel (rnnt_grad) timed with HIP events inside the timed steps
+  cpu_baseline  the CPU oracle (oracle/step_ref.py, fp32, torch intra-op threads = host cores) on a bounded sample
+"""
+import argparse
+import ctypes
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
+
+
+def synth_batch(B, seconds, device, seed=1234, vocab=256, sr=16000):
+    g = torch.Generator().manual_seed(seed)
+    L = int(seconds * sr)
+    lens = torch.round(L * (0.6 + 0.4 * torch.rand(B, generator=g))).long()
+    lens[0] = L
+    x = 0.1 * torch.randn(B, L, generator=g)
+    x[:, 1:] = 0.5 * (x[:, 1:] + x[:, :-1])  # 2-tap low-pass
+    for b in range(B):
+        x[b, lens[b]:] = 0
+    dur = lens.float() / sr
+    from indic_cl_asr_amd.encoder import subsampled_length
+    from indic_cl_asr_amd.features import mel_frame_count
+    tl = []
+    for b in range(B):
+        tp = subsampled_length(mel_frame_count(int(lens[b])))
+        tl.append(max(1, min(int(round(7 * float(dur[b]))), tp - 1)))
+    tl = torch.tensor(tl)
+    U = int(tl.max())
+    tok = torch.randint(0, vocab, (B, U), generator=g)
+    batch = (x.to(device), lens.to(device), tok.to(device), tl.to(device))
+    return batch, (lens.tolist(), tl.tolist())
+
+
+class HipEvents:
+    """Pool of hipEvent_t (ctypes on libamdhip64) recorded by ia_rnnt_backward around the gradient kernel."""
+
+    def __init__(self):
+        self.hip = ctypes.CDLL("libamdhip64.so")
+        self.hip.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+        self.hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
+        self.pairs, self.shapes, self.free = [], [], []
+        self.enabled = False
+
+    def _new(self):
+        e = ctypes.c_void_p()
+        assert self.hip.hipEventCreate(ctypes.byref(e)) == 0
+        return e
+
+    def hook(self, B, T, U1, V):
+        if not self.enabled:
+            return None
+        a, b = self._new(), self._new()
+        self.pairs.append((a, b))
+        self.shapes.append((B, T, U1, V))
+        return a, b
+
+    def summary(self):
+        ms, byts = [], []
+        for (a, b), (B, T, U1, V) in zip(self.pairs, self.shapes):
+            t = ctypes.c_float()
+            if self.hip.hipEventElapsedTime(ctypes.byref(t), a, b) == 0:
+                ms.append(t.value)
+                byts.append(2.0 * 4 * B * T * U1 * V)  # read logits once + write grads once
+        if not ms:
+            return None
+        return sum(ms) / len(ms), sum(byts) / len(byts), len(ms)
+
+
+def cpu_baseline(seconds, cfg_kw, sample_bs=4, freeze_till=12):
+    """CPU oracle on a bounded sample: ONE sub-batch (fused_batch_size=4 utterances) of the same workload,
+    one full step (fwd + EWC penalty + bwd + AdamW)."""
+    from oracle import step_ref as S
+    torch.manual_seed(0)
+    o = S.OracleHybridModel(d_model=cfg_kw["d_model"], n_layers=cfg_kw["n_layers"], n_heads=cfg_kw["n_heads"],
+                            pred_hidden=cfg_kw["pred_hidden"], joint_hidden=cfg_kw["joint_hidden"])
+    S.freeze_layer(o, freeze_till)
+    o.train()
+    (sig, sl, tok, tl), _ = synth_batch(sample_bs, seconds, "cpu")
+    params = S.get_params(o)
+    fish = {n: torch.rand_like(p) * 1e-3 for n, p in params.items()}
+    ck = {n: p.detach().clone() for n, p in params.items()}
+    opt = torch.optim.AdamW([p for p in o.parameters() if p.requires_grad], lr=1e-4)
+    t0 = time.time()
+    opt.zero_grad()
+    loss, _ = o.training_step((sig, sl, tok, tl), ['hi'] * sample_bs)
+    pen, _ = S.ewc_penalty_grads(10.0, fish, S.get_params(o), ck)
+    for n, p in o.named_parameters():
+        p.grad = pen[n] if n in pen else None
+    loss.backward()
+    opt.step()
+    dt = time.time() - t0
+    return dict(value=sample_bs / dt, unit="utterances/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"1 step of {sample_bs} x {seconds:g} s utterances (one fused sub-batch of the same workload), "
+                       f"fp32 oracle/step_ref.py + oracle/rnnt_ref.c, {dt:.1f} s wall")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
+    ap.add_argument("--seconds", type=float, default=15.0)
+    ap.add_argument("--preset", default="medium")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--freeze", type=int, default=12, help="config.yaml model.freeze_encoder_till (-1: train everything)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-bs", type=int, default=4)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=dev)  # nccl == RCCL on ROCm
+
+    from indic_cl_asr_amd import cl
+    from indic_cl_asr_amd.config import model_config
+    from indic_cl_asr_amd.losses import rnnt as rnnt_mod
+    from indic_cl_asr_amd.model import EncDecHybridRNNTCTCModel, freeze_layer
+
+    torch.manual_seed(1234)
+    cfg = model_config(args.preset, compute_dtype=args.dtype)
+    model = EncDecHybridRNNTCTCModel(cfg).to(dev)
+    if args.freeze >= 0:
+        freeze_layer(model, args.freeze)
+        model.encoder.encoder_frozen_till = args.freeze
+    model.train()
+    flat = cl.FlatParams(model)
+    opt = cl.FusedAdamW(flat, lr=1e-4)
+    # EWC state of "task > 0": Fisher from a previous task (synthetic, positive) and the previous optimum
+    fisher = cl.get_zero_params(model)
+    fisher.flat.copy_(torch.rand(flat.numel, device=dev) * 1e-3)
+    checkpoint = cl.get_params_clone(model)
+    batch, host_lens = synth_batch(args.batch, args.seconds, dev, seed=1234 + rank)
+    langs = ['hi'] * args.batch
+
+    events = HipEvents()
+    rnnt_mod.PROFILE_HOOK = events.hook
+
+    def step():
+        opt.zero_grad()
+        loss, monitor = model.training_step(batch, langs, host_lengths=host_lens)
+        monitor['ewc_penalty'] = cl.ewc_penalty_into_grads(flat, fisher, checkpoint, e_lambda=10.0)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    events.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    events.enabled = False
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = world * args.batch * args.steps / dt
+        out = {
+            "metric": "utterances/sec (15 s @16 kHz) Conformer-M RNNT-CTC+EWC train step",
+            "value": round(value, 3), "unit": "utterances/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: Conformer-{args.preset} (d={cfg.d_model}, {cfg.n_layers}L, "
+                                   f"H={cfg.joint_hidden}) hybrid RNNT-CTC + EWC, bs={args.batch}/GPU x {args.seconds:g} s, "
+                                   f"{args.dtype} projections, freeze_encoder_till={args.freeze}, 22x257 heads, "
+                                   f"fused_batch_size={cfg.fused_batch_size}",
+                       "global_batch": world * args.batch, "parallelism": f"dp{world}",
+                       "final_loss": round(float(loss.item()), 4)},
+        }
+        s = events.summary()
+        if s is not None:
+            avg_ms, avg_bytes, n = s
+            ach = avg_bytes / (avg_ms * 1e-3) / 1e9
+            out["roofline"] = {"kernel": "rnnt_grad", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                               "launches": n, "avg_launch_ms": round(avg_ms, 4),
+                               "algorithmic_bytes_per_launch": int(avg_bytes)}
+        if not args.no_cpu_baseline and world == 1:
+            kw = dict(d_model=cfg.d_model, n_layers=cfg.n_layers, n_heads=cfg.n_heads, pred_hidden=cfg.pred_hidden,
+                      joint_hidden=cfg.joint_hidden)
+            out["cpu_baseline"] = cpu_baseline(args.seconds, kw, args.cpu_sample_bs, max(args.freeze, 0))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

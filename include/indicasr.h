@@ -57,6 +57,25 @@ size_t ia_rnnt_workspace_bytes(int B, int T, int U1);
 int ia_rnnt_loss(const float* logits, const int64_t* labels, const int64_t* act_lens, const int64_t* label_lens,
                  int B, int T, int U1, int V, int blank, float fastemit_lambda, float clamp,
                  float* costs, float* grads, void* workspace, size_t workspace_bytes, ia_stream_t stream);
+/* The same computation split at the autograd boundary (what the product's training step calls):
+ *   ia_rnnt_forward   K1 (denominators + gathers) + K2 (alpha; beta too when need_backward) + costs.
+ *   ia_rnnt_backward  per-cell scalars + the streaming gradient kernel, using the state ia_rnnt_forward left in
+ *                     `workspace` for the SAME logits.  cost_grad [B] f32 (device; NULL = ones) is the upstream
+ *                     d(loss)/d(cost_b): it is folded into the kernel, so the lattice is written exactly once
+ *                     (the reference multiplies the stored grads by grad_output in a second pass,
+ *                     K/rnnt_pytorch.py:88-91).  The reference clamps BEFORE that scaling, so clamp > 0 requires
+ *                     cost_grad == NULL (IA_INVALID_VALUE otherwise; scale the result afterwards).
+ *                     grads may alias logits.  ev_start/ev_stop: optional CALLER-OWNED hipEvent_t
+ *                     (void*, NULL to skip) recorded on `stream` right around the gradient kernel (rnnt_grad) so a
+ *                     benchmark can time the HBM-bound kernel inside a live training step.
+ */
+int ia_rnnt_forward(const float* logits, const int64_t* labels, const int64_t* act_lens, const int64_t* label_lens,
+                    int B, int T, int U1, int V, int blank, float fastemit_lambda, int need_backward, float* costs,
+                    void* workspace, size_t workspace_bytes, ia_stream_t stream);
+int ia_rnnt_backward(const float* logits, const int64_t* labels, const int64_t* act_lens, const int64_t* label_lens,
+                     int B, int T, int U1, int V, int blank, float fastemit_lambda, float clamp,
+                     const float* cost_grad, float* grads, void* workspace, size_t workspace_bytes, ia_stream_t stream,
+                     void* grad_kernel_start_event, void* grad_kernel_stop_event);
 /* Test/debug helper: copies the forward/backward variables left in `workspace` by ia_rnnt_loss into
  * dense [B,T,U1] f32 tensors (zero outside the valid lattice), the layout of the reference's
  * alphas/betas workspace (gpu_rnnt.py:267-293) that its kernel tests compare
@@ -64,6 +83,36 @@ int ia_rnnt_loss(const float* logits, const int64_t* labels, const int64_t* act_
 int ia_rnnt_export_alphas_betas(const void* workspace, size_t workspace_bytes, const int64_t* act_lens,
                                 const int64_t* label_lens, int B, int T, int U1, float* alphas, float* betas,
                                 ia_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Continual-learning regularisers and optimizer over ONE flat fp32 buffer holding every trainable parameter
+ * (tensor k occupies [off_k, off_k + numel_k), off_k a multiple of 64 floats, gaps zero-filled).
+ *
+ * chunk_table: int32[nchunks][4] = {offset (multiple of 4), count (<= ia_cl_chunk_elems()), segment id, 0};
+ *              chunks never straddle two tensors.  seg_inv_numel[k] = 1/numel_k.
+ *
+ * ia_cl_penalty        replaces get_penalty_grads R/cl_baseline_ewc.py:69-81 (+ set_grads R/utils.py:316-321) and
+ *                      penalty R/cl_baseline_mas.py:70-75:
+ *                         g = coef * weight * (theta - theta_star)      (EWC: coef = 2*e_lambda, weight = Fisher;
+ *                                                                        MAS: coef = 2*mas_lambda, weight = omega)
+ *                         grad = g (accumulate = 0: "pre-load .grad") or grad += g (accumulate = 1); grad may be NULL
+ *                         seg_abs_mean[k] += mean_k |g|   (caller zeroes; NULL to skip; EWC monitor 'ewc_penalty')
+ *                         penalty_sum[0]  += sum weight*(theta-theta_star)^2  (caller zeroes; NULL to skip; MAS 'mass_loss')
+ * ia_cl_fisher_accumulate  R/cl_baseline_ewc.py:245-255:  fisher += loss_scalar[0] * grad^2  (scalar read on device)
+ * ia_cl_abs_accumulate     R/cl_baseline_mas.py:267-270:  omega  += |grad|
+ * ia_adamw_step            torch.optim.AdamW update (R/cl_baseline.py:137; lr 1e-4, betas .9/.999, eps 1e-8, wd 1e-2),
+ *                          `step` counts from 1; grad is multiplied by grad_scale first (1.0, or 1/world for DP mean);
+ *                          shadow_bf16 (optional, n x bf16) receives the updated weights rounded to bf16.
+ */
+int ia_cl_chunk_elems(void);
+int ia_cl_penalty(const float* theta, const float* theta_star, const float* weight, float coef, float* grad,
+                  int accumulate, const int32_t* chunk_table, int nchunks, const float* seg_inv_numel,
+                  float* seg_abs_mean, float* penalty_sum, ia_stream_t stream);
+int ia_cl_fisher_accumulate(float* fisher, const float* grad, const float* loss_scalar, int64_t n, ia_stream_t stream);
+int ia_cl_abs_accumulate(float* omega, const float* grad, int64_t n, ia_stream_t stream);
+int ia_adamw_step(float* theta, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int step, float grad_scale, void* shadow_bf16,
+                  ia_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -23,7 +23,14 @@ SIGNATURES = {
     "ia_version": (_c.c_char_p, []),
     "ia_rnnt_workspace_bytes": (_sz, [_i, _i, _i]),
     "ia_rnnt_loss": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _sz, _vp]),
+    "ia_rnnt_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _sz, _vp]),
+    "ia_rnnt_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
     "ia_rnnt_export_alphas_betas": (_i, [_vp, _sz, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "ia_cl_chunk_elems": (_i, []),
+    "ia_cl_penalty": (_i, [_vp, _vp, _vp, _f, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
+    "ia_cl_fisher_accumulate": (_i, [_vp, _vp, _vp, _i64, _vp]),
+    "ia_cl_abs_accumulate": (_i, [_vp, _vp, _i64, _vp]),
+    "ia_adamw_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f, _vp, _vp]),
 }
 
 _lib = None

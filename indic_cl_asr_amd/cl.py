@@ -1,0 +1,307 @@
+"""Continual-learning state and arithmetic on flat device buffers (EWC / MAS / LwF + AdamW + DP exchange).
+
+Reference call sites restated here (R/ = reference repo root):
+  get_params / get_params_clone / get_zero_params / get_grads / set_grads ... R/utils.py:273-321
+  get_penalty_grads (EWC) ............................................... R/cl_baseline_ewc.py:69-81
+  Fisher epoch ........................................................... R/cl_baseline_ewc.py:245-282
+  penalty (MAS) + importance epoch ...................................... R/cl_baseline_mas.py:70-75,212-288
+  LwF distillation ....................................................... R/cl_baseline_lwf.py:212-264
+  AdamW(lr) / zero_grad / step ........................................... R/cl_baseline.py:137,187-196
+
+MI355X design: every trainable parameter lives in ONE flat fp32 buffer (`FlatParams.theta`), `.grad`s are views
+of ONE flat gradient buffer, so the penalty, Fisher/omega accumulation, AdamW and the RCCL all-reduce are each
+a single launch / a single collective over ~N*4 bytes instead of ~300 per-tensor kernels.
+The dict-of-tensors API of the reference is kept: the dicts handed out are `FlatDict`s (name -> view).
+"""
+import math
+from contextlib import contextmanager
+from typing import Dict, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+_ALIGN = 64  # floats: every tensor starts on a 256-byte boundary inside the flat buffers
+
+
+class FlatDict(dict):
+    """name -> view into `.flat` (a 1-D fp32 device tensor laid out by `.layout`)."""
+
+    def __init__(self, layout: "FlatParams", flat: torch.Tensor):
+        super().__init__()
+        self.layout, self.flat = layout, flat
+        for name, off, numel, shape in layout.entries:
+            self[name] = flat[off:off + numel].view(shape)
+
+
+class FlatParams:
+    def __init__(self, model: torch.nn.Module):
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        if not named:
+            raise ValueError("model has no trainable parameters")
+        dev = named[0][1].device
+        self.model = model
+        self.entries, off = [], 0
+        for n, p in named:
+            if p.dtype != torch.float32:
+                raise TypeError(f"{n}: master parameters must be float32")
+            self.entries.append((n, off, p.numel(), tuple(p.shape)))
+            off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.numel = off
+        self.params = [p for _, p in named]
+        self.names = [n for n, _ in named]
+        self.theta = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        self._theta_views = FlatDict(self, self.theta)
+        self._grad_views = FlatDict(self, self.grad)
+        with torch.no_grad():
+            for (n, o, k, shape), p in zip(self.entries, self.params):
+                self._theta_views[n].copy_(p.data)
+                p.data = self._theta_views[n]
+                p.grad = self._grad_views[n]
+        # chunk table for ia_cl_penalty (chunks never straddle tensors)
+        ch = _lib.lib().ia_cl_chunk_elems() if dev.type == "cuda" else 4096
+        rows = []
+        for seg, (n, o, k, shape) in enumerate(self.entries):
+            for c0 in range(0, k, ch):
+                rows.append((o + c0, min(ch, k - c0), seg, 0))
+        self.chunk_table = torch.tensor(rows, dtype=torch.int32, device=dev)
+        self.seg_inv_numel = torch.tensor([1.0 / e[2] for e in self.entries], dtype=torch.float32, device=dev)
+        model._ia_flat = self
+
+    # -- buffers ---------------------------------------------------------------------------------
+    def zeros(self) -> FlatDict:
+        return FlatDict(self, torch.zeros_like(self.theta))
+
+    def clone_theta(self) -> FlatDict:
+        return FlatDict(self, self.theta.clone())
+
+    def params_dict(self) -> FlatDict:
+        return self._theta_views
+
+    def grads_dict(self) -> FlatDict:
+        return self._grad_views
+
+    def attach_grads(self):
+        for n, p in zip(self.names, self.params):
+            p.grad = self._grad_views[n]
+
+    def zero_grad(self):
+        self.grad.zero_()
+        self.attach_grads()
+
+    @contextmanager
+    def weights(self, other: FlatDict):
+        """Run with the parameters temporarily pointing at another flat buffer (LwF teacher forward) -- no
+        torch.save/torch.load ping-pong and no barriers (R/cl_baseline_lwf.py:220-234 does both per batch)."""
+        try:
+            for n, p in zip(self.names, self.params):
+                p.data = other[n]
+            yield
+        finally:
+            for n, p in zip(self.names, self.params):
+                p.data = self._theta_views[n]
+
+
+def flat_of(model) -> FlatParams:
+    m = getattr(model, "module", model)
+    f = getattr(m, "_ia_flat", None)
+    if f is None:
+        f = FlatParams(m)
+    return f
+
+
+# ----------------------------------------------------------------------------- R/utils.py:273-321 drop-ins
+def get_params(model) -> FlatDict:
+    return flat_of(model).params_dict()
+
+
+def get_params_clone(model) -> FlatDict:
+    return flat_of(model).clone_theta()
+
+
+def get_zero_params(model, device=None) -> FlatDict:
+    return flat_of(model).zeros()
+
+
+def get_grads(model) -> FlatDict:
+    return flat_of(model).grads_dict()
+
+
+def set_grads(model, grad_dict):
+    """R/utils.py:316-321.  A FlatDict produced by get_penalty_grads already IS the flat gradient buffer."""
+    f = flat_of(model)
+    if isinstance(grad_dict, FlatDict) and grad_dict.flat.data_ptr() != f.grad.data_ptr():
+        f.grad.copy_(grad_dict.flat)
+        grad_dict = f.grads_dict()
+    for name, p in getattr(model, "module", model).named_parameters():
+        p.grad = grad_dict[name] if name in grad_dict else None
+
+
+def save_model(model, path):
+    """R/utils.py:265-271: trainable-only state dict (same interchange format)."""
+    torch.save({n: p.data.clone() for n, p in getattr(model, "module", model).named_parameters() if p.requires_grad}, path)
+
+
+# ----------------------------------------------------------------------------- EWC
+def ewc_penalty_into_grads(flat: FlatParams, fisher: FlatDict, checkpoint: FlatDict, e_lambda: float,
+                           monitor_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """grad <- 2*lambda*F*(theta-theta*) (pre-load, autograd accumulates on top: R/cl_baseline_ewc.py:228-231);
+    returns a 0-dim device tensor = mean_k mean|penalty_k| (the 'ewc_penalty' monitor, :74-80)."""
+    L = _lib.lib()
+    seg = torch.zeros(len(flat.entries), dtype=torch.float32, device=flat.theta.device)
+    st = L.ia_cl_penalty(_lib.ptr(flat.theta), _lib.ptr(checkpoint.flat), _lib.ptr(fisher.flat), 2.0 * float(e_lambda),
+                         _lib.ptr(flat.grad), 0, _lib.ptr(flat.chunk_table), flat.chunk_table.shape[0],
+                         _lib.ptr(flat.seg_inv_numel), _lib.ptr(seg), None, _lib.stream_ptr())
+    _lib.check(st, "ia_cl_penalty")
+    flat.attach_grads()
+    return seg.mean()
+
+
+def get_penalty_grads(config, fish: FlatDict, curr_checkpoint: FlatDict, checkpoint: FlatDict):
+    """Signature of R/cl_baseline_ewc.py:69: returns (grad dict, python float)."""
+    flat = fish.layout
+    avg = ewc_penalty_into_grads(flat, fish, checkpoint, config.cl_config.e_lambda)
+    return flat.grads_dict(), avg.item()
+
+
+def fisher_accumulate(flat: FlatParams, fish: FlatDict, loss: torch.Tensor):
+    """fish += mean(loss) * grad**2 (R/cl_baseline_ewc.py:245-255), loss stays on the device."""
+    s = loss.detach().float().mean().reshape(1).contiguous()
+    st = _lib.lib().ia_cl_fisher_accumulate(_lib.ptr(fish.flat), _lib.ptr(flat.grad), _lib.ptr(s), flat.numel,
+                                            _lib.stream_ptr())
+    _lib.check(st, "ia_cl_fisher_accumulate")
+
+
+def fisher_finish(main_fish: Optional[FlatDict], fish: FlatDict, total_ds: int, e_gamma: float,
+                  group=None) -> FlatDict:
+    """fish /= N; main = gamma*main + fish (R/cl_baseline_ewc.py:267-280).  Under DP the rank-local Fisher sums and
+    sample counts are all-reduced first (one RCCL collective over the flat buffer) so the result equals the
+    1-GPU Fisher over the union of the shards (the reference keeps rank-local dicts)."""
+    n = torch.tensor([float(total_ds)], device=fish.flat.device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(fish.flat, group=group)
+        dist.all_reduce(n, group=group)
+    fish.flat.div_(n)
+    if main_fish is None:
+        return fish
+    main_fish.flat.mul_(e_gamma).add_(fish.flat)
+    return main_fish
+
+
+# ----------------------------------------------------------------------------- MAS
+def mas_penalty_add_grads(flat: FlatParams, importance: FlatDict, checkpoint: FlatDict, mas_lambda: float):
+    """Adds d/dtheta [mas_lambda * sum omega (theta-theta*)^2] to the flat gradient buffer and returns the
+    un-weighted penalty value as a 0-dim device tensor ('mass_loss', R/cl_baseline_mas.py:70-75,231-234).
+    The reference obtains the same gradient through autograd on `loss + mass_loss*mas_lambda`."""
+    val = torch.zeros(1, dtype=torch.float32, device=flat.theta.device)
+    st = _lib.lib().ia_cl_penalty(_lib.ptr(flat.theta), _lib.ptr(checkpoint.flat), _lib.ptr(importance.flat),
+                                  2.0 * float(mas_lambda), _lib.ptr(flat.grad), 1, _lib.ptr(flat.chunk_table),
+                                  flat.chunk_table.shape[0], None, None, _lib.ptr(val), _lib.stream_ptr())
+    _lib.check(st, "ia_cl_penalty")
+    return val[0]
+
+
+def penalty(model, main_importance: FlatDict, prev_params: FlatDict):
+    """Signature of R/cl_baseline_mas.py:70.  Returns the penalty VALUE (no autograd graph); pair it with
+    mas_penalty_add_grads() after backward, or use MASRegulariser which does both."""
+    flat = flat_of(model)
+    val = torch.zeros(1, dtype=torch.float32, device=flat.theta.device)
+    st = _lib.lib().ia_cl_penalty(_lib.ptr(flat.theta), _lib.ptr(prev_params.flat), _lib.ptr(main_importance.flat), 0.0,
+                                  None, 0, _lib.ptr(flat.chunk_table), flat.chunk_table.shape[0], None, None,
+                                  _lib.ptr(val), _lib.stream_ptr())
+    _lib.check(st, "ia_cl_penalty")
+    return val[0]
+
+
+def mas_importance_loss(model, mas_ctx: float):
+    """R/cl_baseline_mas.py:258-265 on the stashed raw logits (joint.store_list, ctc_decoder.decoder_logits)."""
+    m = getattr(model, "module", model)
+    decoder_logits = (m.ctc_decoder.decoder_logits.flatten(end_dim=-2).float() ** 2).sum(dim=-1).mean()
+    rnn_logits = 0
+    for i in m.joint.store_list:
+        rnn_logits = rnn_logits + (i.flatten(end_dim=-2).float() ** 2).sum(dim=-1).mean()
+    rnn_logits = rnn_logits / len(m.joint.store_list)
+    return rnn_logits * (1 - mas_ctx) + decoder_logits * mas_ctx
+
+
+def importance_accumulate(flat: FlatParams, importance: FlatDict):
+    st = _lib.lib().ia_cl_abs_accumulate(_lib.ptr(importance.flat), _lib.ptr(flat.grad), flat.numel, _lib.stream_ptr())
+    _lib.check(st, "ia_cl_abs_accumulate")
+
+
+def importance_finish(importance: FlatDict, n_batches: int, group=None) -> FlatDict:
+    """omega /= #batches (R/cl_baseline_mas.py:284-287; overwrites the previous task's omega as the reference
+    does).  Under DP: all-reduce(SUM) of omega and of the batch counts first."""
+    n = torch.tensor([float(n_batches)], device=importance.flat.device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(importance.flat, group=group)
+        dist.all_reduce(n, group=group)
+    importance.flat.div_(n)
+    return importance
+
+
+# ----------------------------------------------------------------------------- LwF
+def lwf_kd_loss(loss, prob, prob_, pred_store_list, store_list, knowledge_distillation: float, kd_ctx: float):
+    """R/cl_baseline_lwf.py:242-264.  Returns (total loss, rnnt_kd, ctc_kd) -- device tensors."""
+    F = torch.nn.functional
+    ctc_kd_loss = F.kl_div(prob, prob_.exp(), reduction='batchmean')
+    rnnt_kd = 0
+    for i, j in zip(store_list, pred_store_list):
+        rnnt_kd = rnnt_kd + F.kl_div(j, i.exp(), reduction='batchmean')
+    rnnt_kd = rnnt_kd / len(store_list)
+    total = loss * (1 - knowledge_distillation) + knowledge_distillation * ((1 - kd_ctx) * rnnt_kd + kd_ctx * ctc_kd_loss)
+    return total, rnnt_kd, ctc_kd_loss
+
+
+def lwf_teacher_forward(model, flat: FlatParams, teacher: FlatDict, batch, lang_ids, host_lengths=None):
+    """Teacher pass with the previous task's weights resident in HBM (R/cl_baseline_lwf.py:213-232 semantics:
+    no_grad, store_sub_enc + detach)."""
+    m = getattr(model, "module", model)
+    with torch.no_grad(), flat.weights(teacher):
+        m.joint.store_sub_enc, m.joint.detach_sub_enc = True, True
+        step = m._step
+        _, _, prob_ = m.training_step(batch, lang_ids, return_probs=True, host_lengths=host_lengths)
+        m._step = step  # same SpecAugment/dither draw for the student pass
+        store_list = m.joint.store_list
+    return prob_, store_list
+
+
+# ----------------------------------------------------------------------------- optimizer + DP
+class FusedAdamW:
+    """torch.optim.AdamW(model.parameters(), lr) of R/cl_baseline.py:137 as one launch over the flat buffers.
+    step() first averages the flat gradient across ranks (RCCL all-reduce over xGMI) when a process group
+    exists -- the reference wraps the model in DDP but never arms its reducer."""
+
+    def __init__(self, model_or_flat, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, group=None,
+                 bf16_shadow=False):
+        self.flat = model_or_flat if isinstance(model_or_flat, FlatParams) else flat_of(model_or_flat)
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.exp_avg = torch.zeros_like(self.flat.theta)
+        self.exp_avg_sq = torch.zeros_like(self.flat.theta)
+        self.step_count = 0
+        self.group = group
+        self.shadow = torch.zeros(self.flat.numel, dtype=torch.bfloat16, device=self.flat.theta.device) if bf16_shadow else None
+        self.param_groups = [dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, params=self.flat.params)]
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.flat.zero_grad()
+
+    def allreduce_grads(self):
+        if dist.is_available() and dist.is_initialized():
+            ws = dist.get_world_size(self.group)
+            if ws > 1:
+                dist.all_reduce(self.flat.grad, group=self.group)
+                return 1.0 / ws
+        return 1.0
+
+    def step(self, grad_scale: Optional[float] = None):
+        scale = self.allreduce_grads() * (1.0 if grad_scale is None else grad_scale)
+        self.step_count += 1
+        g = self.param_groups[0]
+        st = _lib.lib().ia_adamw_step(_lib.ptr(self.flat.theta), _lib.ptr(self.flat.grad), _lib.ptr(self.exp_avg),
+                                      _lib.ptr(self.exp_avg_sq), self.flat.numel, float(g["lr"]), float(g["betas"][0]),
+                                      float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), self.step_count,
+                                      float(scale), _lib.ptr(self.shadow), _lib.stream_ptr())
+        _lib.check(st, "ia_adamw_step")

@@ -1,0 +1,139 @@
+"""Model hyper-parameters and the reference's flat `config.yaml` (drop-in boundary).
+
+* ModelConfig carries what the reference gets from the `.nemo` checkpoint's model_config.yaml
+  (NeMo/examples/asr/conf/conformer/hybrid_transducer_ctc/conformer_hybrid_transducer_ctc_bpe.yaml:62-211,
+  size table conformer_transducer_bpe.yaml:8-18).
+* load_config()/override_config_with_args() keep R/config.yaml:1-44 parsing and the auto-generated
+  `--a.b.c value` CLI overrides of R/utils.py:77-116 (bools as true|false strings) without OmegaConf.
+"""
+import argparse
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import yaml
+
+LANGS22 = ['as', 'bn', 'brx', 'doi', 'gu', 'hi', 'kn', 'kok', 'ks', 'mai', 'ml', 'mni', 'mr', 'ne', 'or', 'pa', 'sa',
+           'sat', 'sd', 'ta', 'te', 'ur']
+
+
+@dataclass
+class ModelConfig:
+    # encoder (yaml :88-128)
+    feat_in: int = 80
+    d_model: int = 256
+    n_layers: int = 16
+    n_heads: int = 4
+    ff_expansion_factor: int = 4
+    conv_kernel_size: int = 31
+    pos_emb_max_len: int = 5000
+    dropout: float = 0.1
+    dropout_pre_encoder: float = 0.1
+    dropout_emb: float = 0.0
+    dropout_att: float = 0.1
+    # prediction / joint (yaml :130-158)
+    pred_hidden: int = 640
+    joint_hidden: int = 640
+    pred_dropout: float = 0.2
+    joint_dropout: float = 0.2
+    fused_batch_size: int = 4
+    # multilingual heads (AI4Bharat fork: 22 x 256 tokens, hybrid_rnnt_ctc_bpe_models.py:100-170)
+    languages: List[str] = field(default_factory=lambda: list(LANGS22))
+    vocab_per_lang: int = 256
+    ctc_loss_weight: float = 0.3
+    # preprocessor / SpecAugment (yaml :63-81)
+    sample_rate: int = 16000
+    n_window_size: int = 400
+    n_window_stride: int = 160
+    n_fft: int = 512
+    preemph: float = 0.97
+    dither: float = 1e-5
+    pad_to: int = 0
+    freq_masks: int = 2
+    time_masks: int = 10
+    freq_width: int = 27
+    time_width: float = 0.05
+    # loss (yaml :186-192)
+    fastemit_lambda: float = 0.0
+    clamp: float = -1.0
+    # MI355X compute dtype for the dense projections ("bf16" | "fp32"); losses, norms and softmax stay fp32
+    compute_dtype: str = "bf16"
+
+    @property
+    def d_ff(self):
+        return self.d_model * self.ff_expansion_factor
+
+    @property
+    def d_head(self):
+        return self.d_model // self.n_heads
+
+
+PRESETS = {
+    # BASELINE.json configs[0]: d=144 "small" of the task statement (NeMo's own small is d=176)
+    "small": dict(d_model=144, n_layers=16, n_heads=4, pred_hidden=320, joint_hidden=320),
+    "medium": dict(d_model=256, n_layers=16, n_heads=4, pred_hidden=640, joint_hidden=640),
+    "large": dict(d_model=512, n_layers=18, n_heads=8, pred_hidden=640, joint_hidden=640),
+    # the checkpoint the reference actually fine-tunes (IndicConformerASR.ipynb cell 32)
+    "ai4b_large": dict(d_model=512, n_layers=17, n_heads=8, pred_hidden=640, joint_hidden=640),
+    "tiny": dict(d_model=32, n_layers=2, n_heads=4, pred_hidden=24, joint_hidden=24, languages=['hi', 'ta'],
+                 vocab_per_lang=16, fused_batch_size=2),
+}
+
+
+def model_config(preset="medium", **overrides) -> ModelConfig:
+    kw = dict(PRESETS[preset])
+    kw.update(overrides)
+    return ModelConfig(**kw)
+
+
+# ------------------------------------------------------------------------------------------- config.yaml
+class AttrDict(dict):
+    """Attribute access over nested dicts (the subset of OmegaConf behaviour the CL scripts use)."""
+
+    def __getattr__(self, k):
+        try:
+            v = self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+        return v
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def _wrap(node):
+    if isinstance(node, dict):
+        return AttrDict({k: _wrap(v) for k, v in node.items()})
+    return node
+
+
+def load_config(path="config.yaml") -> AttrDict:
+    with open(path) as f:
+        return _wrap(yaml.safe_load(f))
+
+
+def override_config_with_args(cfg, argv: Optional[List[str]] = None):
+    """R/utils.py:77-116: one `--a.b.c` flag per scalar leaf, bools parsed from true|false."""
+    parser = argparse.ArgumentParser()
+
+    def register(prefix, node):
+        for key, value in node.items():
+            full = f"{prefix}.{key}" if prefix else key
+            if isinstance(value, bool):
+                parser.add_argument(f"--{full}", type=str, choices=["true", "false"])
+            elif isinstance(value, (int, float, str)):
+                parser.add_argument(f"--{full}", type=type(value))
+            elif isinstance(value, dict):
+                register(full, value)
+
+    register("", cfg)
+    args, _ = parser.parse_known_args(argv)
+    for full, val in vars(args).items():
+        if val is None:
+            continue
+        parts = full.split(".")
+        sub = cfg
+        for p in parts[:-1]:
+            sub = sub[p]
+        orig = type(sub[parts[-1]])
+        sub[parts[-1]] = (val.lower() == "true") if orig is bool else orig(val)
+    return cfg

@@ -1,6 +1,7 @@
 // Shared device/host helpers for libindicasr_hip.so (gfx950 / CDNA4 only, wave = 64).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
 #include <math.h>
 #include <stddef.h>
 #include <stdint.h>

@@ -269,7 +269,8 @@ __global__ __launch_bounds__(256) void rnnt_cell_scalars(
     const float* __restrict__ denom, const float* __restrict__ PB, const float* __restrict__ PL,
     const float* __restrict__ ALPHA, const float* __restrict__ BETA, const float* __restrict__ ll,
     const int64_t* __restrict__ labels, const int64_t* __restrict__ act_lens, const int64_t* __restrict__ label_lens,
-    int B, int T, int U1, int rows, int U1s, float fastemit, float4* __restrict__ cs) {
+    int B, int T, int U1, int rows, int U1s, float fastemit, const float* __restrict__ cost_grad,
+    float4* __restrict__ cs) {
     const int64_t cells = (int64_t)B * T * U1;
     const float l1p = log1pf(fastemit);
     for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < cells; c += (int64_t)gridDim.x * 256) {
@@ -277,8 +278,10 @@ __global__ __launch_bounds__(256) void rnnt_cell_scalars(
         const int64_t bt = c / U1;
         const int t = (int)(bt % T), b = (int)(bt / T);
         const int Tb = (int)act_lens[b], Ub = (int)label_lens[b] + 1;
-        float4 o = make_float4(IA_NEG_INF, 0.f, 0.f, __int_as_float(-1));
-        if (t < Tb && u < Ub) {
+        // .w = (label+1) | sign bit of the upstream cost gradient; .x = -inf marks "writes zeros"
+        float4 o = make_float4(IA_NEG_INF, 0.f, 0.f, __int_as_float(0));
+        const float sg = cost_grad ? cost_grad[b] : 1.f;
+        if (t < Tb && u < Ub && sg != 0.f) {
             const size_t row = ((size_t)b * rows + RNNT_GUARD + (t + u)) * U1s;
             const float a = ALPHA[row + u], be = BETA[row + u], L = ll[b];
             const float lpb = PB[row + u];
@@ -291,9 +294,13 @@ __global__ __launch_bounds__(256) void rnnt_cell_scalars(
                 el = __expf(l1p + a + lpl - L + bu1);
                 if (fastemit > 0.f)
                     c0 = denom[c] + __logf(__expf(a + be - L) + fastemit * __expf(a + lpl + bu1 - L));
-                o.w = __int_as_float((int)labels[(int64_t)b * (U1 - 1) + u]);
+                o.w = __int_as_float((int)labels[(int64_t)b * (U1 - 1) + u] + 1);
             }
-            o.x = c0; o.y = eb; o.z = el;
+            // upstream gradient folded in: |s| into the three magnitudes (c0 is an exponent), sign into .w
+            const float as = fabsf(sg);
+            o.x = (as == 1.f) ? c0 : c0 + __logf(as);
+            o.y = eb * as; o.z = el * as;
+            if (sg < 0.f) o.w = __int_as_float(__float_as_int(o.w) | 0x80000000);
         }
         cs[c] = o;
     }
@@ -305,10 +312,11 @@ constexpr int K3_CELLS = 64;  // cells per block iteration: 64*V floats, 16-byte
 
 __device__ __forceinline__ float grad_elem(float x, int v, const float4& s, int blank, float clamp) {
     float g = __expf(x + s.x);
+    const int w = __float_as_int(s.w);
     if (v == blank) g -= s.y;
-    if (v == __float_as_int(s.w)) g -= s.z;
-    if (clamp > 0.f) g = fminf(fmaxf(g, -clamp), clamp);
-    return g;
+    if (v + 1 == (w & 0x7fffffff)) g -= s.z;
+    if (clamp > 0.f) g = fminf(fmaxf(g, -clamp), clamp);  // only reachable with cost_grad == NULL (|s| = 1)
+    return (w < 0) ? -g : g;
 }
 
 __global__ __launch_bounds__(K3_THREADS) void rnnt_grad(const float* logits, float* grads,
@@ -405,23 +413,28 @@ extern "C" size_t ia_rnnt_workspace_bytes(int B, int T, int U1) {
     return w.total;
 }
 
-extern "C" int ia_rnnt_loss(const float* logits, const int64_t* labels, const int64_t* act_lens,
-                            const int64_t* label_lens, int B, int T, int U1, int V, int blank, float fastemit,
-                            float clamp, float* costs, float* grads, void* workspace, size_t workspace_bytes,
-                            ia_stream_t stream) {
-    if (!logits || !act_lens || !label_lens || !costs || !workspace) return IA_INVALID_VALUE;
+static int rnnt_check(const float* logits, const int64_t* labels, const int64_t* act_lens, const int64_t* label_lens,
+                      int B, int T, int U1, int V, int blank, const void* workspace, size_t workspace_bytes, RnntWs* w) {
+    if (!logits || !act_lens || !label_lens || !workspace) return IA_INVALID_VALUE;
     if (B <= 0 || T <= 0 || U1 <= 0 || V < 1 || blank < 0 || blank >= V) return IA_INVALID_VALUE;
     if ((int64_t)B * T * U1 >= (int64_t)1 << 31) return IA_UNSUPPORTED;
     if (U1 > 1 && !labels) return IA_INVALID_VALUE;
-    if (!ia_is_aligned(logits, 16) || (grads && !ia_is_aligned(grads, 16)) || !ia_is_aligned(workspace, 256))
-        return IA_INVALID_VALUE;
+    if (!ia_is_aligned(logits, 16) || !ia_is_aligned(workspace, 256)) return IA_INVALID_VALUE;
+    if (!rnnt_ws_layout(B, T, U1, w)) return IA_UNSUPPORTED;
+    if (workspace_bytes < w->total) return IA_WORKSPACE_TOO_SMALL;
+    return IA_OK;
+}
+
+extern "C" int ia_rnnt_forward(const float* logits, const int64_t* labels, const int64_t* act_lens,
+                               const int64_t* label_lens, int B, int T, int U1, int V, int blank, float fastemit,
+                               int need_backward, float* costs, void* workspace, size_t workspace_bytes,
+                               ia_stream_t stream) {
     RnntWs w;
-    if (!rnnt_ws_layout(B, T, U1, &w)) return IA_UNSUPPORTED;
-    if (workspace_bytes < w.total) return IA_WORKSPACE_TOO_SMALL;
+    if (!costs) return IA_INVALID_VALUE;
+    const int rc = rnnt_check(logits, labels, act_lens, label_lens, B, T, U1, V, blank, workspace, workspace_bytes, &w);
+    if (rc != IA_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     char* ws = (char*)workspace;
-    const int64_t cells = (int64_t)B * T * U1;
-
     // K1: one workgroup per (b,t) frame, waves stride over the label axis
     {
         K1Out o{(float*)(ws + w.off_denom), (float*)(ws + w.off_pb), (float*)(ws + w.off_pl), (float*)(ws + w.off_pla),
@@ -443,8 +456,7 @@ extern "C" int ia_rnnt_loss(const float* logits, const int64_t* labels, const in
 #undef IA_K1
     }
     IA_RETURN_IF_LAUNCH_FAILED();
-
-    const int with_beta = grads ? 1 : 0;
+    const int with_beta = need_backward ? 1 : 0;
     switch (w.K) {
         case 1: launch_alpha_beta<1>(w, ws, act_lens, label_lens, B, with_beta, st); break;
         case 2: launch_alpha_beta<2>(w, ws, act_lens, label_lens, B, with_beta, st); break;
@@ -456,20 +468,46 @@ extern "C" int ia_rnnt_loss(const float* logits, const int64_t* labels, const in
     hipLaunchKernelGGL(rnnt_costs, dim3((B + 255) / 256), dim3(256), 0, st, (const float*)(ws + w.off_ll), B, fastemit,
                        costs);
     IA_RETURN_IF_LAUNCH_FAILED();
-    if (!grads) return IA_OK;
+    return IA_OK;
+}
 
+extern "C" int ia_rnnt_backward(const float* logits, const int64_t* labels, const int64_t* act_lens,
+                                const int64_t* label_lens, int B, int T, int U1, int V, int blank, float fastemit,
+                                float clamp, const float* cost_grad, float* grads, void* workspace,
+                                size_t workspace_bytes, ia_stream_t stream, void* ev_start, void* ev_stop) {
+    RnntWs w;
+    if (!grads || !ia_is_aligned(grads, 16)) return IA_INVALID_VALUE;
+    if (clamp > 0.f && cost_grad) return IA_INVALID_VALUE;  // clamp acts on the un-scaled gradient: scale afterwards
+    const int rc = rnnt_check(logits, labels, act_lens, label_lens, B, T, U1, V, blank, workspace, workspace_bytes, &w);
+    if (rc != IA_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    const int64_t cells = (int64_t)B * T * U1;
     const int gridc = (int)((cells + 255) / 256 < 4096 ? (cells + 255) / 256 : 4096);
     hipLaunchKernelGGL(rnnt_cell_scalars, dim3(gridc), dim3(256), 0, st, (const float*)(ws + w.off_denom),
                        (const float*)(ws + w.off_pb), (const float*)(ws + w.off_pl), (const float*)(ws + w.off_alpha),
                        (const float*)(ws + w.off_beta), (const float*)(ws + w.off_ll), labels, act_lens, label_lens, B,
-                       T, U1, w.rows, w.U1s, fastemit, (float4*)(ws + w.off_cs));
+                       T, U1, w.rows, w.U1s, fastemit, cost_grad, (float4*)(ws + w.off_cs));
     IA_RETURN_IF_LAUNCH_FAILED();
     const int64_t nchunks3 = (cells + K3_CELLS - 1) / K3_CELLS;
     const int grid3 = (int)(nchunks3 < 8192 ? nchunks3 : 8192);
+    if (ev_start && hipEventRecord((hipEvent_t)ev_start, st) != hipSuccess) return IA_LAUNCH_FAILED;
     hipLaunchKernelGGL(rnnt_grad, dim3(grid3), dim3(K3_THREADS), 0, st, logits, grads, (const float4*)(ws + w.off_cs),
                        cells, V, blank, clamp);
     IA_RETURN_IF_LAUNCH_FAILED();
+    if (ev_stop && hipEventRecord((hipEvent_t)ev_stop, st) != hipSuccess) return IA_LAUNCH_FAILED;
     return IA_OK;
+}
+
+extern "C" int ia_rnnt_loss(const float* logits, const int64_t* labels, const int64_t* act_lens,
+                            const int64_t* label_lens, int B, int T, int U1, int V, int blank, float fastemit,
+                            float clamp, float* costs, float* grads, void* workspace, size_t workspace_bytes,
+                            ia_stream_t stream) {
+    int rc = ia_rnnt_forward(logits, labels, act_lens, label_lens, B, T, U1, V, blank, fastemit, grads ? 1 : 0, costs,
+                             workspace, workspace_bytes, stream);
+    if (rc != IA_OK || !grads) return rc;
+    return ia_rnnt_backward(logits, labels, act_lens, label_lens, B, T, U1, V, blank, fastemit, clamp, nullptr, grads,
+                            workspace, workspace_bytes, stream, nullptr, nullptr);
 }
 
 extern "C" int ia_rnnt_export_alphas_betas(const void* workspace, size_t workspace_bytes, const int64_t* act_lens,

@@ -1,0 +1,228 @@
+"""Prediction network, joint network (fused joint+loss per sub-batch) and the CTC head, with the reference's
+module tree / parameter names (A/modules/rnnt.py:524-792,1175-1710; A/modules/conv_asr.py:402-490;
+C/parts/rnn.py:151-235,536-561).
+"""
+from contextlib import nullcontext
+from typing import List
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def label_collate(labels, device=None):
+    """C/parts/rnn.py:536-561: list of label lists / tensor -> padded int64 [B,U] (pad 0.0)."""
+    if isinstance(labels, torch.Tensor):
+        return labels.type(torch.int64)
+    if not isinstance(labels, (list, tuple)):
+        raise ValueError(f"`labels` should be a list or tensor not {type(labels)}")
+    B = len(labels)
+    U = max(len(l) for l in labels)
+    out = torch.zeros((B, U), dtype=torch.int64, device=device)
+    for e, l in enumerate(labels):
+        out[e, :len(l)] = torch.as_tensor(l, dtype=torch.int64)
+    return out
+
+
+class LSTMDropout(nn.Module):
+    def __init__(self, input_size, hidden_size, dropout, forget_gate_bias=1.0):
+        super().__init__()
+        self.lstm = nn.LSTM(input_size=input_size, hidden_size=hidden_size, num_layers=1)
+        with torch.no_grad():  # C/parts/rnn.py:212-219
+            self.lstm.bias_ih_l0[hidden_size:2 * hidden_size].fill_(forget_gate_bias)
+            self.lstm.bias_hh_l0[hidden_size:2 * hidden_size] *= 0.0
+        self.dropout = nn.Dropout(dropout) if dropout else None
+
+    def forward(self, x, h=None):
+        x, h = self.lstm(x, h)
+        if self.dropout:
+            x = self.dropout(x)
+        return x, h
+
+
+class RNNTDecoder(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        vocab = len(cfg.languages) * cfg.vocab_per_lang
+        self.pred_hidden = cfg.pred_hidden
+        self.blank_idx = vocab
+        self.blank_as_pad = True
+        self.prediction = nn.ModuleDict({
+            "embed": nn.Embedding(vocab + 1, cfg.pred_hidden, padding_idx=vocab),
+            "dec_rnn": LSTMDropout(cfg.pred_hidden, cfg.pred_hidden, cfg.pred_dropout),
+        })
+
+    def predict(self, y=None, state=None, add_sos=True, batch_size=None):
+        p = next(self.parameters())
+        if y is not None:
+            y = self.prediction["embed"](y.to(p.device))
+        else:
+            B = batch_size if batch_size is not None else (1 if state is None else state[0].size(1))
+            y = torch.zeros((B, 1, self.pred_hidden), device=p.device, dtype=p.dtype)
+        if add_sos:
+            B, U, H = y.shape
+            y = torch.cat([torch.zeros((B, 1, H), device=y.device, dtype=y.dtype), y], dim=1).contiguous()
+        g, hid = self.prediction["dec_rnn"](y.transpose(0, 1), state)
+        return g.transpose(0, 1), hid
+
+    def forward(self, targets, target_length, states=None):
+        y = label_collate(targets)
+        g, states = self.predict(y, state=states, add_sos=True)  # (B, U+1, H)
+        return g.transpose(1, 2), target_length, states          # (B, H, U+1)
+
+
+class RNNTJoint(nn.Module):
+    """joint_net = [ReLU, Dropout, ModuleDict{lang: Linear(H, 257)}] exactly as rnnt.py:1694-1703 so parameter
+    names match (`joint.joint_net.2.hi.weight`)."""
+
+    def __init__(self, cfg, loss=None):
+        super().__init__()
+        self.cfg = cfg
+        self.pred = nn.Linear(cfg.pred_hidden, cfg.joint_hidden)
+        self.enc = nn.Linear(cfg.d_model, cfg.joint_hidden)
+        final = nn.ModuleDict({l: nn.Linear(cfg.joint_hidden, cfg.vocab_per_lang + 1) for l in cfg.languages})
+        layers = [nn.ReLU(inplace=True)] + ([nn.Dropout(p=cfg.joint_dropout)] if cfg.joint_dropout else []) + [final]
+        self.joint_net = nn.Sequential(*layers)
+        self._fused_batch_size = cfg.fused_batch_size
+        self._loss = loss
+        self._fuse_loss_wer = True
+        self.store_sub_enc = False
+        self.store_sub_logits = False
+        self.detach_sub_enc = False
+        self.store_list: List[torch.Tensor] = []
+        self.temp_logits = None
+
+    @property
+    def loss(self):
+        return self._loss
+
+    def set_loss(self, loss):
+        self._loss = loss
+
+    @property
+    def fused_batch_size(self):
+        return self._fused_batch_size
+
+    def set_fused_batch_size(self, n):
+        self._fused_batch_size = n
+
+    def project_encoder(self, x):
+        return self.enc(x)
+
+    def project_prednet(self, x):
+        return self.pred(x)
+
+    def joint_after_projection(self, f, g, language_ids=None):
+        inp = f.unsqueeze(2) + g.unsqueeze(1)  # [B,T,U,H]
+        for m in self.joint_net[:-1]:
+            inp = m(inp)
+        heads = self.joint_net[-1]
+        if language_ids is None:
+            raise ValueError("language_ids are required by the multilingual joint (rnnt.py:1624-1640)")
+        if len(set(language_ids)) == 1:
+            res = heads[language_ids[0]](inp)
+        else:
+            res = torch.stack([heads[l](x) for x, l in zip(inp, language_ids)])
+        if self.store_sub_logits:
+            self.temp_logits = res.clone()
+        return res  # raw logits: the accelerator branch of rnnt.py:1651-1656
+
+    def joint(self, f, g, language_ids=None):
+        return self.joint_after_projection(self.project_encoder(f), self.project_prednet(g), language_ids)
+
+    def forward(self, encoder_outputs, decoder_outputs, encoder_lengths=None, transcripts=None,
+                transcript_lengths=None, compute_wer=False, language_ids=None, host_lengths=None):
+        """Fused joint + loss over sub-batches (rnnt.py:1403-1561).  Returns (loss, wer, wer_num, wer_denom);
+        `host_lengths` = (enc_lens list, tgt_lens list) lets the loop narrow each sub-batch without a
+        device->host sync (the reference calls .max() on device tensors per sub-batch, :1440-1441)."""
+        enc = encoder_outputs.transpose(1, 2)
+        dec = decoder_outputs.transpose(1, 2)
+        if (encoder_lengths is None) or (transcript_lengths is None):
+            raise ValueError("`fuse_loss_wer` is set, therefore encoder and target lengths must be provided as well!")
+        if self._loss is None:
+            raise ValueError("`fuse_loss_wer` flag is set, but `loss` and `wer` modules were not provided! ")
+        if host_lengths is None:
+            host_lengths = (encoder_lengths.tolist(), transcript_lengths.tolist())
+        h_enc, h_tgt = host_lengths
+        B = int(enc.size(0))
+        amp = (torch.autocast(device_type="cuda", dtype=torch.bfloat16)
+               if self.cfg.compute_dtype == "bf16" and enc.is_cuda else nullcontext())
+        losses, target_lengths, stash = [], [], []
+        for begin in range(0, B, self._fused_batch_size):
+            end = min(begin + self._fused_batch_size, B)
+            max_t = max(h_enc[begin:end])
+            max_u = max(h_tgt[begin:end])
+            sub_enc = enc[begin:end, :max_t]
+            sub_dec = dec[begin:end, :max_u + 1]
+            sub_tr = transcripts[begin:end, :max_u]
+            with amp:
+                sub_joint = self.joint(sub_enc, sub_dec, language_ids=language_ids[begin:end])
+            if self.store_sub_enc:
+                stash.append(sub_joint.detach().clone() if self.detach_sub_enc else sub_joint.clone())
+            if self.store_sub_logits:
+                lg = self.temp_logits
+                stash.append(lg.detach().clone() if self.detach_sub_enc else lg.clone())
+            red = self._loss.reduction
+            self._loss.reduction = None
+            loss_batch = self._loss(log_probs=sub_joint, targets=sub_tr, input_lengths=encoder_lengths[begin:end],
+                                    target_lengths=transcript_lengths[begin:end], max_T=max_t, max_U=max_u)
+            self._loss.reduction = red
+            losses.append(loss_batch)
+            target_lengths.append(transcript_lengths[begin:end])
+        losses = self._loss.reduce(losses, target_lengths)
+        if self.store_sub_enc or self.store_sub_logits:
+            self.store_list = stash
+        return losses, None, None, None
+
+
+class ConvASRDecoder(nn.Module):
+    """Parameter layout of the reference (Conv1d(d -> n_lang*256+1, k=1), conv_asr.py:445) but the projection
+    touches only the batch language's 257 rows: the reference computes all 5633 columns and masked_selects
+    (:469-480), 22x wasted FLOPs and an H2D mask copy per call."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self.vocab_per_lang = cfg.vocab_per_lang
+        n = len(cfg.languages) * cfg.vocab_per_lang + 1
+        self._num_classes = n
+        self.decoder_layers = nn.Sequential(nn.Conv1d(cfg.d_model, n, kernel_size=1, bias=True))
+        nn.init.xavier_uniform_(self.decoder_layers[0].weight, gain=1.0)
+        self.lang_index = {l: i for i, l in enumerate(cfg.languages)}
+        self.language_masks = {}
+        for l, i in self.lang_index.items():
+            m = [False] * n
+            m[i * cfg.vocab_per_lang:(i + 1) * cfg.vocab_per_lang] = [True] * cfg.vocab_per_lang
+            m[-1] = True
+            self.language_masks[l] = m
+        self.return_logits_ = False
+        self.decoder_logits = None
+        self.temperature = 1.0
+
+    def _rows(self, lang, device):
+        i = self.lang_index[lang]
+        v = self.vocab_per_lang
+        return torch.cat([torch.arange(i * v, (i + 1) * v, device=device), torch.tensor([self._num_classes - 1], device=device)])
+
+    def forward(self, encoder_output, language_ids=None):
+        w = self.decoder_layers[0].weight.squeeze(-1)  # [n, d]
+        b = self.decoder_layers[0].bias
+        x = encoder_output.transpose(1, 2)  # [B,T,d]
+        amp = (torch.autocast(device_type="cuda", dtype=torch.bfloat16)
+               if self.cfg.compute_dtype == "bf16" and x.is_cuda else nullcontext())
+        with amp:
+            if language_ids is None:
+                out = F.linear(x, w, b)
+            elif len(set(language_ids)) == 1:
+                rows = self._rows(language_ids[0], x.device)
+                out = F.linear(x, w.index_select(0, rows), b.index_select(0, rows))
+            else:
+                out = torch.stack([F.linear(xi, w.index_select(0, self._rows(l, x.device)),
+                                            b.index_select(0, self._rows(l, x.device)))
+                                   for xi, l in zip(x, language_ids)])
+        out = out.float()
+        if self.temperature != 1.0:
+            out = out / self.temperature
+        if self.return_logits_:
+            self.decoder_logits = out.clone()
+        return F.log_softmax(out, dim=-1)

@@ -1,0 +1,186 @@
+"""Conformer encoder with the reference's module tree and parameter names (A/modules/conformer_encoder.py:259-662,
+A/parts/submodules/{conformer_modules,multi_head_attention,subsampling}.py) on MI355X.
+
+Differences in HOW (not WHAT): no [B,T',T'] mask tensor and no all_reduce(MAX)+.item() per forward
+(conformer_encoder.py:664-675) -- lengths only; rel-shift is index arithmetic; frame counts are integers;
+dense projections run in cfg.compute_dtype on the matrix cores, norms/softmax/BN in fp32.
+"""
+import math
+from contextlib import nullcontext
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+
+def subsampled_length(n):
+    """Two stride-2 k=3 p=1 convolutions: floor((n-1)/2)+1 twice == subsampling.py:566-576 (float32 there;
+    equality for every n up to 30 s is asserted in tests/test_oracle_step.py::test_frame_count_rule)."""
+    n = (n - 1) // 2 + 1
+    return (n - 1) // 2 + 1
+
+
+class ConvSubsampling(nn.Module):
+    def __init__(self, feat_in, feat_out, conv_channels):
+        super().__init__()
+        self.conv = nn.Sequential(nn.Conv2d(1, conv_channels, 3, 2, 1), nn.ReLU(True),
+                                  nn.Conv2d(conv_channels, conv_channels, 3, 2, 1), nn.ReLU(True))
+        self.out = nn.Linear(conv_channels * subsampled_length(feat_in), feat_out)
+
+    def forward(self, x, lengths):
+        lengths = subsampled_length(lengths)
+        x = self.conv(x.unsqueeze(1))
+        b, c, t, f = x.size()
+        x = self.out(x.transpose(1, 2).reshape(b, t, -1))
+        return x, lengths
+
+
+class RelPositionalEncoding(nn.Module):
+    """multi_head_attention.py:935-979: table row r <-> relative position (Lmax-1-r)."""
+
+    def __init__(self, d_model, max_len, xscale, dropout_rate, dropout_rate_emb=0.0):
+        super().__init__()
+        self.d_model, self.xscale, self.max_len = d_model, xscale, max_len
+        self.dropout = nn.Dropout(dropout_rate)
+        self.dropout_emb = nn.Dropout(dropout_rate_emb) if dropout_rate_emb > 0 else None
+        self.register_buffer("pe", self._table(max_len), persistent=False)
+
+    def _table(self, length):
+        positions = torch.arange(length - 1, -length, -1, dtype=torch.float32).unsqueeze(1)
+        div_term = torch.exp(torch.arange(0, self.d_model, 2, dtype=torch.float32) * -(math.log(10000.0) / self.d_model))
+        pe = torch.zeros(positions.size(0), self.d_model)
+        pe[:, 0::2] = torch.sin(positions * div_term)
+        pe[:, 1::2] = torch.cos(positions * div_term)
+        return pe.unsqueeze(0)
+
+    def extend_pe(self, length, device):
+        if self.pe.size(1) < 2 * length - 1:
+            self.pe = self._table(length).to(device)
+
+    def forward(self, x):
+        if self.xscale:
+            x = x * self.xscale
+        T = x.size(1)
+        centre = self.pe.size(1) // 2 + 1
+        pos_emb = self.pe[:, centre - T: centre + T - 1]
+        if self.dropout_emb is not None:
+            pos_emb = self.dropout_emb(pos_emb)
+        return self.dropout(x), pos_emb
+
+
+class RelPositionMultiHeadAttention(nn.Module):
+    def __init__(self, n_head, n_feat, dropout_rate):
+        super().__init__()
+        self.d_k, self.h = n_feat // n_head, n_head
+        self.linear_q = nn.Linear(n_feat, n_feat)
+        self.linear_k = nn.Linear(n_feat, n_feat)
+        self.linear_v = nn.Linear(n_feat, n_feat)
+        self.linear_out = nn.Linear(n_feat, n_feat)
+        self.linear_pos = nn.Linear(n_feat, n_feat, bias=False)
+        self.pos_bias_u = nn.Parameter(torch.zeros(self.h, self.d_k))
+        self.pos_bias_v = nn.Parameter(torch.zeros(self.h, self.d_k))
+        self.dropout_rate = dropout_rate
+
+    def forward(self, x, lens, pos_emb):
+        B, T, _ = x.shape
+        q = self.linear_q(x).view(B, T, self.h, self.d_k).transpose(1, 2)
+        k = self.linear_k(x).view(B, T, self.h, self.d_k).transpose(1, 2)
+        v = self.linear_v(x).view(B, T, self.h, self.d_k).transpose(1, 2)
+        p = self.linear_pos(pos_emb.to(x.dtype)).view(-1, self.h, self.d_k).transpose(0, 1)  # [h,2T-1,dk]
+        ctx = ops.rel_pos_attention(q, k, v, p, self.pos_bias_u, self.pos_bias_v, lens, self.dropout_rate, self.training)
+        return self.linear_out(ctx.transpose(1, 2).reshape(B, T, self.h * self.d_k))
+
+
+class ConformerFeedForward(nn.Module):
+    def __init__(self, d_model, d_ff, dropout):
+        super().__init__()
+        self.linear1 = nn.Linear(d_model, d_ff)
+        self.dropout = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(d_ff, d_model)
+
+    def forward(self, x):
+        return self.linear2(self.dropout(F.silu(self.linear1(x))))
+
+
+class CausalConv1D(nn.Conv1d):
+    """Parameter holder with the reference's name (depthwise_conv.weight/bias); the arithmetic runs in
+    ops.glu_dwconv_bn_silu."""
+
+    def __init__(self, ch, k):
+        super().__init__(ch, ch, k, stride=1, padding=0, groups=ch, bias=True)
+
+
+class ConformerConvolution(nn.Module):
+    def __init__(self, d_model, kernel_size):
+        super().__init__()
+        self.pointwise_conv1 = nn.Conv1d(d_model, d_model * 2, 1)
+        self.depthwise_conv = CausalConv1D(d_model, kernel_size)
+        self.batch_norm = nn.BatchNorm1d(d_model)
+        self.pointwise_conv2 = nn.Conv1d(d_model, d_model, 1)
+
+    def forward(self, x, pad_mask):
+        # k=1 convolutions are plain projections over the feature axis: keep [B,T,d] and skip two transposes
+        x2 = F.linear(x, self.pointwise_conv1.weight.squeeze(-1), self.pointwise_conv1.bias).transpose(1, 2)
+        y = ops.glu_dwconv_bn_silu(x2, pad_mask, self.depthwise_conv.weight, self.depthwise_conv.bias, self.batch_norm,
+                                   self.training)
+        y = y.transpose(1, 2).to(x.dtype)
+        return F.linear(y, self.pointwise_conv2.weight.squeeze(-1), self.pointwise_conv2.bias)
+
+
+class ConformerLayer(nn.Module):
+    def __init__(self, d_model, d_ff, n_heads, conv_kernel_size, dropout, dropout_att):
+        super().__init__()
+        self.fc_factor = 0.5
+        self.norm_feed_forward1 = nn.LayerNorm(d_model)
+        self.feed_forward1 = ConformerFeedForward(d_model, d_ff, dropout)
+        self.norm_conv = nn.LayerNorm(d_model)
+        self.conv = ConformerConvolution(d_model, conv_kernel_size)
+        self.norm_self_att = nn.LayerNorm(d_model)
+        self.self_attn = RelPositionMultiHeadAttention(n_heads, d_model, dropout_att)
+        self.norm_feed_forward2 = nn.LayerNorm(d_model)
+        self.feed_forward2 = ConformerFeedForward(d_model, d_ff, dropout)
+        self.dropout = nn.Dropout(dropout)
+        self.norm_out = nn.LayerNorm(d_model)
+
+    def forward(self, x, lens, pos_emb, pad_mask):
+        residual = x
+        residual = residual + self.dropout(self.feed_forward1(self.norm_feed_forward1(x))) * self.fc_factor
+        residual = residual + self.dropout(self.self_attn(self.norm_self_att(residual), lens, pos_emb))
+        residual = residual + self.dropout(self.conv(self.norm_conv(residual), pad_mask))
+        residual = residual + self.dropout(self.feed_forward2(self.norm_feed_forward2(residual))) * self.fc_factor
+        return self.norm_out(residual)
+
+
+class ConformerEncoder(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        d = cfg.d_model
+        self.d_model = d
+        self.pre_encode = ConvSubsampling(cfg.feat_in, d, d)
+        self.pos_enc = RelPositionalEncoding(d, cfg.pos_emb_max_len, math.sqrt(d), cfg.dropout_pre_encoder, cfg.dropout_emb)
+        self.layers = nn.ModuleList([ConformerLayer(d, cfg.d_ff, cfg.n_heads, cfg.conv_kernel_size, cfg.dropout,
+                                                    cfg.dropout_att) for _ in range(cfg.n_layers)])
+        self.encoder_frozen_till = -1  # the reference's custom attribute (conformer_encoder.py:447)
+
+    def _amp(self, x):
+        if self.cfg.compute_dtype == "bf16" and x.is_cuda:
+            return torch.autocast(device_type="cuda", dtype=torch.bfloat16)
+        return nullcontext()
+
+    def forward(self, audio_signal, length):
+        """audio_signal [B,feat,Tm] f32, length [B] i64 -> (encoded [B,d,T'], encoded_len [B] i64)."""
+        with self._amp(audio_signal):
+            with (torch.no_grad() if self.encoder_frozen_till > 0 else nullcontext()):
+                x = audio_signal.transpose(1, 2)
+                x, length = self.pre_encode(x, length)
+                length = length.to(torch.int64)
+                T = x.size(1)
+                x, pos_emb = self.pos_enc(x)
+                pad_mask = torch.arange(T, device=x.device)[None, :] >= length[:, None]
+            for lth, layer in enumerate(self.layers):
+                with (torch.no_grad() if self.encoder_frozen_till > lth else nullcontext()):
+                    x = layer(x, length, pos_emb, pad_mask)
+        return x.transpose(1, 2), length

@@ -63,27 +63,76 @@ def certify_inputs(log_probs, labels, lengths, label_lengths, max_T=None, max_U=
         raise ValueError(f"Output length mismatch! Given U: {U}, Expected max U from target lengths: {max_U} + 1")
 
 
-def rnnt_loss_hip(acts, labels, act_lens, label_lens, blank, fastemit_lambda=0.0, clamp=0.0, want_grads=True,
-                  inplace=False, workspace=None):
-    """Raw call through the C ABI (ia_rnnt_loss).  Returns (costs[B], grads or None, workspace)."""
-    if not acts.is_cuda:
-        raise RuntimeError("rnnt_loss_hip: acts must live on the MI355X (no CPU path in the product)")
-    if acts.dtype != torch.float32:
-        raise TypeError("rnnt_loss_hip: acts must be float32 (A/losses/rnnt.py:449-468 forces fp32)")
+# Optional profiling hook used by bench.py: callable(B, T, U1, V) -> (start_event_ptr, stop_event_ptr) or None; the
+# events are recorded around the gradient kernel of that launch.
+PROFILE_HOOK = None
+
+
+def _workspace(acts, workspace=None):
     B, T, U1, V = acts.shape
-    L = _lib.lib()
-    nbytes = L.ia_rnnt_workspace_bytes(B, T, U1)
+    nbytes = _lib.lib().ia_rnnt_workspace_bytes(B, T, U1)
     if nbytes == 0:
         raise RuntimeError(f"ia_rnnt_workspace_bytes({B},{T},{U1}) unsupported (U1 <= 1024)")
     if workspace is None or workspace.numel() < nbytes:
         workspace = torch.empty(nbytes, dtype=torch.uint8, device=acts.device)
+    return workspace, nbytes
+
+
+def _check_acts(acts):
+    if not acts.is_cuda:
+        raise RuntimeError("rnnt loss: acts must live on the MI355X (no CPU path in the product)")
+    if acts.dtype != torch.float32:
+        raise TypeError("rnnt loss: acts must be float32 (A/losses/rnnt.py:449-468 forces fp32)")
+
+
+def rnnt_forward_hip(acts, labels, act_lens, label_lens, blank, fastemit_lambda=0.0, need_backward=True, workspace=None):
+    """ia_rnnt_forward: costs [B] + the state the backward needs (kept in `workspace`)."""
+    _check_acts(acts)
+    B, T, U1, V = acts.shape
+    workspace, nbytes = _workspace(acts, workspace)
+    costs = torch.empty(B, dtype=torch.float32, device=acts.device)
+    st = _lib.lib().ia_rnnt_forward(_lib.ptr(acts), _lib.ptr(labels), _lib.ptr(act_lens), _lib.ptr(label_lens), B, T,
+                                    U1, V, int(blank), float(fastemit_lambda), int(bool(need_backward)), _lib.ptr(costs),
+                                    _lib.ptr(workspace), nbytes, _lib.stream_ptr())
+    _lib.check(st, "ia_rnnt_forward")
+    return costs, workspace
+
+
+def rnnt_backward_hip(acts, labels, act_lens, label_lens, blank, workspace, cost_grad=None, fastemit_lambda=0.0,
+                      clamp=0.0, inplace=False):
+    """ia_rnnt_backward: d/d(logits) with the upstream per-utterance gradient folded into the single write."""
+    B, T, U1, V = acts.shape
+    _, nbytes = _workspace(acts, workspace)
+    grads = acts if inplace else torch.empty_like(acts)
+    post_scale = None
+    if clamp > 0.0 and cost_grad is not None:
+        post_scale, cost_grad = cost_grad, None
+    if cost_grad is not None:
+        cost_grad = cost_grad.to(torch.float32).contiguous()
+    hook = PROFILE_HOOK(B, T, U1, V) if PROFILE_HOOK is not None else None
+    ev0, ev1 = hook if hook is not None else (None, None)
+    st = _lib.lib().ia_rnnt_backward(_lib.ptr(acts), _lib.ptr(labels), _lib.ptr(act_lens), _lib.ptr(label_lens), B, T,
+                                     U1, V, int(blank), float(fastemit_lambda), float(clamp), _lib.ptr(cost_grad),
+                                     _lib.ptr(grads), _lib.ptr(workspace), nbytes, _lib.stream_ptr(), ev0, ev1)
+    _lib.check(st, "ia_rnnt_backward")
+    if post_scale is not None:
+        grads.mul_(post_scale.view(-1, 1, 1, 1).to(grads))
+    return grads
+
+
+def rnnt_loss_hip(acts, labels, act_lens, label_lens, blank, fastemit_lambda=0.0, clamp=0.0, want_grads=True,
+                  inplace=False, workspace=None):
+    """Raw call through the C ABI (ia_rnnt_loss).  Returns (costs[B], grads or None, workspace)."""
+    _check_acts(acts)
+    B, T, U1, V = acts.shape
+    workspace, nbytes = _workspace(acts, workspace)
     costs = torch.empty(B, dtype=torch.float32, device=acts.device)
     grads = None
     if want_grads:
         grads = acts if inplace else torch.empty_like(acts)
-    st = L.ia_rnnt_loss(_lib.ptr(acts), _lib.ptr(labels), _lib.ptr(act_lens), _lib.ptr(label_lens), B, T, U1, V,
-                        int(blank), float(fastemit_lambda), float(clamp), _lib.ptr(costs), _lib.ptr(grads),
-                        _lib.ptr(workspace), nbytes, _lib.stream_ptr())
+    st = _lib.lib().ia_rnnt_loss(_lib.ptr(acts), _lib.ptr(labels), _lib.ptr(act_lens), _lib.ptr(label_lens), B, T, U1, V,
+                                 int(blank), float(fastemit_lambda), float(clamp), _lib.ptr(costs), _lib.ptr(grads),
+                                 _lib.ptr(workspace), nbytes, _lib.stream_ptr())
     _lib.check(st, "ia_rnnt_loss")
     return costs, grads, workspace
 
@@ -101,31 +150,41 @@ def rnnt_alphas_betas(workspace, act_lens, label_lens, B, T, U1):
 
 
 class _RNNTHip(torch.autograd.Function):
+    """_RNNTNumba (K/rnnt_pytorch.py:40-91) with the gradient kernel deferred to backward(): the upstream gradient
+    is known there, so the [B,T,U,V] gradient is written once, already scaled."""
+
     @staticmethod
-    def forward(ctx, acts, labels, act_lens, label_lens, blank, reduction, fastemit_lambda, clamp, max_T, max_U):
+    def forward(ctx, acts, labels, act_lens, label_lens, blank, reduction, fastemit_lambda, clamp, max_T, max_U,
+                own_acts):
         certify_inputs(acts, labels, act_lens, label_lens, max_T, max_U)
         if clamp < 0:
             raise ValueError("`clamp` must be 0.0 or positive float value.")
         need = acts.requires_grad
-        costs, grads, _ = rnnt_loss_hip(acts.detach(), labels, act_lens, label_lens, blank, fastemit_lambda, clamp,
-                                        want_grads=need)
+        a = acts.detach()
+        costs, ws = rnnt_forward_hip(a, labels, act_lens, label_lens, blank, fastemit_lambda, need_backward=need)
+        ctx.cfg = (blank, reduction, fastemit_lambda, clamp, bool(own_acts), acts.size(0))
+        if need:
+            ctx.state = (a, labels, act_lens, label_lens, ws)
         if reduction in ['sum', 'mean']:
             costs = costs.sum().unsqueeze_(-1)
             if reduction == 'mean':
                 costs /= acts.size(0)
-                if grads is not None:
-                    grads /= acts.size(0)
-        ctx.grads = grads
         return costs
 
     @staticmethod
     def backward(ctx, grad_output):
-        if grad_output is not None and ctx.grads is not None:
-            grad_output = grad_output.view(-1, 1, 1, 1).to(ctx.grads)
-            g = ctx.grads.mul_(grad_output)
-            ctx.grads = None
-            return g, None, None, None, None, None, None, None, None, None
-        return (None,) * 10
+        state = getattr(ctx, "state", None)
+        if grad_output is None or state is None:
+            return (None,) * 11
+        a, labels, act_lens, label_lens, ws = state
+        blank, reduction, fastemit_lambda, clamp, own, B = ctx.cfg
+        go = grad_output.reshape(-1).float()
+        if reduction in ['sum', 'mean']:
+            go = go.expand(B) / (B if reduction == 'mean' else 1)
+        g = rnnt_backward_hip(a, labels, act_lens, label_lens, blank, ws, cost_grad=go.contiguous(),
+                              fastemit_lambda=fastemit_lambda, clamp=clamp, inplace=own)
+        ctx.state = None
+        return (g,) + (None,) * 10
 
 
 class RNNTLossHIP(torch.nn.Module):
@@ -139,9 +198,11 @@ class RNNTLossHIP(torch.nn.Module):
         self.reduction = reduction
         self.loss = _RNNTHip.apply
 
-    def forward(self, acts, labels, act_lens, label_lens, max_T=None, max_U=None):
+    def forward(self, acts, labels, act_lens, label_lens, max_T=None, max_U=None, own_acts=False):
+        """`own_acts=True`: the caller promises nothing else reads `acts` after this loss, so backward() writes the
+        gradient in place over it (saves one lattice-sized allocation)."""
         return self.loss(acts, labels, act_lens, label_lens, self.blank, self.reduction, self.fastemit_lambda,
-                         self.clamp, max_T, max_U)
+                         self.clamp, max_T, max_U, own_acts)
 
 
 class RNNTLoss(torch.nn.Module):
@@ -184,15 +245,17 @@ class RNNTLoss(torch.nn.Module):
             max_T = int(input_lengths.max())
         if max_U is None:
             max_U = int(target_lengths.max())
+        own = False
         if log_probs.dtype != torch.float32:
-            log_probs = log_probs.float()
+            log_probs = log_probs.float()  # private fp32 copy: the gradient may overwrite it in place
+            own = True
         if log_probs.shape[1] != max_T:
             log_probs = log_probs.narrow(dim=1, start=0, length=max_T).contiguous()
         if not targets.is_contiguous():
             targets = targets.contiguous()
         if targets.shape[1] != max_U:
             targets = targets.narrow(dim=1, start=0, length=max_U).contiguous()
-        loss = self._loss(log_probs, targets, input_lengths, target_lengths, max_T, max_U)
+        loss = self._loss(log_probs, targets, input_lengths, target_lengths, max_T, max_U, own)
         if self.reduction is not None:
             loss = self.reduce(loss, target_lengths)
         return loss

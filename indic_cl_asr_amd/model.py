@@ -1,0 +1,155 @@
+"""EncDecHybridRNNTCTCModel for MI355X: the reference's Python surface for the hot path
+(A/models/hybrid_rnnt_ctc_models.py:859-930 training_step, A/models/rnnt_models.py:606-655 forward,
+A/models/hybrid_rnnt_ctc_bpe_models.py:43-170 construction) so R/cl_baseline{,_ewc,_mas,_lwf}.py keep working
+on `model.module.training_step(batch, [lang]*B)` and the MAS/LwF stash flags.
+
+What is deliberately NOT reproduced from the reference step: 6x gc.collect()+empty_cache(),
+4x .item() (one batched D2H read instead), per-sub-batch .max() syncs, CUDA_LAUNCH_BLOCKING.
+"""
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from .config import ModelConfig, model_config
+from .decoder import ConvASRDecoder, RNNTDecoder, RNNTJoint
+from .encoder import ConformerEncoder, subsampled_length
+from .features import AudioToMelSpectrogramPreprocessor, SpectrogramAugmentation, mel_frame_count
+from .losses.ctc import CTCLoss
+from .losses.rnnt import RNNTLoss
+
+
+@dataclass
+class InternalTranscribeConfig:  # hybrid_rnnt_ctc_models.py:98-111 (importable name kept for the CL scripts)
+    device: Optional[torch.device] = None
+    dtype: Optional[torch.dtype] = None
+    training_mode: bool = False
+    logging_level: Optional[int] = None
+    dither_value: float = 0.0
+    pad_to_value: int = 0
+    temp_dir: Optional[str] = None
+
+
+@dataclass
+class TranscribeConfig:  # :114-127
+    batch_size: int = 4
+    return_hypotheses: bool = False
+    num_workers: Optional[int] = None
+    channel_selector: Optional[int] = None
+    augmentor: Optional[dict] = None
+    verbose: bool = True
+    partial_hypothesis: Optional[List] = None
+    _internal: Optional[InternalTranscribeConfig] = None
+
+
+class _WerStub(nn.Module):
+    """Holds `log_prediction` (the scripts set it, R/cl_baseline.py:127-128).  Batch-WER inside the step is a
+    SURVEY §8(f) NEXT row (greedy decode + editdistance); until then the monitor carries NaN for it."""
+
+    def __init__(self):
+        super().__init__()
+        self.log_prediction = False
+
+
+class EncDecHybridRNNTCTCModel(nn.Module):
+    def __init__(self, cfg: Optional[ModelConfig] = None, **kw):
+        super().__init__()
+        self.cfg = cfg = cfg or model_config(**kw)
+        self.preprocessor = AudioToMelSpectrogramPreprocessor(cfg)
+        self.spec_augmentation = SpectrogramAugmentation(cfg) if (cfg.freq_masks + cfg.time_masks) > 0 else None
+        self.encoder = ConformerEncoder(cfg)
+        self.decoder = RNNTDecoder(cfg)
+        self.loss = RNNTLoss(num_classes=cfg.vocab_per_lang, reduction='mean_batch',
+                             loss_kwargs=dict(fastemit_lambda=cfg.fastemit_lambda, clamp=cfg.clamp))
+        self.joint = RNNTJoint(cfg, loss=self.loss)
+        self.ctc_decoder = ConvASRDecoder(cfg)
+        self.ctc_loss = CTCLoss(num_classes=cfg.vocab_per_lang, zero_infinity=True, reduction='mean_batch')
+        self.ctc_loss_weight = cfg.ctc_loss_weight
+        self.wer = _WerStub()
+        self.ctc_wer = _WerStub()
+        self.cur_decoder = "rnnt"
+        self.language_masks = self.ctc_decoder.language_masks
+        self._step = 0
+        self.seed = 1234
+        self.spec_augment_enabled = True
+        self.dither_enabled = True
+
+    def disable_dropout(self):
+        """Deterministic numerics runs (parity tests): p=0 everywhere, module tree / parameter names unchanged."""
+        for mod in self.modules():
+            if isinstance(mod, nn.Dropout):
+                mod.p = 0.0
+            if hasattr(mod, "dropout_rate"):
+                mod.dropout_rate = 0.0
+        return self
+
+    # ------------------------------------------------------------------ forward (rnnt_models.py:606-655)
+    def forward(self, input_signal=None, input_signal_length=None, processed_signal=None,
+                processed_signal_length=None, language_ids=None):
+        has_input = input_signal is not None and input_signal_length is not None
+        has_proc = processed_signal is not None and processed_signal_length is not None
+        if (has_input ^ has_proc) is False:
+            raise ValueError(f"{self} Arguments ``input_signal`` and ``input_signal_length`` are mutually exclusive "
+                             " with ``processed_signal`` and ``processed_signal_len`` arguments.")
+        if not has_proc:
+            spans = None
+            if self.spec_augmentation is not None and self.training and self.spec_augment_enabled:
+                flen = self.preprocessor.featurizer.get_seq_len(input_signal_length)
+                g = torch.Generator(device=input_signal.device)
+                g.manual_seed(self.seed * 1000003 + self._step)
+                spans = self.spec_augmentation.draw(flen, self.cfg.feat_in, g)
+            processed_signal, processed_signal_length = self.preprocessor(
+                input_signal=input_signal, length=input_signal_length, spec_aug=spans, dither=self.dither_enabled,
+                seed=self.seed * 7919 + self._step)
+        elif self.spec_augmentation is not None and self.training and self.spec_augment_enabled:
+            processed_signal = self.spec_augmentation(input_spec=processed_signal, length=processed_signal_length)
+        encoded, encoded_len = self.encoder(audio_signal=processed_signal, length=processed_signal_length)
+        return encoded, encoded_len
+
+    # ------------------------------------------------------------------ training_step (:859-930)
+    def training_step(self, batch, lang_ids, return_probs=False, host_lengths=None):
+        """batch = (signal [B,L] f32, signal_len [B] i64, transcript [B,U] i64, transcript_len [B] i64), all on the
+        device.  `host_lengths` = (signal_len list, transcript_len list): optional host copies (the collate
+        function has them) that remove the only device->host read the sub-batch loop needs."""
+        signal, signal_len, transcript, transcript_len = batch
+        language_ids = lang_ids
+        if host_lengths is None:
+            both = torch.stack([signal_len.long(), transcript_len.long()]).tolist()  # one D2H read
+            host_lengths = (both[0], both[1])
+        h_sig, h_tgt = host_lengths
+        h_enc = [subsampled_length(mel_frame_count(int(n), self.cfg.n_fft, self.cfg.n_window_stride)) for n in h_sig]
+
+        encoded, encoded_len = self.forward(input_signal=signal, input_signal_length=signal_len)
+        decoder, target_length, states = self.decoder(targets=transcript, target_length=transcript_len)
+        loss_value, wer, _, _ = self.joint(encoder_outputs=encoded, decoder_outputs=decoder, encoder_lengths=encoded_len,
+                                           transcripts=transcript, transcript_lengths=transcript_len, compute_wer=False,
+                                           language_ids=language_ids, host_lengths=(h_enc, h_tgt))
+        log_probs = self.ctc_decoder(encoder_output=encoded, language_ids=language_ids)
+        ctc_loss = self.ctc_loss(log_probs=log_probs, targets=transcript, input_lengths=encoded_len,
+                                 target_lengths=transcript_len)
+        rnnt_only = loss_value
+        loss_value = (1 - self.ctc_loss_weight) * loss_value + self.ctc_loss_weight * ctc_loss
+        vals = torch.stack([rnnt_only.detach().float(), ctc_loss.detach().float(), loss_value.detach().float()]).tolist()
+        monitor = {'training_batch_wer': torch.tensor(float('nan')), 'train_rnnt_loss': vals[0],
+                   'train_ctc_loss': vals[1], 'training_batch_wer_ctc': float('nan'), 'train_loss': vals[2]}
+        self._step += 1
+        if return_probs:
+            return loss_value, monitor, log_probs
+        return loss_value, monitor
+
+
+EncDecHybridRNNTCTCBPEModel = EncDecHybridRNNTCTCModel
+
+
+def freeze_layer(model, num_layers):
+    """R/utils.py:246-263 verbatim semantics."""
+    for p in model.parameters():
+        p.requires_grad = False
+    for i, layer in enumerate(model.encoder.layers):
+        if i > num_layers:
+            for p in layer.parameters():
+                p.requires_grad = True
+    for mod in (model.decoder, model.ctc_decoder, model.joint):
+        for p in mod.parameters():
+            p.requires_grad = True

@@ -428,7 +428,8 @@ class OracleHybridModel(nn.Module):
                  vocab_per_lang=256, fused_batch_size=4, ctc_loss_weight=0.3, conv_kernel_size=31, feat_in=80):
         super().__init__()
         self.languages = list(languages or LANGS22)
-        self.preprocessor = FilterbankFeatures(nfilt=feat_in)
+        self.preprocessor = nn.Module()  # AudioToMelSpectrogramPreprocessor.featurizer (audio_preprocessing.py:88-94)
+        self.preprocessor.featurizer = FilterbankFeatures(nfilt=feat_in)
         self.encoder = ConformerEncoder(feat_in, n_layers, d_model, n_heads, conv_kernel_size=conv_kernel_size)
         self.decoder = RNNTDecoder(len(self.languages) * vocab_per_lang, pred_hidden)
         self.joint = RNNTJoint(d_model, pred_hidden, joint_hidden, self.languages, vocab_per_lang, fused_batch_size)
@@ -440,7 +441,7 @@ class OracleHybridModel(nn.Module):
         return _RNNTOracleFn.apply(logits.float().contiguous(), targets.contiguous().long(), il.long(), tl.long(), self.blank)
 
     def forward(self, input_signal, input_signal_length, spec_aug=None, dither_noise=None):
-        feats, flen = self.preprocessor(input_signal, input_signal_length, dither_noise)
+        feats, flen = self.preprocessor.featurizer(input_signal, input_signal_length, dither_noise)
         if spec_aug is not None and self.training:
             feats = spec_augment_apply(feats, *spec_aug)
         return self.encoder(feats, flen)

@@ -140,3 +140,26 @@ def test_full_size_properties():
     a2 = acts.clone()
     c2, g2, _ = rnnt_loss_hip(a2, labels, fl, gl, 256, inplace=True)
     assert torch.equal(g2, grads) and torch.equal(c2, costs)
+
+
+def test_upstream_gradient_folding():
+    """backward() folds d(loss)/d(cost_b) into the single gradient write: positive, negative and zero weights."""
+    from indic_cl_asr_amd.losses.rnnt import RNNTLossHIP
+    from oracle import rnnt_oracle as orc
+    rng = np.random.RandomState(3)
+    B, T, U1, V = 4, 9, 5, 11
+    x = rng.randn(B, T, U1, V).astype(np.float32)
+    labels = rng.randint(0, V - 1, size=(B, U1 - 1))
+    fl, gl = np.array([9, 7, 9, 4]), np.array([4, 2, 3, 4])
+    ref = orc.rnnt_loss(x, labels, fl, gl, V - 1)
+    wts = np.array([0.7, -1.3, 0.0, 2.0], np.float32)
+    a = torch.tensor(x, device="cuda", requires_grad=True)
+    costs = RNNTLossHIP(blank=V - 1, reduction="none")(a, _t(labels, torch.int64), _t(fl, torch.int64), _t(gl, torch.int64))
+    (costs * torch.tensor(wts, device="cuda")).sum().backward()
+    assert np.allclose(a.grad.cpu().numpy(), ref["grads"] * wts[:, None, None, None], rtol=1e-3, atol=1e-5)
+    # clamp > 0 clamps BEFORE the scaling (reference order)
+    refc = orc.rnnt_loss(x, labels, fl, gl, V - 1, clamp=0.05)
+    a2 = torch.tensor(x, device="cuda", requires_grad=True)
+    c2 = RNNTLossHIP(blank=V - 1, reduction="none", clamp=0.05)(a2, _t(labels, torch.int64), _t(fl, torch.int64), _t(gl, torch.int64))
+    (c2 * torch.tensor(wts, device="cuda")).sum().backward()
+    assert np.allclose(a2.grad.cpu().numpy(), refc["grads"] * wts[:, None, None, None], rtol=1e-3, atol=1e-5)
