@@ -62,27 +62,29 @@ class HipEvents:
         self.hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
         self.pairs, self.shapes, self.free = [], [], []
         self.enabled = False
+        self.kernel_name = "rnnt_grad"
 
     def _new(self):
         e = ctypes.c_void_p()
         assert self.hip.hipEventCreate(ctypes.byref(e)) == 0
         return e
 
-    def hook(self, B, T, U1, V):
+    def hook(self, B, T, U1, V, elem_bytes=4):
         if not self.enabled:
             return None
         a, b = self._new(), self._new()
         self.pairs.append((a, b))
-        self.shapes.append((B, T, U1, V))
+        self.shapes.append((B, T, U1, V, elem_bytes))
         return a, b
 
     def summary(self):
         ms, byts = [], []
-        for (a, b), (B, T, U1, V) in zip(self.pairs, self.shapes):
+        for (a, b), (B, T, U1, V, eb) in zip(self.pairs, self.shapes):
             t = ctypes.c_float()
             if self.hip.hipEventElapsedTime(ctypes.byref(t), a, b) == 0:
                 ms.append(t.value)
-                byts.append(2.0 * 4 * B * T * U1 * V)  # read logits once + write grads once
+                # read logits once + write grads once, eb bytes per lattice element
+                byts.append(2.0 * eb * B * T * U1 * V)
         if not ms:
             return None
         return sum(ms) / len(ms), sum(byts) / len(byts), len(ms)
@@ -164,6 +166,8 @@ def main():
 
     events = HipEvents()
     rnnt_mod.PROFILE_HOOK = events.hook
+    if model.joint.use_fused and args.dtype == "bf16":
+        events.kernel_name = "joint_grad_h_kernel"  # the fused path's f16 in-place gradient kernel
 
     def step():
         opt.zero_grad()
@@ -211,7 +215,7 @@ def main():
         if s is not None:
             avg_ms, avg_bytes, n = s
             ach = avg_bytes / (avg_ms * 1e-3) / 1e9
-            out["roofline"] = {"kernel": "rnnt_grad", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+            out["roofline"] = {"kernel": events.kernel_name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                                "launches": n, "avg_launch_ms": round(avg_ms, 4),
                                "algorithmic_bytes_per_launch": int(avg_bytes)}

@@ -85,6 +85,47 @@ int ia_rnnt_export_alphas_betas(const void* workspace, size_t workspace_bytes, c
                                 ia_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Fused RNNT joint (f16 matrix-core path).  Replaces RNNTJoint.joint_after_projection A/modules/rnnt.py:1587-1665
+ * (f.unsqueeze(2)+g.unsqueeze(1) -> ReLU -> Dropout -> Linear(H->V)) fused with the loss front end
+ * (reduce_max/reduce_exp K/utils/cuda_utils/reduce.py:299-360 and the blank/label gathers of logp()
+ * K/utils/cuda_utils/gpu_rnnt_kernel.py:41-64).  The [B,T,U1,H] hidden tensor is never materialised in forward.
+ *
+ *   f [B,T,H] f16 (encoder projection), g [B,U1,H] f16 (prediction projection), W [272,H] f16 (rows >= V zero; the
+ *   caller pre-multiplies by 1/(1-dropout_p)), bias [V] f32.  Limits: V <= 272, H % 64 == 0 (IA_UNSUPPORTED else).
+ *   logits out: [B*T*U1, LD] f16, LD = ia_joint_ld(V) (row stride in elements, 16-byte rows, columns >= V zero);
+ *               rows outside an utterance's valid lattice are left untouched.
+ *   workspace : same layout/size as ia_rnnt_workspace_bytes(B,T,U1); receives the denominators and the
+ *               diagonal-major blank/label log-prob side arrays, i.e. exactly the state ia_rnnt_forward's first
+ *               kernel leaves, so ia_rnnt_lattice() continues from here.
+ *   dropout   : counter-based keep mask keyed by (seed, lattice cell, hidden unit / 8), regenerated identically by
+ *               ia_joint_hidden / ia_joint_dh_reduce; keep probability 1 - round(256 p)/256.
+ * ia_rnnt_lattice: alpha (and beta when need_backward) wavefront + costs from the side arrays in `workspace`.
+ * ia_joint_backward_g: G = kappa * cost_grad[b] * d cost_b / d logits written IN PLACE over the f16 logits rows
+ *               (zero outside the lattice and in the pad columns) -- a GEMM-ready [B*T*U1, LD] f16 operand.
+ *               kappa > 0: power-of-two range scale chosen by the caller so that kappa*|cost_grad| ~ 1.
+ *               ev_start/ev_stop: optional caller-owned hipEvent_t recorded around the streaming gradient kernel.
+ * ia_joint_hidden: hidden[cell, 0:H] = keep * relu(f+g) (un-scaled), hidden[cell, H] = 1, rest of the LDH-wide row 0.
+ * ia_joint_dh_reduce: d f[b,t,:] = (1/kappa) sum_u mask * dH[b,t,u,:] (written), d g[b,u,:] += (1/kappa) sum_t ...
+ *               (f32 atomics; caller zeroes df and dg).  dH = G @ W[0:LD,:] is a library GEMM by the caller.
+ */
+int ia_joint_ld(int V);
+int ia_joint_fwd(const void* f, const void* g, const void* W, const float* bias, const int64_t* labels,
+                 const int64_t* act_lens, const int64_t* label_lens, int B, int T, int U1, int H, int V, int blank,
+                 float dropout_p, unsigned seed, void* logits, int LD, void* workspace, size_t workspace_bytes,
+                 ia_stream_t stream);
+int ia_rnnt_lattice(const int64_t* act_lens, const int64_t* label_lens, int B, int T, int U1, float fastemit_lambda,
+                    int need_backward, float* costs, void* workspace, size_t workspace_bytes, ia_stream_t stream);
+int ia_joint_backward_g(void* logits_inout, const int64_t* labels, const int64_t* act_lens, const int64_t* label_lens,
+                        int B, int T, int U1, int V, int LD, int blank, float fastemit_lambda, const float* cost_grad,
+                        float kappa, void* workspace, size_t workspace_bytes, ia_stream_t stream,
+                        void* grad_kernel_start_event, void* grad_kernel_stop_event);
+int ia_joint_hidden(const void* f, const void* g, void* hidden, int B, int T, int U1, int H, int LDH, float dropout_p,
+                    unsigned seed, ia_stream_t stream);
+int ia_joint_dh_reduce(const void* dh, const void* f, const void* g, const int64_t* act_lens,
+                       const int64_t* label_lens, float* df, float* dg, int B, int T, int U1, int H, float inv_kappa,
+                       float dropout_p, unsigned seed, ia_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Continual-learning regularisers and optimizer over ONE flat fp32 buffer holding every trainable parameter
  * (tensor k occupies [off_k, off_k + numel_k), off_k a multiple of 64 floats, gaps zero-filled).
  *

@@ -26,6 +26,12 @@ SIGNATURES = {
     "ia_rnnt_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _sz, _vp]),
     "ia_rnnt_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
     "ia_rnnt_export_alphas_betas": (_i, [_vp, _sz, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "ia_joint_ld": (_i, [_i]),
+    "ia_joint_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _c.c_uint, _vp, _i, _vp, _sz, _vp]),
+    "ia_rnnt_lattice": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _sz, _vp]),
+    "ia_joint_backward_g": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _f, _vp, _sz, _vp, _vp, _vp]),
+    "ia_joint_hidden": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _c.c_uint, _vp]),
+    "ia_joint_dh_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _c.c_uint, _vp]),
     "ia_cl_chunk_elems": (_i, []),
     "ia_cl_penalty": (_i, [_vp, _vp, _vp, _f, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "ia_cl_fisher_accumulate": (_i, [_vp, _vp, _vp, _i64, _vp]),

@@ -1,0 +1,188 @@
+// Backward-side kernels of the fused RNNT joint (forward: joint_fwd.hip).  The two dense contractions of the
+// backward -- dHidden = G @ W and dW = G^T @ hidden -- are plain library GEMMs over GEMM-ready f16 operands that
+// these kernels produce/consume; everything around them is fused here:
+//   joint_grad_h ........ G = kappa * s_b * (exp(x + c0) - [v=blank] eb - [v=label] el) in place over the f16 logits
+//                         rows (gpu_rnnt_kernel.py:351-403 semantics; s_b = upstream d loss/d cost_b folded in by
+//                         rnnt_cell_scalars; kappa = power-of-two range scale for f16), zero outside the lattice.
+//   joint_hidden ........ hidden[cell, 0:H] = keep * relu(f[b,t,:] + g[b,u,:]), column H = 1 (so the dW GEMM also
+//                         yields dbias), regenerated with the same counter-based dropout mask as the forward.
+//   joint_dh_reduce ..... one pass over dHidden: apply the relu/dropout mask (recomputed from f,g), unscale, and reduce
+//                         over u -> d f[b,t,:] (registers) and over t -> d g[b,u,:] (one f32 atomic per 16 frames).
+#include "joint_common.h"
+#include "rnnt_ws.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void joint_grad_h_kernel(_Float16* __restrict__ x, const float4* __restrict__ cs,
+                                                           int64_t cells, int LD, int V, int blank, float kappa) {
+    const int vpr = LD / 8;  // 16-byte vectors per row
+    const int64_t nvec = cells * vpr;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        const int64_t cell = i / vpr;
+        const int v0 = (int)(i - cell * vpr) * 8;
+        const float4 s = cs[cell];
+        union { uint4 u; _Float16 h[8]; } io;
+        io.u = make_uint4(0, 0, 0, 0);
+        if (s.x != IA_NEG_INF) {
+            io.u = reinterpret_cast<const uint4*>(x)[i];
+            const int w = __float_as_int(s.w);
+            const int lab = (w & 0x7fffffff) - 1;
+            const float sign = (w < 0) ? -kappa : kappa;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int v = v0 + j;
+                float g = __expf((float)io.h[j] + s.x);
+                if (v == blank) g -= s.y;
+                if (v == lab) g -= s.z;
+                io.h[j] = (v < V) ? (_Float16)(g * sign) : (_Float16)0.f;
+            }
+        }
+        reinterpret_cast<uint4*>(x)[i] = io.u;
+    }
+}
+
+template <bool DROPOUT>
+__global__ __launch_bounds__(256) void joint_hidden_kernel(const _Float16* __restrict__ f, const _Float16* __restrict__ g,
+                                                           _Float16* __restrict__ hid, int T, int U1, int H, int LDH,
+                                                           int64_t cells, unsigned seed, unsigned thr) {
+    const int vpr = LDH / 8, hv = H / 8;
+    const int64_t nvec = cells * vpr;
+    const h2 zero2 = {(_Float16)0, (_Float16)0};
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        const int64_t cell = i / vpr;
+        const int kv = (int)(i - cell * vpr);
+        union { h8 v; h2 p[4]; uint4 u; } o;
+        if (kv < hv) {
+            const int u = (int)(cell % U1);
+            const int64_t bt = cell / U1;
+            const int64_t b = bt / T;
+            union { h8 v; h2 p[4]; } x, y;
+            x.v = *reinterpret_cast<const h8*>(f + bt * H + kv * 8);
+            y.v = *reinterpret_cast<const h8*>(g + (b * U1 + u) * H + kv * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o.p[j] = __builtin_elementwise_max(x.p[j] + y.p[j], zero2);
+            if (DROPOUT) o.v = apply_keep8(o.v, dropout_keep8(seed, (unsigned)cell, (unsigned)kv, thr));
+        } else {
+            o.u = make_uint4(0, 0, 0, 0);
+            if (kv == hv) o.v[0] = (_Float16)1.f;  // ones column -> dbias row of the dW GEMM
+        }
+        reinterpret_cast<uint4*>(hid)[i] = o.u;
+    }
+}
+
+// grid = B * ceil(T/16); block = H/2 threads, thread owns 2 adjacent hidden units.
+constexpr int DHR_T = 16;
+template <bool DROPOUT>
+__global__ void joint_dh_reduce_kernel(const _Float16* __restrict__ dh, const _Float16* __restrict__ f,
+                                       const _Float16* __restrict__ g, const int64_t* __restrict__ act_lens,
+                                       const int64_t* __restrict__ label_lens, float* __restrict__ df,
+                                       float* __restrict__ dg, int T, int U1, int H, float inv_kappa, unsigned seed,
+                                       unsigned thr) {
+    const int ntc = (T + DHR_T - 1) / DHR_T;
+    const int b = blockIdx.x / ntc, t0 = (blockIdx.x - b * ntc) * DHR_T;
+    const int Tb = (int)act_lens[b], Ub = (int)label_lens[b] + 1;
+    if (t0 >= Tb) return;
+    const int nt = (Tb - t0 < DHR_T) ? (Tb - t0) : DHR_T;
+    const int h = threadIdx.x * 2;
+    float accf[DHR_T][2];
+    h2 fv[DHR_T];
+#pragma unroll
+    for (int i = 0; i < DHR_T; ++i) {
+        accf[i][0] = accf[i][1] = 0.f;
+        fv[i] = (i < nt) ? *reinterpret_cast<const h2*>(f + ((size_t)b * T + t0 + i) * H + h) : (h2){(_Float16)0, (_Float16)0};
+    }
+    for (int u = 0; u < Ub; ++u) {
+        const h2 gv = *reinterpret_cast<const h2*>(g + ((size_t)b * U1 + u) * H + h);
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < DHR_T; ++i) {
+            if (i < nt) {  // wave-uniform
+                const size_t cell = ((size_t)b * T + t0 + i) * U1 + u;
+                const h2 d = *reinterpret_cast<const h2*>(dh + cell * H + h);
+                const h2 pre = fv[i] + gv;
+                float d0 = ((float)pre[0] > 0.f) ? (float)d[0] : 0.f;
+                float d1 = ((float)pre[1] > 0.f) ? (float)d[1] : 0.f;
+                if (DROPOUT) {
+                    const unsigned m = dropout_keep8(seed, (unsigned)cell, (unsigned)(h >> 3), thr);
+                    d0 = ((m >> (h & 7)) & 1u) ? d0 : 0.f;
+                    d1 = ((m >> ((h & 7) + 1)) & 1u) ? d1 : 0.f;
+                }
+                accf[i][0] += d0; accf[i][1] += d1;
+                s0 += d0; s1 += d1;
+            }
+        }
+        atomicAdd(dg + ((size_t)b * U1 + u) * H + h, s0 * inv_kappa);
+        atomicAdd(dg + ((size_t)b * U1 + u) * H + h + 1, s1 * inv_kappa);
+    }
+#pragma unroll
+    for (int i = 0; i < DHR_T; ++i)
+        if (i < nt) {
+            float2 o = make_float2(accf[i][0] * inv_kappa, accf[i][1] * inv_kappa);
+            *reinterpret_cast<float2*>(df + ((size_t)b * T + t0 + i) * H + h) = o;
+        }
+}
+
+inline int grid_for(int64_t nvec) {
+    int64_t b = (nvec + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
+}
+}  // namespace
+
+extern "C" int ia_joint_backward_g(void* logits_inout, const int64_t* labels, const int64_t* act_lens,
+                                   const int64_t* label_lens, int B, int T, int U1, int V, int LD, int blank,
+                                   float fastemit, const float* cost_grad, float kappa, void* workspace,
+                                   size_t workspace_bytes, ia_stream_t stream, void* ev_start, void* ev_stop) {
+    if (!logits_inout || !act_lens || !label_lens || !workspace || B <= 0 || T <= 0 || U1 <= 0) return IA_INVALID_VALUE;
+    if (LD < V || LD % 8 != 0 || !ia_is_aligned(logits_inout, 16) || !ia_is_aligned(workspace, 256) || !(kappa > 0.f))
+        return IA_INVALID_VALUE;
+    RnntWs w;
+    if (!rnnt_ws_layout(B, T, U1, &w)) return IA_UNSUPPORTED;
+    if (workspace_bytes < w.total) return IA_WORKSPACE_TOO_SMALL;
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    const int64_t cells = (int64_t)B * T * U1;
+    int rc = ia_rnnt_cell_scalars_launch(ws, &w, labels, act_lens, label_lens, B, T, U1, fastemit, cost_grad, st);
+    if (rc != IA_OK) return rc;
+    if (ev_start && hipEventRecord((hipEvent_t)ev_start, st) != hipSuccess) return IA_LAUNCH_FAILED;
+    hipLaunchKernelGGL(joint_grad_h_kernel, dim3(grid_for(cells * (LD / 8))), dim3(256), 0, st, (_Float16*)logits_inout,
+                       (const float4*)(ws + w.off_cs), cells, LD, V, blank, kappa);
+    IA_RETURN_IF_LAUNCH_FAILED();
+    if (ev_stop && hipEventRecord((hipEvent_t)ev_stop, st) != hipSuccess) return IA_LAUNCH_FAILED;
+    return IA_OK;
+}
+
+extern "C" int ia_joint_hidden(const void* f, const void* g, void* hidden, int B, int T, int U1, int H, int LDH,
+                               float dropout_p, unsigned seed, ia_stream_t stream) {
+    if (!f || !g || !hidden || B <= 0 || T <= 0 || U1 <= 0 || H % 8 != 0 || LDH < H + 8 || LDH % 8 != 0)
+        return IA_INVALID_VALUE;
+    if (!ia_is_aligned(f, 16) || !ia_is_aligned(g, 16) || !ia_is_aligned(hidden, 16)) return IA_INVALID_VALUE;
+    const int64_t cells = (int64_t)B * T * U1;
+    const unsigned thr = (unsigned)(dropout_p * 256.f + 0.5f);
+    const dim3 grid(grid_for(cells * (LDH / 8))), blk(256);
+    if (thr > 0)
+        hipLaunchKernelGGL((joint_hidden_kernel<true>), grid, blk, 0, (hipStream_t)stream, (const _Float16*)f,
+                           (const _Float16*)g, (_Float16*)hidden, T, U1, H, LDH, cells, seed, thr);
+    else
+        hipLaunchKernelGGL((joint_hidden_kernel<false>), grid, blk, 0, (hipStream_t)stream, (const _Float16*)f,
+                           (const _Float16*)g, (_Float16*)hidden, T, U1, H, LDH, cells, seed, thr);
+    IA_RETURN_IF_LAUNCH_FAILED();
+    return IA_OK;
+}
+
+extern "C" int ia_joint_dh_reduce(const void* dh, const void* f, const void* g, const int64_t* act_lens,
+                                  const int64_t* label_lens, float* df, float* dg, int B, int T, int U1, int H,
+                                  float inv_kappa, float dropout_p, unsigned seed, ia_stream_t stream) {
+    if (!dh || !f || !g || !act_lens || !label_lens || !df || !dg || B <= 0 || T <= 0 || U1 <= 0) return IA_INVALID_VALUE;
+    if (H % 8 != 0 || H / 2 > 1024 || !ia_is_aligned(df, 8)) return IA_UNSUPPORTED;
+    const unsigned thr = (unsigned)(dropout_p * 256.f + 0.5f);
+    const int ntc = (T + DHR_T - 1) / DHR_T;
+    const dim3 grid((unsigned)(B * ntc)), blk(H / 2);
+    if (thr > 0)
+        hipLaunchKernelGGL((joint_dh_reduce_kernel<true>), grid, blk, 0, (hipStream_t)stream, (const _Float16*)dh,
+                           (const _Float16*)f, (const _Float16*)g, act_lens, label_lens, df, dg, T, U1, H, inv_kappa, seed, thr);
+    else
+        hipLaunchKernelGGL((joint_dh_reduce_kernel<false>), grid, blk, 0, (hipStream_t)stream, (const _Float16*)dh,
+                           (const _Float16*)f, (const _Float16*)g, act_lens, label_lens, df, dg, T, U1, H, inv_kappa, seed, thr);
+    IA_RETURN_IF_LAUNCH_FAILED();
+    return IA_OK;
+}

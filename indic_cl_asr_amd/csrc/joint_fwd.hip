@@ -1,0 +1,286 @@
+// Fused RNNT joint forward for gfx950: logits = relu(f[b,t,:] + g[b,u,:]) (dropout) @ W^T + bias on the matrix
+// cores, with the transducer-loss front end (denominator + blank/label gathers) in the epilogue.
+//
+// Replaces RNNTJoint.joint_after_projection A/modules/rnnt.py:1587-1665 (broadcast add, ReLU, Dropout, per-language
+// Linear(H -> 257)) + the loss's reduce_max/reduce_exp passes (K/utils/cuda_utils/reduce.py:121-248): the
+// [B,T,U,H] hidden tensor (2.5x the lattice) is never materialised -- every MFMA A-operand fragment is built in
+// registers from one f row and one g row with packed-f16 VALU (v_pk_add_f16 / v_pk_max_f16; gfx950 has no packed
+// bf16 VALU, which is why this path runs in f16 like the reference's own AMP mode) -- and the logits leave the chip
+// once, as f16 rows padded to LD columns (16-byte aligned rows, GEMM-ready for the backward).
+//
+// Tiling (v_mfma_f32_16x16x32_f16): workgroup = 4 waves = 16 t x 16 u lattice cells of one utterance; wave w owns
+// t = t0+4w..+3, i.e. 4 row-subtiles (one per t, 16 u each) x NT=17 column tiles (272 >= V): 272 accumulator
+// registers, one wave per SIMD.  W streams through LDS in 64-deep K chunks (double buffered, 144-byte padded rows:
+// conflict-free ds_read_b128 B fragments shared by the 4 waves); f/g tiles stay in LDS for the whole K loop.
+// Epilogue per subtile: +bias, round to f16 (the denominator is computed from the ROUNDED logits, so the fused
+// log-softmax gradient sums to zero exactly as with autocast logits), row max / sum-exp with 16-lane DPP
+// reductions, transpose through LDS, coalesced 16-byte row stores, blank/label gathers into the diagonal-major
+// side arrays that rnnt_alpha_beta consumes.
+#include <hip/hip_fp16.h>
+
+#include "ia_common.h"
+#include "rnnt_ws.h"
+#include "joint_common.h"
+
+namespace {
+
+struct JointFwdArgs {
+    const _Float16* f;       // [B,T,H]
+    const _Float16* g;       // [B,U1,H]
+    const _Float16* W;       // [JVP,H] rows >= V zero (already scaled by 1/(1-p) when dropout is on)
+    const float* bias;       // [V]
+    const int64_t* labels;   // [B,U1-1]
+    const int64_t* act_lens; // [B]
+    const int64_t* label_lens;
+    _Float16* logits;        // [B*T*U1, LD]
+    float* denom; float* PB; float* PL; float* PLa;
+    int B, T, U1, H, V, LD, blank, rows, U1s;
+    unsigned seed, thr;
+};
+
+template <bool DROPOUT>
+__global__ __launch_bounds__(J_THREADS, 1) void joint_fwd_kernel(JointFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int H = a.H;
+    const int frow = H * 2 + 16;                       // bytes per f/g row in LDS (padded)
+    unsigned char* sF = smem;                          // JT rows
+    unsigned char* sG = sF + JT * frow;                // JU rows
+    unsigned char* sW = sG + JU * frow;                // 2 x JVP x JWROW  (later reused as the transpose scratch)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, q = lane >> 4;
+
+    const int nut = (a.U1 + JU - 1) / JU, ntt = (a.T + JT - 1) / JT;
+    int bid = blockIdx.x;
+    const int ut = bid % nut; bid /= nut;
+    const int tt = bid % ntt;
+    const int b = bid / ntt;
+    const int t0 = tt * JT, u0 = ut * JU;
+    const int Tb = (int)a.act_lens[b], Ub = (int)a.label_lens[b] + 1;
+    if (t0 >= Tb || u0 >= Ub) return;  // whole tile outside this utterance's lattice (wave-uniform)
+
+    // ---- stage f and g tiles (zero rows past T / U1)
+    {
+        const int vec_per_row = H / 8;  // 16-byte vectors
+        for (int i = tid; i < (JT + JU) * vec_per_row; i += J_THREADS) {
+            const int r = i / vec_per_row, v = i - r * vec_per_row;
+            uint4 val = make_uint4(0, 0, 0, 0);
+            if (r < JT) {
+                if (t0 + r < a.T) val = reinterpret_cast<const uint4*>(a.f + ((size_t)b * a.T + t0 + r) * H)[v];
+                *reinterpret_cast<uint4*>(sF + r * frow + v * 16) = val;
+            } else {
+                const int ru = r - JT;
+                if (u0 + ru < a.U1) val = reinterpret_cast<const uint4*>(a.g + ((size_t)b * a.U1 + u0 + ru) * H)[v];
+                *reinterpret_cast<uint4*>(sG + ru * frow + v * 16) = val;
+            }
+        }
+    }
+    // ---- W chunk staging: JVP rows x 64 k (128 B) = 8 x 16-byte vectors per row
+    constexpr int WVEC = JVP * (JKC / 8);               // 2176 vectors per chunk
+    constexpr int WFULL = WVEC / J_THREADS;              // 8 full rounds ...
+    constexpr int WREM = WVEC - WFULL * J_THREADS;       // ... + 128 vectors (threads 0..127), kept in a named register
+    static_assert(WFULL == 8, "staging registers are named w0..w7");
+    uint4 w0, w1, w2, w3, w4, w5, w6, w7, wlast = make_uint4(0, 0, 0, 0);  // named: arrays here end up in scratch
+#define J_W_SRC(kc_, i_) \
+    reinterpret_cast<const uint4*>(a.W + (size_t)((tid + (i_) * J_THREADS) >> 3) * H + (kc_) * JKC)[(tid + (i_) * J_THREADS) & 7]
+#define J_W_DST(buf_, i_) \
+    *reinterpret_cast<uint4*>(sW + (buf_) * (JVP * JWROW) + ((tid + (i_) * J_THREADS) >> 3) * JWROW + ((tid + (i_) * J_THREADS) & 7) * 16)
+#define J_W_LOAD(kc_)                                                                                     \
+    do {                                                                                                  \
+        w0 = J_W_SRC(kc_, 0);                                                            \
+        w1 = J_W_SRC(kc_, 1);                                                            \
+        w2 = J_W_SRC(kc_, 2);                                                            \
+        w3 = J_W_SRC(kc_, 3);                                                            \
+        w4 = J_W_SRC(kc_, 4);                                                            \
+        w5 = J_W_SRC(kc_, 5);                                                            \
+        w6 = J_W_SRC(kc_, 6);                                                            \
+        w7 = J_W_SRC(kc_, 7);                                                            \
+        if (tid < WREM) wlast = J_W_SRC(kc_, WFULL);                                                      \
+    } while (0)
+#define J_W_STORE(buf_)                                                                                   \
+    do {                                                                                                  \
+        J_W_DST(buf_, 0) = w0;                                                            \
+        J_W_DST(buf_, 1) = w1;                                                            \
+        J_W_DST(buf_, 2) = w2;                                                            \
+        J_W_DST(buf_, 3) = w3;                                                            \
+        J_W_DST(buf_, 4) = w4;                                                            \
+        J_W_DST(buf_, 5) = w5;                                                            \
+        J_W_DST(buf_, 6) = w6;                                                            \
+        J_W_DST(buf_, 7) = w7;                                                            \
+        if (tid < WREM) J_W_DST(buf_, WFULL) = wlast;                                                     \
+    } while (0)
+
+    f4 acc[4][JNT];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int n = 0; n < JNT; ++n) acc[s][n] = (f4){0.f, 0.f, 0.f, 0.f};
+
+    const int nkc = H / JKC;
+    J_W_LOAD(0);
+    J_W_STORE(0);
+    __syncthreads();
+    const int tw = t0 + wave * 4;  // first t of this wave
+    const unsigned cell_base = (unsigned)(((size_t)b * a.T + tw) * a.U1 + u0 + c);  // + s*U1 per subtile
+    const h2 zero2 = {(_Float16)0, (_Float16)0};
+    for (int kc = 0; kc < nkc; ++kc) {
+        if (kc + 1 < nkc) J_W_LOAD(kc + 1);
+        const unsigned char* wb = sW + (kc & 1) * (JVP * JWROW);
+#pragma unroll
+        for (int ks = 0; ks < JKC / 32; ++ks) {
+            const int kbyte = (kc * JKC + ks * 32 + q * 8) * 2;  // byte offset of this lane's 8 k values in an f/g row
+            const h8 gf = *reinterpret_cast<const h8*>(sG + c * frow + kbyte);
+            h8 A[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const h8 ff = *reinterpret_cast<const h8*>(sF + (wave * 4 + s) * frow + kbyte);
+                union { h8 v; h2 p[4]; } x, y, z;
+                x.v = gf; y.v = ff;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) z.p[j] = __builtin_elementwise_max(x.p[j] + y.p[j], zero2);
+                A[s] = z.v;
+                if (DROPOUT) {
+                    const unsigned kg = (unsigned)((kc * JKC + ks * 32) / 8 + q);
+                    A[s] = apply_keep8(A[s], dropout_keep8(a.seed, cell_base + (unsigned)(s * a.U1), kg, a.thr));
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < JNT; ++n) {
+                const h8 Bf = *reinterpret_cast<const h8*>(wb + (n * 16 + c) * JWROW + (ks * 32 + q * 8) * 2);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc[s][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[s], Bf, acc[s][n], 0, 0, 0);
+            }
+        }
+        __syncthreads();               // everyone done reading buffer (kc&1)... and (kc+1)&1 from the previous round
+        if (kc + 1 < nkc) {
+            J_W_STORE((kc + 1) & 1);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: per subtile s (one t), rows u = u0 + 4q + r, cols v = 16n + c
+    float biasr[JNT];
+#pragma unroll
+    for (int n = 0; n < JNT; ++n) biasr[n] = (16 * n + c < a.V) ? a.bias[16 * n + c] : 0.f;
+    // transpose scratch: per wave 16 rows x LDT bytes, LDT = JVP*2 + 16
+    constexpr int LDT = JVP * 2 + 16;
+    unsigned char* sT = sW + wave * (16 * LDT);
+    const int64_t* lab = a.labels + (int64_t)b * (a.U1 - 1);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int t = tw + s;
+        float m[4] = {IA_NEG_INF, IA_NEG_INF, IA_NEG_INF, IA_NEG_INF};
+#pragma unroll
+        for (int n = 0; n < JNT; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const _Float16 xh = (_Float16)(acc[s][n][r] + biasr[n]);
+                acc[s][n][r] = (float)xh;  // keep the ROUNDED logit
+                if (16 * n + c < a.V) m[r] = fmaxf(m[r], acc[s][n][r]);
+            }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {  // reduce over the 16 lanes (c) of this q group: DPP inside a 16-lane row
+            m[r] = fmaxf(m[r], IA_DPP_F(m[r], m[r], 0xB1, 0xF));
+            m[r] = fmaxf(m[r], IA_DPP_F(m[r], m[r], 0x4E, 0xF));
+            m[r] = fmaxf(m[r], IA_DPP_F(m[r], m[r], 0x141, 0xF));
+            m[r] = fmaxf(m[r], IA_DPP_F(m[r], m[r], 0x140, 0xF));
+        }
+        float sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int n = 0; n < JNT; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (16 * n + c < a.V) sum[r] += __builtin_amdgcn_exp2f((acc[s][n][r] - m[r]) * 1.44269504088896341f);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sum[r] += IA_DPP_F(0.f, sum[r], 0xB1, 0xF);
+            sum[r] += IA_DPP_F(0.f, sum[r], 0x4E, 0xF);
+            sum[r] += IA_DPP_F(0.f, sum[r], 0x141, 0xF);
+            sum[r] += IA_DPP_F(0.f, sum[r], 0x140, 0xF);
+        }
+        // C layout -> LDS rows [u_local = 4q + r][v]
+#pragma unroll
+        for (int n = 0; n < JNT; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                *reinterpret_cast<_Float16*>(sT + (4 * q + r) * LDT + (16 * n + c) * 2) = (_Float16)acc[s][n][r];
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS writes landed (scratch is wave-private)
+        if (t < Tb) {
+            // coalesced row stores: 16 rows x (LD*2/16) vectors
+            const int vec_per_row = a.LD / 8;
+            for (int i = lane; i < 16 * vec_per_row; i += 64) {
+                const int r = i / vec_per_row, v = i - r * vec_per_row;
+                const int u = u0 + r;
+                if (u < Ub) {
+                    const uint4 val = *reinterpret_cast<const uint4*>(sT + r * LDT + v * 16);
+                    reinterpret_cast<uint4*>(a.logits + (((size_t)b * a.T + t) * a.U1 + u) * a.LD)[v] = val;
+                }
+            }
+            // per-row scalars: lanes c == 0 own rows 4q + r
+            if (c == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ul = 4 * q + r, u = u0 + ul;
+                    if (u < Ub) {
+                        const float dn = -m[r] - 0.69314718055994531f * __builtin_amdgcn_logf(sum[r]);
+                        const int64_t cell = ((int64_t)b * a.T + t) * a.U1 + u;
+                        a.denom[cell] = dn;
+                        const size_t row = ((size_t)b * a.rows + RNNT_GUARD + (t + u)) * a.U1s;
+                        const float xb = (float)*reinterpret_cast<const _Float16*>(sT + ul * LDT + a.blank * 2);
+                        a.PB[row + u] = xb + dn;
+                        float lpl = 0.f;
+                        if (u < Ub - 1) lpl = (float)*reinterpret_cast<const _Float16*>(sT + ul * LDT + (int)lab[u] * 2) + dn;
+                        a.PL[row + u] = lpl;
+                        a.PLa[row + a.U1s + u + 1] = lpl;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+    }
+}
+
+}  // namespace
+
+extern "C" int ia_joint_ld(int V) { return (V + 7) / 8 * 8; }  // logits row stride (elements): 16-byte rows
+
+extern "C" int ia_joint_fwd(const void* f, const void* g, const void* W, const float* bias, const int64_t* labels,
+                            const int64_t* act_lens, const int64_t* label_lens, int B, int T, int U1, int H, int V,
+                            int blank, float dropout_p, unsigned seed, void* logits, int LD, void* workspace,
+                            size_t workspace_bytes, ia_stream_t stream) {
+    if (!f || !g || !W || !bias || !act_lens || !label_lens || !logits || !workspace) return IA_INVALID_VALUE;
+    if (B <= 0 || T <= 0 || U1 <= 0 || V < 1 || blank < 0 || blank >= V) return IA_INVALID_VALUE;
+    if (U1 > 1 && !labels) return IA_INVALID_VALUE;
+    if (V > JVP || H % JKC != 0 || H < JKC || LD < V || LD % 8 != 0 || LD > JVP) return IA_UNSUPPORTED;
+    if (dropout_p < 0.f || dropout_p >= 1.f) return IA_INVALID_VALUE;
+    if (!ia_is_aligned(f, 16) || !ia_is_aligned(g, 16) || !ia_is_aligned(W, 16) || !ia_is_aligned(logits, 16) ||
+        !ia_is_aligned(workspace, 256))
+        return IA_INVALID_VALUE;
+    if ((int64_t)B * T * U1 >= (int64_t)1 << 31) return IA_UNSUPPORTED;
+    RnntWs w;
+    if (!rnnt_ws_layout(B, T, U1, &w)) return IA_UNSUPPORTED;
+    if (workspace_bytes < w.total) return IA_WORKSPACE_TOO_SMALL;
+    char* ws = (char*)workspace;
+    JointFwdArgs a;
+    a.f = (const _Float16*)f; a.g = (const _Float16*)g; a.W = (const _Float16*)W; a.bias = bias; a.labels = labels;
+    a.act_lens = act_lens; a.label_lens = label_lens; a.logits = (_Float16*)logits;
+    a.denom = (float*)(ws + w.off_denom); a.PB = (float*)(ws + w.off_pb); a.PL = (float*)(ws + w.off_pl);
+    a.PLa = (float*)(ws + w.off_pla);
+    a.B = B; a.T = T; a.U1 = U1; a.H = H; a.V = V; a.LD = LD; a.blank = blank; a.rows = w.rows; a.U1s = w.U1s;
+    a.seed = seed;
+    a.thr = (unsigned)(dropout_p * 256.f + 0.5f);
+    const int frow = H * 2 + 16;
+    const size_t lds = (size_t)(JT + JU) * frow + 2 * (size_t)JVP * JWROW;
+    if (lds > 160 * 1024) return IA_UNSUPPORTED;
+    const int nut = (U1 + JU - 1) / JU, ntt = (T + JT - 1) / JT;
+    const dim3 grid((unsigned)((int64_t)B * ntt * nut)), blk(J_THREADS);
+    hipStream_t st = (hipStream_t)stream;
+    if (a.thr > 0) {
+        if (hipFuncSetAttribute((const void*)joint_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return IA_LAUNCH_FAILED;
+        hipLaunchKernelGGL((joint_fwd_kernel<true>), grid, blk, lds, st, a);
+    } else {
+        if (hipFuncSetAttribute((const void*)joint_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return IA_LAUNCH_FAILED;
+        hipLaunchKernelGGL((joint_fwd_kernel<false>), grid, blk, lds, st, a);
+    }
+    IA_RETURN_IF_LAUNCH_FAILED();
+    return IA_OK;
+}

@@ -13,39 +13,9 @@
 //
 // Padded cells (t >= T_b or u > U_b) are never read from HBM.
 #include "ia_common.h"
+#include "rnnt_ws.h"
 
 namespace {
-
-constexpr int RNNT_GUARD = 8;  // guard rows before/after each utterance's diagonals: K2 runs whole PF-step
-                               // groups with unconditional loads/stores (no branch => counted vmcnt waits)
-struct RnntWs {
-    int K;        // label positions per lane in K2 (power of two)
-    int U1s;      // side-array row stride (= 64*K floats)
-    int rows;     // side-array rows per utterance (diagonals + 2 + guard rows on both sides)
-    size_t off_denom, off_pb, off_pl, off_pla, off_alpha, off_beta, off_ll, off_cs, total;
-};
-
-inline bool rnnt_ws_layout(int B, int T, int U1, RnntWs* w) {
-    int K = 1;
-    while (64 * K < U1 + 1) K <<= 1;
-    if (K > 16) return false;
-    w->K = K;
-    w->U1s = 64 * K;
-    w->rows = T + U1 + 1 + 2 * RNNT_GUARD;
-    const size_t cells = (size_t)B * T * U1;
-    const size_t side = (size_t)B * w->rows * w->U1s * sizeof(float);
-    size_t o = 0;
-    w->off_denom = o; o = ia_align_up(o + cells * sizeof(float), 256);
-    w->off_pb = o;    o = ia_align_up(o + side, 256);
-    w->off_pl = o;    o = ia_align_up(o + side, 256);
-    w->off_pla = o;   o = ia_align_up(o + side, 256);
-    w->off_alpha = o; o = ia_align_up(o + side, 256);
-    w->off_beta = o;  o = ia_align_up(o + side, 256);
-    w->off_ll = o;    o = ia_align_up(o + (size_t)2 * B * sizeof(float), 256);
-    w->off_cs = o;    o = ia_align_up(o + cells * sizeof(float4), 256);
-    w->total = o;
-    return true;
-}
 
 // ------------------------------------------------------------------------------------------------ K1
 constexpr int K1_THREADS = 256;
@@ -413,6 +383,19 @@ extern "C" size_t ia_rnnt_workspace_bytes(int B, int T, int U1) {
     return w.total;
 }
 
+int ia_rnnt_cell_scalars_launch(char* ws, const RnntWs* w, const int64_t* labels, const int64_t* act_lens,
+                                const int64_t* label_lens, int B, int T, int U1, float fastemit,
+                                const float* cost_grad, hipStream_t st) {
+    const int64_t cells = (int64_t)B * T * U1;
+    const int gridc = (int)((cells + 255) / 256 < 4096 ? (cells + 255) / 256 : 4096);
+    hipLaunchKernelGGL(rnnt_cell_scalars, dim3(gridc), dim3(256), 0, st, (const float*)(ws + w->off_denom),
+                       (const float*)(ws + w->off_pb), (const float*)(ws + w->off_pl), (const float*)(ws + w->off_alpha),
+                       (const float*)(ws + w->off_beta), (const float*)(ws + w->off_ll), labels, act_lens, label_lens, B,
+                       T, U1, w->rows, w->U1s, fastemit, cost_grad, (float4*)(ws + w->off_cs));
+    IA_RETURN_IF_LAUNCH_FAILED();
+    return IA_OK;
+}
+
 static int rnnt_check(const float* logits, const int64_t* labels, const int64_t* act_lens, const int64_t* label_lens,
                       int B, int T, int U1, int V, int blank, const void* workspace, size_t workspace_bytes, RnntWs* w) {
     if (!logits || !act_lens || !label_lens || !workspace) return IA_INVALID_VALUE;
@@ -471,6 +454,31 @@ extern "C" int ia_rnnt_forward(const float* logits, const int64_t* labels, const
     return IA_OK;
 }
 
+extern "C" int ia_rnnt_lattice(const int64_t* act_lens, const int64_t* label_lens, int B, int T, int U1,
+                               float fastemit, int need_backward, float* costs, void* workspace,
+                               size_t workspace_bytes, ia_stream_t stream) {
+    RnntWs w;
+    if (!act_lens || !label_lens || !costs || !workspace || B <= 0 || T <= 0 || U1 <= 0) return IA_INVALID_VALUE;
+    if (!ia_is_aligned(workspace, 256)) return IA_INVALID_VALUE;
+    if (!rnnt_ws_layout(B, T, U1, &w)) return IA_UNSUPPORTED;
+    if (workspace_bytes < w.total) return IA_WORKSPACE_TOO_SMALL;
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    const int with_beta = need_backward ? 1 : 0;
+    switch (w.K) {
+        case 1: launch_alpha_beta<1>(w, ws, act_lens, label_lens, B, with_beta, st); break;
+        case 2: launch_alpha_beta<2>(w, ws, act_lens, label_lens, B, with_beta, st); break;
+        case 4: launch_alpha_beta<4>(w, ws, act_lens, label_lens, B, with_beta, st); break;
+        case 8: launch_alpha_beta<8>(w, ws, act_lens, label_lens, B, with_beta, st); break;
+        default: launch_alpha_beta<16>(w, ws, act_lens, label_lens, B, with_beta, st); break;
+    }
+    IA_RETURN_IF_LAUNCH_FAILED();
+    hipLaunchKernelGGL(rnnt_costs, dim3((B + 255) / 256), dim3(256), 0, st, (const float*)(ws + w.off_ll), B, fastemit,
+                       costs);
+    IA_RETURN_IF_LAUNCH_FAILED();
+    return IA_OK;
+}
+
 extern "C" int ia_rnnt_backward(const float* logits, const int64_t* labels, const int64_t* act_lens,
                                 const int64_t* label_lens, int B, int T, int U1, int V, int blank, float fastemit,
                                 float clamp, const float* cost_grad, float* grads, void* workspace,
@@ -483,12 +491,8 @@ extern "C" int ia_rnnt_backward(const float* logits, const int64_t* labels, cons
     hipStream_t st = (hipStream_t)stream;
     char* ws = (char*)workspace;
     const int64_t cells = (int64_t)B * T * U1;
-    const int gridc = (int)((cells + 255) / 256 < 4096 ? (cells + 255) / 256 : 4096);
-    hipLaunchKernelGGL(rnnt_cell_scalars, dim3(gridc), dim3(256), 0, st, (const float*)(ws + w.off_denom),
-                       (const float*)(ws + w.off_pb), (const float*)(ws + w.off_pl), (const float*)(ws + w.off_alpha),
-                       (const float*)(ws + w.off_beta), (const float*)(ws + w.off_ll), labels, act_lens, label_lens, B,
-                       T, U1, w.rows, w.U1s, fastemit, cost_grad, (float4*)(ws + w.off_cs));
-    IA_RETURN_IF_LAUNCH_FAILED();
+    const int rcs = ia_rnnt_cell_scalars_launch(ws, &w, labels, act_lens, label_lens, B, T, U1, fastemit, cost_grad, st);
+    if (rcs != IA_OK) return rcs;
     const int64_t nchunks3 = (cells + K3_CELLS - 1) / K3_CELLS;
     const int grid3 = (int)(nchunks3 < 8192 ? nchunks3 : 8192);
     if (ev_start && hipEventRecord((hipEvent_t)ev_start, st) != hipSuccess) return IA_LAUNCH_FAILED;

@@ -91,6 +91,11 @@ class RNNTJoint(nn.Module):
         self.detach_sub_enc = False
         self.store_list: List[torch.Tensor] = []
         self.temp_logits = None
+        # MI355X: whole-batch fused joint+loss on the matrix cores (ops/joint.py) whenever the step does not need
+        # the per-sub-batch logits stash (MAS importance / LwF passes keep the stash semantics on the unfused path)
+        self.use_fused = True
+        self.loss_scale_hint = 1.0   # expected |d loss / d cost_b| (set by the model: (1-ctc_w)/B)
+        self.dropout_seed = 0
 
     @property
     def loss(self):
@@ -145,6 +150,9 @@ class RNNTJoint(nn.Module):
             host_lengths = (encoder_lengths.tolist(), transcript_lengths.tolist())
         h_enc, h_tgt = host_lengths
         B = int(enc.size(0))
+        if self._fused_eligible(enc, language_ids):
+            return self._forward_fused(enc, dec, encoder_lengths, transcripts, transcript_lengths, language_ids,
+                                       max(h_enc), max(h_tgt)), None, None, None
         amp = (torch.autocast(device_type="cuda", dtype=torch.bfloat16)
                if self.cfg.compute_dtype == "bf16" and enc.is_cuda else nullcontext())
         losses, target_lengths, stash = [], [], []
@@ -173,6 +181,32 @@ class RNNTJoint(nn.Module):
         if self.store_sub_enc or self.store_sub_logits:
             self.store_list = stash
         return losses, None, None, None
+
+
+    # ------------------------------------------------------------------ fused path
+    def _fused_eligible(self, enc, language_ids):
+        from .ops.joint import fused_joint_supported
+        lk = self._loss._loss
+        return (self.use_fused and self.cfg.compute_dtype == "bf16" and not (self.store_sub_enc or self.store_sub_logits)
+                and language_ids is not None and len(set(language_ids)) == 1 and lk.clamp <= 0.0
+                and fused_joint_supported(self.cfg.joint_hidden, self.cfg.vocab_per_lang + 1, enc.device))
+
+    def _forward_fused(self, enc, dec, encoder_lengths, transcripts, transcript_lengths, language_ids, max_t, max_u):
+        from .ops.joint import fused_joint_rnnt
+        head = self.joint_net[-1][language_ids[0]]
+        p = 0.0
+        for m in self.joint_net[:-1]:
+            if isinstance(m, nn.Dropout) and self.training:
+                p = float(m.p)
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+            f = self.enc(enc[:, :max_t])
+            g = self.pred(dec[:, :max_u + 1])
+        lk = self._loss._loss
+        costs = fused_joint_rnnt(f, g, head.weight, head.bias, transcripts[:, :max_u].contiguous().long(),
+                                 encoder_lengths.long(), transcript_lengths.long(), lk.blank, dropout_p=p,
+                                 seed=self.dropout_seed, fastemit_lambda=lk.fastemit_lambda,
+                                 scale_hint=self.loss_scale_hint)
+        return self._loss.reduce([costs], [transcript_lengths])
 
 
 class ConvASRDecoder(nn.Module):

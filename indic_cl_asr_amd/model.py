@@ -122,6 +122,8 @@ class EncDecHybridRNNTCTCModel(nn.Module):
 
         encoded, encoded_len = self.forward(input_signal=signal, input_signal_length=signal_len)
         decoder, target_length, states = self.decoder(targets=transcript, target_length=transcript_len)
+        self.joint.loss_scale_hint = (1.0 - self.ctc_loss_weight) / max(1, signal.shape[0])
+        self.joint.dropout_seed = (self.seed * 2654435761 + self._step * 40503) & 0x7FFFFFFF
         loss_value, wer, _, _ = self.joint(encoder_outputs=encoded, decoder_outputs=decoder, encoder_lengths=encoded_len,
                                            transcripts=transcript, transcript_lengths=transcript_len, compute_wer=False,
                                            language_ids=language_ids, host_lengths=(h_enc, h_tgt))

@@ -1,0 +1,98 @@
+"""Fused joint + transducer loss on the matrix cores (csrc/joint_fwd.hip, joint_bwd.hip, rnnt_loss.hip).
+
+fused_joint_rnnt(f, g, W, bias, ...) -> per-utterance costs [B], with gradients to f, g, W, bias.
+Semantics = RNNTJoint.joint_after_projection (A/modules/rnnt.py:1587-1665) followed by the transducer loss on the
+accelerator branch (raw logits in, fused log-softmax gradient out), computed like the reference's AMP mode: f16
+operands, f32 accumulation, logits rounded to f16, loss in f32.
+"""
+import math
+
+import torch
+
+from .. import _lib
+
+JOINT_MAX_V = 272
+
+
+def fused_joint_supported(H, V, device):
+    return device.type == "cuda" and H % 64 == 0 and H >= 64 and V <= JOINT_MAX_V
+
+
+def _kappa_for(scale_hint):
+    s = abs(float(scale_hint)) if scale_hint else 1.0
+    return float(2.0 ** math.floor(-math.log2(s))) if s > 0 else 1.0
+
+
+class _FusedJointRNNT(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, f, g, W, bias, labels, act_lens, label_lens, blank, dropout_p, seed, fastemit, scale_hint):
+        from ..losses import rnnt as rl
+        L = _lib.lib()
+        B, T, H = f.shape
+        U1 = g.shape[1]
+        V = W.shape[0]
+        dev = f.device
+        need = any(ctx.needs_input_grad[:4])
+        f16 = f.detach().to(torch.float16).contiguous()
+        g16 = g.detach().to(torch.float16).contiguous()
+        p = float(dropout_p)
+        LD = L.ia_joint_ld(V)
+        Wp = torch.zeros(JOINT_MAX_V, H, dtype=torch.float16, device=dev)
+        Wp[:V] = (W.detach().float() / (1.0 - p)).to(torch.float16) if p > 0 else W.detach().to(torch.float16)
+        bias32 = bias.detach().float().contiguous()
+        nbytes = L.ia_rnnt_workspace_bytes(B, T, U1)
+        if nbytes == 0:
+            raise RuntimeError("fused joint: unsupported lattice size (U1 <= 1024)")
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        logits = torch.empty(B * T * U1, LD, dtype=torch.float16, device=dev)
+        st = L.ia_joint_fwd(_lib.ptr(f16), _lib.ptr(g16), _lib.ptr(Wp), _lib.ptr(bias32), _lib.ptr(labels),
+                            _lib.ptr(act_lens), _lib.ptr(label_lens), B, T, U1, H, V, int(blank), p, int(seed) & 0xFFFFFFFF,
+                            _lib.ptr(logits), LD, _lib.ptr(ws), nbytes, _lib.stream_ptr())
+        _lib.check(st, "ia_joint_fwd")
+        costs = torch.empty(B, dtype=torch.float32, device=dev)
+        st = L.ia_rnnt_lattice(_lib.ptr(act_lens), _lib.ptr(label_lens), B, T, U1, float(fastemit), int(need),
+                               _lib.ptr(costs), _lib.ptr(ws), nbytes, _lib.stream_ptr())
+        _lib.check(st, "ia_rnnt_lattice")
+        if need:
+            ctx.saved = (f16, g16, Wp, logits, ws, labels, act_lens, label_lens)
+            ctx.meta = (B, T, U1, H, V, LD, int(blank), p, int(seed) & 0xFFFFFFFF, float(fastemit),
+                        _kappa_for(scale_hint), f.dtype, g.dtype, W.dtype, bias.dtype, nbytes)
+        return costs
+
+    @staticmethod
+    def backward(ctx, gcosts):
+        from ..losses import rnnt as rl
+        L = _lib.lib()
+        f16, g16, Wp, logits, ws, labels, act_lens, label_lens = ctx.saved
+        B, T, U1, H, V, LD, blank, p, seed, fastemit, kappa, fdt, gdt, wdt, bdt, nbytes = ctx.meta
+        ctx.saved = None
+        dev = f16.device
+        cg = gcosts.reshape(-1).float().contiguous()
+        hook = rl.PROFILE_HOOK(B, T, U1, V, 2) if rl.PROFILE_HOOK is not None else None
+        ev0, ev1 = hook if hook is not None else (None, None)
+        st = L.ia_joint_backward_g(_lib.ptr(logits), _lib.ptr(labels), _lib.ptr(act_lens), _lib.ptr(label_lens), B, T, U1, V,
+                                   LD, blank, fastemit, _lib.ptr(cg), kappa, _lib.ptr(ws), nbytes, _lib.stream_ptr(), ev0, ev1)
+        _lib.check(st, "ia_joint_backward_g")
+        G = logits  # [cells, LD] f16, = kappa * dL/dlogits
+        dH = torch.mm(G, Wp[:LD])  # [cells, H] f16 (plain library GEMM)
+        df = torch.zeros(B, T, H, dtype=torch.float32, device=dev)
+        dg = torch.zeros(B, U1, H, dtype=torch.float32, device=dev)
+        st = L.ia_joint_dh_reduce(_lib.ptr(dH), _lib.ptr(f16), _lib.ptr(g16), _lib.ptr(act_lens), _lib.ptr(label_lens),
+                                  _lib.ptr(df), _lib.ptr(dg), B, T, U1, H, 1.0 / kappa, p, seed, _lib.stream_ptr())
+        _lib.check(st, "ia_joint_dh_reduce")
+        del dH
+        LDH = H + 8
+        hid = torch.empty(B * T * U1, LDH, dtype=torch.float16, device=dev)
+        st = L.ia_joint_hidden(_lib.ptr(f16), _lib.ptr(g16), _lib.ptr(hid), B, T, U1, H, LDH, p, seed, _lib.stream_ptr())
+        _lib.check(st, "ia_joint_hidden")
+        dWx = torch.mm(G.t(), hid, out_dtype=torch.float32)  # [LD, LDH] f32 (plain library GEMM, split-K inside)
+        dW = dWx[:V, :H] * (1.0 / (kappa * (1.0 - p)))
+        db = dWx[:V, H] * (1.0 / kappa)
+        return df.to(fdt), dg.to(gdt), dW.to(wdt), db.to(bdt), None, None, None, None, None, None, None, None
+
+
+def fused_joint_rnnt(f, g, W, bias, labels, act_lens, label_lens, blank, dropout_p=0.0, seed=0, fastemit_lambda=0.0,
+                     scale_hint=1.0):
+    """f [B,T,H], g [B,U1,H] (any float dtype), W [V,H], bias [V] -> costs [B] f32 (differentiable)."""
+    return _FusedJointRNNT.apply(f, g, W, bias, labels.contiguous(), act_lens.contiguous(), label_lens.contiguous(),
+                                 blank, dropout_p, seed, fastemit_lambda, scale_hint)

@@ -1,0 +1,74 @@
+"""GPU parity of the fused joint (MFMA f16) + transducer loss against an fp64 restatement of the same
+quantised computation (f16 operands, f16-rounded logits) pushed through the CPU oracle."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _reference(f, g, W, b, labels, fl, gl, blank, weights):
+    """f16-quantised operands, fp64 math; logits rounded to f16 as the kernel stores them."""
+    from oracle import rnnt_oracle as orc
+    f16, g16, W16 = f.half().double(), g.half().double(), W.half().double()
+    pre = (f.half()[:, :, None, :] + g.half()[:, None, :, :])          # f16 add (as v_pk_add_f16)
+    hid = torch.relu(pre).double()
+    logits = (hid @ W16.t() + b.double()).half().float()
+    r = orc.rnnt_loss(logits.numpy(), labels.numpy(), fl.numpy(), gl.numpy(), blank)
+    G = torch.from_numpy(r["grads"]).double() * weights.double().view(-1, 1, 1, 1)   # dL/dlogits
+    dhid = (G @ W16) * (pre.double() > 0)
+    df, dg = dhid.sum(2), dhid.sum(1)
+    dW = torch.einsum("btuv,btuh->vh", G, hid)
+    db = G.sum((0, 1, 2))
+    return r["costs"], df, dg, dW, db, logits
+
+
+@pytest.mark.parametrize("B,T,U1,H,V", [(2, 21, 9, 64, 30), (3, 37, 19, 128, 257), (1, 16, 16, 64, 272)])
+def test_fused_joint_matches_quantised_reference(B, T, U1, H, V):
+    from indic_cl_asr_amd.ops.joint import fused_joint_rnnt
+    g0 = torch.Generator().manual_seed(B * 100 + T)
+    f = torch.randn(B, T, H, generator=g0) * 0.7
+    g = torch.randn(B, U1, H, generator=g0) * 0.7
+    W = torch.randn(V, H, generator=g0) * 0.15
+    b = torch.randn(V, generator=g0) * 0.1
+    labels = torch.randint(0, V - 1, (B, U1 - 1), generator=g0)
+    fl = torch.randint(max(1, T // 2), T + 1, (B,), generator=g0); fl[0] = T
+    gl = torch.randint(0, U1, (B,), generator=g0); gl[-1] = U1 - 1
+    wts = torch.tensor([0.5, -0.25, 1.0][:B])
+    costs_ref, df, dg, dW, db, _ = _reference(f, g, W, b, labels, fl, gl, V - 1, wts)
+    fc, gc, Wc, bc = (t.cuda().requires_grad_(True) for t in (f, g, W, b))
+    costs = fused_joint_rnnt(fc, gc, Wc, bc, labels.cuda(), fl.cuda(), gl.cuda(), V - 1, scale_hint=0.5)
+    assert np.allclose(costs.detach().cpu().numpy(), costs_ref, rtol=2e-4, atol=2e-3)
+    (costs * wts.cuda()).sum().backward()
+
+    def close(a, ref, what):
+        a, ref = a.detach().cpu().double(), ref.double()
+        tol = 4e-3 * ref.abs().max().item() + 1e-6   # f16 G / f16 dHidden rounding
+        assert (a - ref).abs().max().item() <= tol, (what, (a - ref).abs().max().item(), ref.abs().max().item())
+
+    close(fc.grad, df, "df"); close(gc.grad, dg, "dg"); close(Wc.grad, dW, "dW"); close(bc.grad, db, "dbias")
+
+
+def test_fused_joint_dropout_mask_consistent_between_forward_and_backward():
+    """With dropout on, the analytic gradient must match finite differences of the SAME masked function: checks
+    that joint_hidden / joint_dh_reduce regenerate the forward's mask (and the 1/(1-p) scaling)."""
+    from indic_cl_asr_amd.ops.joint import fused_joint_rnnt
+    torch.manual_seed(5)
+    B, T, U1, H, V = 2, 12, 7, 64, 40
+    f = (torch.randn(B, T, H) * 0.5).cuda(); g = (torch.randn(B, U1, H) * 0.5).cuda()
+    W = (torch.randn(V, H) * 0.2).cuda(); b = torch.zeros(V).cuda()
+    labels = torch.randint(0, V - 1, (B, U1 - 1)).cuda()
+    fl = torch.tensor([T, T - 3]).cuda(); gl = torch.tensor([U1 - 1, U1 - 3]).cuda()
+    fn = lambda ff, bb: fused_joint_rnnt(ff, g, W, bb, labels, fl, gl, V - 1, dropout_p=0.25, seed=1234).sum()
+    bb = b.clone().requires_grad_(True)
+    loss = fn(f, bb); loss.backward()
+    c0 = fused_joint_rnnt(f, g, W, b, labels, fl, gl, V - 1, dropout_p=0.0).sum().item()
+    assert abs(loss.item() - c0) > 1e-3            # the mask does something
+    assert abs(fn(f, b).item() - loss.item()) < 1e-4  # and is deterministic in (seed, cell, unit)
+    # dbias by central differences on two entries (bias enters linearly before the f16 rounding of the logits)
+    for v in (0, V - 1):
+        e = torch.zeros(V, device="cuda"); e[v] = 0.05
+        fd = (fn(f, b + e).item() - fn(f, b - e).item()) / 0.1
+        assert math.isclose(bb.grad[v].item(), fd, rel_tol=0.05, abs_tol=0.02), (v, bb.grad[v].item(), fd)

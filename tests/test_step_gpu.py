@@ -40,8 +40,9 @@ def _batch(B=5, L=12000, U=8, seed=1):
 
 # d(loss)/d(depthwise_conv.bias) is structurally zero: train-mode BatchNorm right after it removes any per-channel
 # constant (conformer_modules.py:353-362).  Both sides compute rounding noise there; compare absolutely.
+# Likewise d/d(linear_k.bias): a constant added to every key shifts all scores of a query equally (softmax-invariant).
 def _structural_zero(name):
-    return name.endswith("depthwise_conv.bias")
+    return name.endswith("depthwise_conv.bias") or name.endswith("self_attn.linear_k.bias")
 
 
 def _close(a, b, rtol, atol, what=""):
@@ -248,3 +249,34 @@ def test_bf16_step_close_to_fp32_oracle():
     lo, mo = o.training_step(batch, ['hi'] * 5)
     lp, mp = m.training_step(tuple(t.cuda() for t in batch), ['hi'] * 5)
     assert math.isclose(mp['train_loss'], mo['train_loss'], rel_tol=2e-2)
+
+
+def test_fused_joint_step_matches_unfused_and_oracle():
+    """Half-precision step (BASELINE config-2 dtype) with the fused joint+loss: loss within 2e-2 of the fp32 oracle
+    and gradients consistent with the unfused product path on the same weights."""
+    from indic_cl_asr_amd.config import model_config
+    from indic_cl_asr_amd.model import EncDecHybridRNNTCTCModel
+    torch.manual_seed(0)
+    kw = dict(d_model=64, n_layers=2, n_heads=4, pred_hidden=64, joint_hidden=64, languages=['hi', 'ta'],
+              vocab_per_lang=16, fused_batch_size=2)
+    o = S.OracleHybridModel(**kw)
+    cfg = model_config('tiny', compute_dtype='bf16', dither=0.0, **kw)
+    ms = []
+    for fused in (True, False):
+        m = EncDecHybridRNNTCTCModel(cfg); m.load_state_dict(o.state_dict()); m.disable_dropout().cuda().train()
+        m.spec_augment_enabled = False; m.joint.use_fused = fused
+        ms.append(m)
+    batch = _batch()
+    o.train()
+    lo, mo = o.training_step(batch, ['hi'] * 5)
+    outs = []
+    for m in ms:
+        lp, mp = m.training_step(tuple(t.cuda() for t in batch), ['hi'] * 5)
+        lp.backward()
+        outs.append(mp)
+        assert math.isclose(mp['train_rnnt_loss'], mo['train_rnnt_loss'], rel_tol=2e-2)
+    assert math.isclose(outs[0]['train_rnnt_loss'], outs[1]['train_rnnt_loss'], rel_tol=5e-3)
+    for n in ("joint.enc.weight", "joint.pred.weight", "joint.joint_net.2.hi.weight", "joint.joint_net.2.hi.bias",
+              "decoder.prediction.embed.weight", "encoder.layers.1.norm_out.weight"):
+        a = dict(ms[0].named_parameters())[n].grad.float(); b = dict(ms[1].named_parameters())[n].grad.float()
+        assert (a - b).abs().max().item() <= 0.03 * b.abs().max().item() + 1e-6, n
