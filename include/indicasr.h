@@ -126,6 +126,36 @@ int ia_joint_dh_reduce(const void* dh, const void* f, const void* g, const int64
                        float dropout_p, unsigned seed, ia_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Conformer block forward building blocks (bf16 projections, fp32 residual stream).
+ *
+ * ia_gemm_bf16:  out = alpha * dropout(act(A[M,K] @ W[N,K]^T + bias)) + R       (matrix cores, bf16 in / f32 acc)
+ *   Replaces nn.Linear / Conv1d(k=1) + the elementwise kernels around them in ConformerFeedForward
+ *   (A/parts/submodules/conformer_modules.py:385-404), the attention projections (multi_head_attention.py:69-96,
+ *   117-119), the pointwise convolutions (conformer_modules.py:340-366) and the residual updates of
+ *   ConformerLayer.forward (:141-214).  A [M,lda] bf16, W [N,ldw] bf16 (nn.Linear layout), bias [N] f32 or NULL,
+ *   act 0 none / 1 SiLU / 2 ReLU, dropout keyed by (seed, row, column/8) with keep scale folded in, R [M,ldr] f32
+ *   residual or NULL (may alias outF), outF [M,ldof] f32 and/or outH [M,ldoh] bf16.  K % 64 == 0, N % 8 == 0.
+ * ia_layernorm:  nn.LayerNorm over the last axis (conformer_modules.py:86-139); optional chained second LayerNorm
+ *   (g2,b2) applied to the first one's result; outF receives the FIRST norm's fp32 result, outH the final bf16.
+ * ia_glu_dwconv: GLU(dim=channels) -> zero frames >= lens[b] -> depthwise conv1d (ksz odd <= 31, 'same' zero padding)
+ *   (conformer_modules.py:345-352, causal_convs.py:72-150).  x2 [B,T,2d] bf16, w [d,ksz] f32, z [B,T,d] f32;
+ *   bn_sum/bn_sumsq [d] f32 += per-channel sums over all B*T frames (caller zeroes) for train-mode BatchNorm.
+ * ia_bn_silu:    BatchNorm1d (train: batch statistics from the sums, running stats updated with `momentum`,
+ *   unbiased variance, num_batches_tracked += 1; eval: running stats) followed by SiLU; out [n_rows,d] bf16
+ *   (conformer_modules.py:353-362).
+ */
+int ia_gemm_bf16(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const float* bias, int act,
+                 float dropout_p, unsigned seed, float alpha, const float* R, int ldr, float* outF, int ldof,
+                 void* outH, int ldoh, ia_stream_t stream);
+int ia_layernorm(const float* x, int ldx, int N, int d, const float* g1, const float* b1, float eps, float* outF,
+                 int ldf, const float* g2, const float* b2, void* outH, int ldh, ia_stream_t stream);
+int ia_glu_dwconv(const void* x2, const int64_t* lens, int B, int T, int d, int ksz, const float* w, const float* bias,
+                  float* z, float* bn_sum, float* bn_sumsq, ia_stream_t stream);
+int ia_bn_silu(const float* z, int64_t n_rows, int d, const float* bn_sum, const float* bn_sumsq, const float* gamma,
+               const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+               float momentum, float eps, int training, void* out, ia_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Continual-learning regularisers and optimizer over ONE flat fp32 buffer holding every trainable parameter
  * (tensor k occupies [off_k, off_k + numel_k), off_k a multiple of 64 floats, gaps zero-filled).
  *

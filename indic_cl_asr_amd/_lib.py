@@ -32,6 +32,10 @@ SIGNATURES = {
     "ia_joint_backward_g": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _f, _vp, _sz, _vp, _vp, _vp]),
     "ia_joint_hidden": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _c.c_uint, _vp]),
     "ia_joint_dh_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _c.c_uint, _vp]),
+    "ia_gemm_bf16": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _f, _c.c_uint, _f, _vp, _i, _vp, _i, _vp, _i, _vp]),
+    "ia_layernorm": (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _vp, _i, _vp, _vp, _vp, _i, _vp]),
+    "ia_glu_dwconv": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ia_bn_silu": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp]),
     "ia_cl_chunk_elems": (_i, []),
     "ia_cl_penalty": (_i, [_vp, _vp, _vp, _f, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "ia_cl_fisher_accumulate": (_i, [_vp, _vp, _vp, _i64, _vp]),

@@ -104,6 +104,7 @@ class EncDecHybridRNNTCTCModel(nn.Module):
                 seed=self.seed * 7919 + self._step)
         elif self.spec_augmentation is not None and self.training and self.spec_augment_enabled:
             processed_signal = self.spec_augmentation(input_spec=processed_signal, length=processed_signal_length)
+        self.encoder.fast_seed = (self.seed * 31 + self._step) & 0x7FFFFFFF
         encoded, encoded_len = self.encoder(audio_signal=processed_signal, length=processed_signal_length)
         return encoded, encoded_len
 

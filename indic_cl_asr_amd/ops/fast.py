@@ -1,0 +1,85 @@
+"""Python faces of the Conformer-block HIP kernels (csrc/gemm_bf16.hip, csrc/encoder_ops.hip) and the bf16 weight
+shadow cache used by the no-autograd (frozen-prefix / teacher / eval) encoder path."""
+import torch
+
+from .. import _lib
+
+_SHADOW = {}
+
+
+def bf16_shadow(*params):
+    """bf16 copy of a parameter (or of several concatenated along dim 0), re-made only when a source version changes.
+    Frozen layers therefore pay the fp32->bf16 cast once, not once per step as autocast does."""
+    key = tuple(id(p) for p in params)
+    ver = tuple(p._version for p in params) + tuple(p.data_ptr() for p in params)
+    hit = _SHADOW.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    with torch.no_grad():
+        w = torch.cat([p.detach().reshape(p.shape[0], -1) for p in params], 0) if len(params) > 1 \
+            else params[0].detach().reshape(params[0].shape[0], -1)
+        w = w.to(torch.bfloat16).contiguous()
+    _SHADOW[key] = (ver, w)
+    return w
+
+
+def f32_cat(*params):
+    key = ("f32",) + tuple(id(p) for p in params)
+    ver = tuple(p._version for p in params) + tuple(p.data_ptr() for p in params)
+    hit = _SHADOW.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    with torch.no_grad():
+        w = torch.cat([p.detach().float().reshape(-1) for p in params], 0).contiguous()
+    _SHADOW[key] = (ver, w)
+    return w
+
+
+def gemm_supported(K, N):
+    return K % 64 == 0 and N % 8 == 0
+
+
+def gemm(a_bf16, w_bf16, bias=None, act=0, dropout_p=0.0, seed=0, alpha=1.0, residual=None, out_f32=None,
+         want_bf16=True):
+    """out = alpha*dropout(act(a @ w^T + bias)) + residual.  a [M,K] bf16, w [N,K] bf16.  Returns (out_f32, out_bf16);
+    `out_f32` may be the residual tensor itself (in-place residual update)."""
+    M, K = a_bf16.shape
+    N = w_bf16.shape[0]
+    outH = torch.empty(M, N, dtype=torch.bfloat16, device=a_bf16.device) if want_bf16 else None
+    st = _lib.lib().ia_gemm_bf16(_lib.ptr(a_bf16), a_bf16.stride(0), _lib.ptr(w_bf16), w_bf16.stride(0), M, N, K,
+                                 _lib.ptr(bias), int(act), float(dropout_p), int(seed) & 0xFFFFFFFF, float(alpha),
+                                 _lib.ptr(residual), residual.stride(0) if residual is not None else 0,
+                                 _lib.ptr(out_f32), out_f32.stride(0) if out_f32 is not None else 0,
+                                 _lib.ptr(outH), N, _lib.stream_ptr())
+    _lib.check(st, "ia_gemm_bf16")
+    return out_f32, outH
+
+
+def layernorm(x_f32, g1, b1, eps=1e-5, out_f32=None, g2=None, b2=None, want_bf16=True):
+    N, d = x_f32.shape
+    outH = torch.empty(N, d, dtype=torch.bfloat16, device=x_f32.device) if want_bf16 else None
+    st = _lib.lib().ia_layernorm(_lib.ptr(x_f32), x_f32.stride(0), N, d, _lib.ptr(g1), _lib.ptr(b1), float(eps),
+                                 _lib.ptr(out_f32), out_f32.stride(0) if out_f32 is not None else 0, _lib.ptr(g2),
+                                 _lib.ptr(b2), _lib.ptr(outH), d, _lib.stream_ptr())
+    _lib.check(st, "ia_layernorm")
+    return outH
+
+
+def glu_dwconv_bn_silu_fast(x2_bf16, lens, B, T, d, dw_weight, dw_bias, bn, training):
+    """x2 [B*T, 2d] bf16 -> [B*T, d] bf16 : GLU, pad mask, depthwise conv, BatchNorm (batch stats in training), SiLU."""
+    L = _lib.lib()
+    dev = x2_bf16.device
+    z = torch.empty(B * T, d, dtype=torch.float32, device=dev)
+    sums = torch.zeros(2, d, dtype=torch.float32, device=dev)
+    ksz = dw_weight.shape[-1]
+    st = L.ia_glu_dwconv(_lib.ptr(x2_bf16), _lib.ptr(lens), B, T, d, ksz, _lib.ptr(dw_weight), _lib.ptr(dw_bias),
+                         _lib.ptr(z), _lib.ptr(sums[0]), _lib.ptr(sums[1]), _lib.stream_ptr())
+    _lib.check(st, "ia_glu_dwconv")
+    out = torch.empty(B * T, d, dtype=torch.bfloat16, device=dev)
+    use_batch = bool(training or not bn.track_running_stats)
+    mom = bn.momentum if bn.momentum is not None else 0.1
+    st = L.ia_bn_silu(_lib.ptr(z), B * T, d, _lib.ptr(sums[0]), _lib.ptr(sums[1]), _lib.ptr(bn.weight), _lib.ptr(bn.bias),
+                      _lib.ptr(bn.running_mean), _lib.ptr(bn.running_var), _lib.ptr(bn.num_batches_tracked), float(mom),
+                      float(bn.eps), int(use_batch), _lib.ptr(out), _lib.stream_ptr())
+    _lib.check(st, "ia_bn_silu")
+    return out

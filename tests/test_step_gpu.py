@@ -280,3 +280,37 @@ def test_fused_joint_step_matches_unfused_and_oracle():
               "decoder.prediction.embed.weight", "encoder.layers.1.norm_out.weight"):
         a = dict(ms[0].named_parameters())[n].grad.float(); b = dict(ms[1].named_parameters())[n].grad.float()
         assert (a - b).abs().max().item() <= 0.03 * b.abs().max().item() + 1e-6, n
+
+
+def test_fast_encoder_prefix_matches_aten_path_and_oracle():
+    """The fused no-autograd encoder path (HIP GEMM+epilogues, LayerNorm, GLU/dwconv/BN kernels) against the ATen
+    composition on the same bf16 model, and against the fp32 oracle (train-mode BatchNorm, dropout off)."""
+    from indic_cl_asr_amd.config import model_config
+    from indic_cl_asr_amd.model import EncDecHybridRNNTCTCModel
+    torch.manual_seed(0)
+    kw = dict(d_model=64, n_layers=3, n_heads=4, pred_hidden=64, joint_hidden=64, languages=['hi', 'ta'],
+              vocab_per_lang=16, fused_batch_size=2)
+    o = S.OracleHybridModel(**kw)
+    with torch.no_grad():
+        for l in o.encoder.layers:
+            l.self_attn.pos_bias_u.normal_(0, 0.2); l.self_attn.pos_bias_v.normal_(0, 0.2)
+            l.conv.batch_norm.weight.uniform_(0.5, 1.5); l.conv.batch_norm.bias.normal_(0, 0.2)
+    cfg = model_config('tiny', compute_dtype='bf16', dither=0.0, **kw)
+    sig, sl, _, _ = _batch()
+    outs, stats = [], []
+    for fast in (True, False):
+        m = EncDecHybridRNNTCTCModel(cfg); m.load_state_dict(o.state_dict()); m.disable_dropout().cuda().train()
+        m.spec_augment_enabled = False; m.encoder.use_fast_path = fast
+        with torch.no_grad():
+            enc, elen = m(input_signal=sig.cuda(), input_signal_length=sl.cuda())
+        outs.append(enc.float().cpu()); stats.append(m.encoder.layers[2].conv.batch_norm.running_var.cpu().clone())
+    o.train()
+    with torch.no_grad():
+        eo, lo = o.forward(sig, sl)
+    assert torch.equal(elen.cpu(), lo)
+    valid = (torch.arange(eo.shape[2])[None, :] < lo[:, None]).unsqueeze(1)
+    ref_scale = (eo * valid).abs().max().item()
+    assert ((outs[0] - outs[1]) * valid).abs().max().item() < 0.04 * ref_scale      # two bf16 paths
+    assert ((outs[0] - eo) * valid).abs().max().item() < 0.06 * ref_scale           # fused path vs fp32 oracle
+    assert torch.allclose(stats[0], stats[1], rtol=2e-2, atol=1e-4)                  # BN running stats updated alike
+    assert torch.allclose(stats[0], o.encoder.layers[2].conv.batch_norm.running_var, rtol=3e-2, atol=1e-4)
