@@ -155,6 +155,17 @@ int ia_bn_silu(const float* z, int64_t n_rows, int d, const float* bn_sum, const
                const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                float momentum, float eps, int training, void* out, ia_stream_t stream);
 
+/* ia_relpos_attention: RelPositionMultiHeadAttention.forward core (A/parts/submodules/multi_head_attention.py:197-250,
+ * rel_shift :184-195, masking :108-111) without materialising any [B,h,T,T] / [B,h,T,2T-1] tensor.
+ *   qkv [B*T, 3*H*dk] bf16 (q | k | v, head-major inside each third), pos_proj [2T-1, H*dk] bf16 (linear_pos(pos_emb)),
+ *   bias_u / bias_v [H,dk] f32, lens [B] i64, ctx out [B*T, H*dk] bf16 (zero rows for queries >= lens[b]).
+ *   vt_scratch: ia_attn_vt_elems(B,T,H) bf16 elements, caller-owned (holds V^T, filled by this call).
+ *   Attention dropout keyed by (seed, b, h, i, j).  Limits: dk == 64, T <= 384 (IA_UNSUPPORTED otherwise). */
+size_t ia_attn_vt_elems(int B, int T, int H);
+int ia_relpos_attention(const void* qkv, const void* pos_proj, const float* bias_u, const float* bias_v,
+                        const int64_t* lens, int B, int T, int H, int dk, float dropout_p, unsigned seed,
+                        void* vt_scratch, void* ctx, ia_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Continual-learning regularisers and optimizer over ONE flat fp32 buffer holding every trainable parameter
  * (tensor k occupies [off_k, off_k + numel_k), off_k a multiple of 64 floats, gaps zero-filled).

@@ -172,11 +172,15 @@ class ConformerLayer(nn.Module):
         _, qkv = fast.gemm(y, fast.bf16_shadow(att.linear_q.weight, att.linear_k.weight, att.linear_v.weight),
                            fast.f32_cat(att.linear_q.bias, att.linear_k.bias, att.linear_v.bias))
         _, pl = fast.gemm(pos_emb, fast.bf16_shadow(att.linear_pos.weight))
-        qkv = qkv.view(B, T, 3, att.h, att.d_k)
-        q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))
-        ctx = ops.rel_pos_attention(q, k, v, pl.view(-1, att.h, att.d_k).transpose(0, 1), att.pos_bias_u, att.pos_bias_v,
-                                    lens, att.dropout_rate, tr)
-        ctx = ctx.transpose(1, 2).reshape(B * T, d).contiguous()
+        if fast.attention_supported(T, att.d_k):
+            ctx = fast.relpos_attention(qkv, pl, att.pos_bias_u, att.pos_bias_v, lens, B, T, att.h, att.d_k,
+                                        att.dropout_rate if tr else 0.0, seed + 7)
+        else:  # long inputs (T' > 384) / other head sizes: ATen composition
+            qkv = qkv.view(B, T, 3, att.h, att.d_k)
+            q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))
+            ctx = ops.rel_pos_attention(q, k, v, pl.view(-1, att.h, att.d_k).transpose(0, 1), att.pos_bias_u,
+                                        att.pos_bias_v, lens, att.dropout_rate, tr)
+            ctx = ctx.transpose(1, 2).reshape(B * T, d).contiguous()
         fast.gemm(ctx, fast.bf16_shadow(att.linear_out.weight), att.linear_out.bias, dropout_p=p, seed=seed + 3,
                   residual=x, out_f32=x, want_bf16=False)
         # convolution module

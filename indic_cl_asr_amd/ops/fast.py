@@ -83,3 +83,27 @@ def glu_dwconv_bn_silu_fast(x2_bf16, lens, B, T, d, dw_weight, dw_bias, bn, trai
                       float(bn.eps), int(use_batch), _lib.ptr(out), _lib.stream_ptr())
     _lib.check(st, "ia_bn_silu")
     return out
+
+
+def attention_supported(T, dk):
+    return dk == 64 and T <= 384
+
+
+_VT = {}
+
+
+def relpos_attention(qkv_bf16, pos_proj_bf16, bias_u, bias_v, lens, B, T, H, dk, dropout_p=0.0, seed=0):
+    """qkv [B*T, 3*H*dk] bf16, pos_proj [2T-1, H*dk] bf16 -> ctx [B*T, H*dk] bf16 (csrc/attention.hip)."""
+    L = _lib.lib()
+    dev = qkv_bf16.device
+    n = L.ia_attn_vt_elems(B, T, H)
+    key = (dev.index, n)
+    vt = _VT.get(key)
+    if vt is None:
+        vt = _VT[key] = torch.empty(n, dtype=torch.bfloat16, device=dev)
+    ctx = torch.empty(B * T, H * dk, dtype=torch.bfloat16, device=dev)
+    st = L.ia_relpos_attention(_lib.ptr(qkv_bf16), _lib.ptr(pos_proj_bf16), _lib.ptr(bias_u), _lib.ptr(bias_v),
+                               _lib.ptr(lens), B, T, H, dk, float(dropout_p), int(seed) & 0xFFFFFFFF, _lib.ptr(vt),
+                               _lib.ptr(ctx), _lib.stream_ptr())
+    _lib.check(st, "ia_relpos_attention")
+    return ctx

@@ -288,8 +288,8 @@ def test_fast_encoder_prefix_matches_aten_path_and_oracle():
     from indic_cl_asr_amd.config import model_config
     from indic_cl_asr_amd.model import EncDecHybridRNNTCTCModel
     torch.manual_seed(0)
-    kw = dict(d_model=64, n_layers=3, n_heads=4, pred_hidden=64, joint_hidden=64, languages=['hi', 'ta'],
-              vocab_per_lang=16, fused_batch_size=2)
+    kw = dict(d_model=128, n_layers=3, n_heads=2, pred_hidden=64, joint_hidden=64, languages=['hi', 'ta'],
+              vocab_per_lang=16, fused_batch_size=2)   # head dim 64: exercises the HIP rel-pos attention kernel
     o = S.OracleHybridModel(**kw)
     with torch.no_grad():
         for l in o.encoder.layers:
