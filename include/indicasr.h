@@ -117,8 +117,14 @@ int ia_rnnt_lattice(const int64_t* act_lens, const int64_t* label_lens, int B, i
                     int need_backward, float* costs, void* workspace, size_t workspace_bytes, ia_stream_t stream);
 int ia_joint_backward_g(void* logits_inout, const int64_t* labels, const int64_t* act_lens, const int64_t* label_lens,
                         int B, int T, int U1, int V, int LD, int blank, float fastemit_lambda, const float* cost_grad,
-                        float kappa, void* workspace, size_t workspace_bytes, ia_stream_t stream,
-                        void* grad_kernel_start_event, void* grad_kernel_stop_event);
+                        float kappa, void* gt_out, int S, int Kc, void* workspace, size_t workspace_bytes,
+                        ia_stream_t stream, void* grad_kernel_start_event, void* grad_kernel_stop_event);
+/* gt_out (optional, NULL to skip): additionally receives G transposed in the chunked K-contiguous layout
+ * GT[s][v][kc] f16 (S chunks of Kc cells, Kc % 64 == 0, S*Kc >= B*T*U1, cells beyond the lattice zero), the A operand
+ * of the split-K weight-gradient GEMM  dW[v,h] = sum_s GT[s] @ HT[s]^T  with HT from ia_joint_hidden_t:
+ * HT[s][hh][kc] = keep*relu(f+g) for hh < H, 1 for hh == H (dbias row), 0 for H < hh < LDH. */
+int ia_joint_hidden_t(const void* f, const void* g, void* hidden_t, int B, int T, int U1, int H, int LDH, int S, int Kc,
+                      float dropout_p, unsigned seed, ia_stream_t stream);
 int ia_joint_hidden(const void* f, const void* g, void* hidden, int B, int T, int U1, int H, int LDH, float dropout_p,
                     unsigned seed, ia_stream_t stream);
 int ia_joint_dh_reduce(const void* dh, const void* f, const void* g, const int64_t* act_lens,

@@ -29,7 +29,8 @@ SIGNATURES = {
     "ia_joint_ld": (_i, [_i]),
     "ia_joint_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _c.c_uint, _vp, _i, _vp, _sz, _vp]),
     "ia_rnnt_lattice": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _sz, _vp]),
-    "ia_joint_backward_g": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _f, _vp, _sz, _vp, _vp, _vp]),
+    "ia_joint_backward_g": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _f, _vp, _i, _i, _vp, _sz, _vp, _vp, _vp]),
+    "ia_joint_hidden_t": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _c.c_uint, _vp]),
     "ia_joint_hidden": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _c.c_uint, _vp]),
     "ia_joint_dh_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _c.c_uint, _vp]),
     "ia_gemm_bf16": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _f, _c.c_uint, _f, _vp, _i, _vp, _i, _vp, _i, _vp]),

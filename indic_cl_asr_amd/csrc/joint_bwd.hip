@@ -122,6 +122,100 @@ __global__ void joint_dh_reduce_kernel(const _Float16* __restrict__ dh, const _F
         }
 }
 
+// Same gradient, one 64-cell tile per iteration, additionally emitting G^T in the chunked K-contiguous layout
+// GT[s][v][kc] (cell = s*Kc + kc) that the split-K weight-gradient GEMM consumes (both operands K-contiguous).
+constexpr int GT_CELLS = 64;
+__global__ __launch_bounds__(256) void joint_grad_h_t_kernel(_Float16* __restrict__ x, const float4* __restrict__ cs,
+                                                             int64_t cells, int LD, int V, int blank, float kappa,
+                                                             _Float16* __restrict__ gt, int S, int Kc) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int ldt = LD + 8;  // halves per LDS row (16-byte multiple)
+    _Float16* tile = reinterpret_cast<_Float16*>(smem);
+    const int vpr = LD / 8;
+    const int64_t ntiles = (int64_t)S * (Kc / GT_CELLS);
+    for (int64_t tile_id = blockIdx.x; tile_id < ntiles; tile_id += gridDim.x) {
+        const int64_t cell0 = tile_id * GT_CELLS;
+        __syncthreads();
+        for (int i = threadIdx.x; i < GT_CELLS * vpr; i += 256) {
+            const int r = i / vpr, v0 = (i - r * vpr) * 8;
+            const int64_t cell = cell0 + r;
+            union { uint4 u; _Float16 h[8]; } io;
+            io.u = make_uint4(0, 0, 0, 0);
+            if (cell < cells) {
+                const float4 s = cs[cell];
+                if (s.x != IA_NEG_INF) {
+                    io.u = reinterpret_cast<const uint4*>(x + cell * LD)[v0 >> 3];
+                    const int w = __float_as_int(s.w);
+                    const int lab = (w & 0x7fffffff) - 1;
+                    const float sign = (w < 0) ? -kappa : kappa;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int v = v0 + j;
+                        float g = __expf((float)io.h[j] + s.x);
+                        if (v == blank) g -= s.y;
+                        if (v == lab) g -= s.z;
+                        io.h[j] = (v < V) ? (_Float16)(g * sign) : (_Float16)0.f;
+                    }
+                }
+                reinterpret_cast<uint4*>(x + cell * LD)[v0 >> 3] = io.u;
+            }
+            *reinterpret_cast<uint4*>(tile + r * ldt + v0) = io.u;
+        }
+        __syncthreads();
+        const int s_idx = (int)(cell0 / Kc);
+        const int kc0 = (int)(cell0 - (int64_t)s_idx * Kc);
+        for (int i = threadIdx.x; i < LD * (GT_CELLS / 8); i += 256) {
+            const int v = i / (GT_CELLS / 8), r0 = (i - v * (GT_CELLS / 8)) * 8;
+            union { uint4 u; _Float16 h[8]; } o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o.h[j] = tile[(r0 + j) * ldt + v];
+            *reinterpret_cast<uint4*>(gt + ((size_t)s_idx * LD + v) * Kc + kc0 + r0) = o.u;
+        }
+    }
+}
+
+// hidden^T in the same chunked layout: HT[s][hh][kc], hh < H: keep*relu(f+g); hh == H: 1; else 0.
+template <bool DROPOUT>
+__global__ __launch_bounds__(256) void joint_hidden_t_kernel(const _Float16* __restrict__ f, const _Float16* __restrict__ g,
+                                                             _Float16* __restrict__ ht, int T, int U1, int H, int LDH,
+                                                             int64_t cells, int S, int Kc, unsigned seed, unsigned thr) {
+    const int kv = Kc / 8;
+    const int64_t nitems = (int64_t)S * LDH * kv;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nitems; i += (int64_t)gridDim.x * 256) {
+        const int k8 = (int)(i % kv);
+        const int64_t r = i / kv;
+        const int hh = (int)(r % LDH);
+        const int s_idx = (int)(r / LDH);
+        const int64_t cell0 = (int64_t)s_idx * Kc + (int64_t)k8 * 8;
+        union { uint4 u; _Float16 h[8]; } o;
+        o.u = make_uint4(0, 0, 0, 0);
+        if (hh <= H && cell0 < cells) {
+            int u = (int)(cell0 % U1);
+            int64_t bt = cell0 / U1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int64_t cell = cell0 + j;
+                if (cell < cells) {
+                    if (hh == H) {
+                        o.h[j] = (_Float16)1.f;
+                    } else {
+                        const int64_t b = bt / T;
+                        const _Float16 pre = f[bt * H + hh] + g[(b * U1 + u) * H + hh];
+                        _Float16 val = pre > (_Float16)0.f ? pre : (_Float16)0.f;
+                        if (DROPOUT) {
+                            const unsigned m = dropout_keep8(seed, (unsigned)cell, (unsigned)(hh >> 3), thr);
+                            if (!((m >> (hh & 7)) & 1u)) val = (_Float16)0.f;
+                        }
+                        o.h[j] = val;
+                    }
+                }
+                if (++u == U1) { u = 0; ++bt; }
+            }
+        }
+        *reinterpret_cast<uint4*>(ht + ((size_t)s_idx * LDH + hh) * Kc + (size_t)k8 * 8) = o.u;
+    }
+}
+
 inline int grid_for(int64_t nvec) {
     int64_t b = (nvec + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
@@ -130,8 +224,9 @@ inline int grid_for(int64_t nvec) {
 
 extern "C" int ia_joint_backward_g(void* logits_inout, const int64_t* labels, const int64_t* act_lens,
                                    const int64_t* label_lens, int B, int T, int U1, int V, int LD, int blank,
-                                   float fastemit, const float* cost_grad, float kappa, void* workspace,
-                                   size_t workspace_bytes, ia_stream_t stream, void* ev_start, void* ev_stop) {
+                                   float fastemit, const float* cost_grad, float kappa, void* gt_out, int S, int Kc,
+                                   void* workspace, size_t workspace_bytes, ia_stream_t stream, void* ev_start,
+                                   void* ev_stop) {
     if (!logits_inout || !act_lens || !label_lens || !workspace || B <= 0 || T <= 0 || U1 <= 0) return IA_INVALID_VALUE;
     if (LD < V || LD % 8 != 0 || !ia_is_aligned(logits_inout, 16) || !ia_is_aligned(workspace, 256) || !(kappa > 0.f))
         return IA_INVALID_VALUE;
@@ -143,9 +238,19 @@ extern "C" int ia_joint_backward_g(void* logits_inout, const int64_t* labels, co
     const int64_t cells = (int64_t)B * T * U1;
     int rc = ia_rnnt_cell_scalars_launch(ws, &w, labels, act_lens, label_lens, B, T, U1, fastemit, cost_grad, st);
     if (rc != IA_OK) return rc;
+    if (gt_out && (S <= 0 || Kc <= 0 || Kc % GT_CELLS != 0 || (int64_t)S * Kc < cells || !ia_is_aligned(gt_out, 16)))
+        return IA_INVALID_VALUE;
     if (ev_start && hipEventRecord((hipEvent_t)ev_start, st) != hipSuccess) return IA_LAUNCH_FAILED;
-    hipLaunchKernelGGL(joint_grad_h_kernel, dim3(grid_for(cells * (LD / 8))), dim3(256), 0, st, (_Float16*)logits_inout,
-                       (const float4*)(ws + w.off_cs), cells, LD, V, blank, kappa);
+    if (gt_out) {
+        const int64_t ntiles = (int64_t)S * (Kc / GT_CELLS);
+        const size_t lds = (size_t)GT_CELLS * (LD + 8) * sizeof(_Float16);
+        hipLaunchKernelGGL(joint_grad_h_t_kernel, dim3((unsigned)(ntiles < 16384 ? ntiles : 16384)), dim3(256), lds, st,
+                           (_Float16*)logits_inout, (const float4*)(ws + w.off_cs), cells, LD, V, blank, kappa,
+                           (_Float16*)gt_out, S, Kc);
+    } else {
+        hipLaunchKernelGGL(joint_grad_h_kernel, dim3(grid_for(cells * (LD / 8))), dim3(256), 0, st, (_Float16*)logits_inout,
+                           (const float4*)(ws + w.off_cs), cells, LD, V, blank, kappa);
+    }
     IA_RETURN_IF_LAUNCH_FAILED();
     if (ev_stop && hipEventRecord((hipEvent_t)ev_stop, st) != hipSuccess) return IA_LAUNCH_FAILED;
     return IA_OK;
@@ -183,6 +288,25 @@ extern "C" int ia_joint_dh_reduce(const void* dh, const void* f, const void* g, 
     else
         hipLaunchKernelGGL((joint_dh_reduce_kernel<false>), grid, blk, 0, (hipStream_t)stream, (const _Float16*)dh,
                            (const _Float16*)f, (const _Float16*)g, act_lens, label_lens, df, dg, T, U1, H, inv_kappa, seed, thr);
+    IA_RETURN_IF_LAUNCH_FAILED();
+    return IA_OK;
+}
+
+extern "C" int ia_joint_hidden_t(const void* f, const void* g, void* hidden_t, int B, int T, int U1, int H, int LDH, int S,
+                                 int Kc, float dropout_p, unsigned seed, ia_stream_t stream) {
+    if (!f || !g || !hidden_t || B <= 0 || T <= 0 || U1 <= 0 || H <= 0 || LDH < H + 1 || S <= 0 || Kc <= 0 || Kc % 8 != 0)
+        return IA_INVALID_VALUE;
+    const int64_t cells = (int64_t)B * T * U1;
+    if ((int64_t)S * Kc < cells || !ia_is_aligned(hidden_t, 16)) return IA_INVALID_VALUE;
+    const unsigned thr = (unsigned)(dropout_p * 256.f + 0.5f);
+    const int64_t nitems = (int64_t)S * LDH * (Kc / 8);
+    const dim3 grid(grid_for(nitems)), blk(256);
+    if (thr > 0)
+        hipLaunchKernelGGL((joint_hidden_t_kernel<true>), grid, blk, 0, (hipStream_t)stream, (const _Float16*)f,
+                           (const _Float16*)g, (_Float16*)hidden_t, T, U1, H, LDH, cells, S, Kc, seed, thr);
+    else
+        hipLaunchKernelGGL((joint_hidden_t_kernel<false>), grid, blk, 0, (hipStream_t)stream, (const _Float16*)f,
+                           (const _Float16*)g, (_Float16*)hidden_t, T, U1, H, LDH, cells, S, Kc, seed, thr);
     IA_RETURN_IF_LAUNCH_FAILED();
     return IA_OK;
 }

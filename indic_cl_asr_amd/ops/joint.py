@@ -70,8 +70,15 @@ class _FusedJointRNNT(torch.autograd.Function):
         cg = gcosts.reshape(-1).float().contiguous()
         hook = rl.PROFILE_HOOK(B, T, U1, V, 2) if rl.PROFILE_HOOK is not None else None
         ev0, ev1 = hook if hook is not None else (None, None)
+        # split-K layout for the weight gradient: S chunks of Kc lattice cells, both GEMM operands K-contiguous
+        cells = B * T * U1
+        S = 64
+        Kc = ((cells + S - 1) // S + 63) // 64 * 64
+        LDH = H + 8
+        GT = torch.empty(S, LD, Kc, dtype=torch.float16, device=dev)
         st = L.ia_joint_backward_g(_lib.ptr(logits), _lib.ptr(labels), _lib.ptr(act_lens), _lib.ptr(label_lens), B, T, U1, V,
-                                   LD, blank, fastemit, _lib.ptr(cg), kappa, _lib.ptr(ws), nbytes, _lib.stream_ptr(), ev0, ev1)
+                                   LD, blank, fastemit, _lib.ptr(cg), kappa, _lib.ptr(GT), S, Kc, _lib.ptr(ws), nbytes,
+                                   _lib.stream_ptr(), ev0, ev1)
         _lib.check(st, "ia_joint_backward_g")
         G = logits  # [cells, LD] f16, = kappa * dL/dlogits
         dH = torch.mm(G, Wp[:LD])  # [cells, H] f16 (plain library GEMM)
@@ -81,11 +88,11 @@ class _FusedJointRNNT(torch.autograd.Function):
                                   _lib.ptr(df), _lib.ptr(dg), B, T, U1, H, 1.0 / kappa, p, seed, _lib.stream_ptr())
         _lib.check(st, "ia_joint_dh_reduce")
         del dH
-        LDH = H + 8
-        hid = torch.empty(B * T * U1, LDH, dtype=torch.float16, device=dev)
-        st = L.ia_joint_hidden(_lib.ptr(f16), _lib.ptr(g16), _lib.ptr(hid), B, T, U1, H, LDH, p, seed, _lib.stream_ptr())
-        _lib.check(st, "ia_joint_hidden")
-        dWx = torch.mm(G.t(), hid, out_dtype=torch.float32)  # [LD, LDH] f32 (plain library GEMM, split-K inside)
+        HT = torch.empty(S, LDH, Kc, dtype=torch.float16, device=dev)
+        st = L.ia_joint_hidden_t(_lib.ptr(f16), _lib.ptr(g16), _lib.ptr(HT), B, T, U1, H, LDH, S, Kc, p, seed, _lib.stream_ptr())
+        _lib.check(st, "ia_joint_hidden_t")
+        # dW (+dbias in column H): batched split-K library GEMM over the chunks, f32 partials summed
+        dWx = torch.bmm(GT, HT.transpose(1, 2), out_dtype=torch.float32).sum(0)  # [LD, LDH]
         dW = dWx[:V, :H] * (1.0 / (kappa * (1.0 - p)))
         db = dWx[:V, H] * (1.0 / kappa)
         return df.to(fdt), dg.to(gdt), dW.to(wdt), db.to(bdt), None, None, None, None, None, None, None, None
