@@ -157,6 +157,13 @@ int ia_layernorm(const float* x, int ldx, int N, int d, const float* g1, const f
                  int ldf, const float* g2, const float* b2, void* outH, int ldh, ia_stream_t stream);
 int ia_glu_dwconv(const void* x2, const int64_t* lens, int B, int T, int d, int ksz, const float* w, const float* bias,
                   float* z, float* bn_sum, float* bn_sumsq, ia_stream_t stream);
+/* Depthwise conv over time on fp32 [B,T,d] with autograd pieces (CausalConv1D as configured by the Conformer conv
+ * module, causal_convs.py:72-150): y = bias + sum_j w[c][j] x[t+j-half]; flip=1 (bias NULL) gives the data gradient;
+ * ia_dwconv_time_wgrad accumulates dw [d,ksz] and db [d] (f32 atomics; caller zeroes). */
+int ia_dwconv_time(const float* x, int B, int T, int d, int ksz, const float* w, const float* bias, int flip, float* y,
+                   ia_stream_t stream);
+int ia_dwconv_time_wgrad(const float* x, const float* dy, int B, int T, int d, int ksz, float* dw, float* db,
+                         ia_stream_t stream);
 int ia_bn_silu(const float* z, int64_t n_rows, int d, const float* bn_sum, const float* bn_sumsq, const float* gamma,
                const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                float momentum, float eps, int training, void* out, ia_stream_t stream);

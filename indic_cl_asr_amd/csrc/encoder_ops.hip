@@ -134,6 +134,68 @@ __global__ void glu_dwconv_kernel(const __bf16* __restrict__ x2, const int64_t* 
     atomicAdd(bn_sumsq + ch, s2);
 }
 
+// Plain depthwise conv over time on fp32 [B,T,d] (autograd path of the trainable blocks):
+//   y[b,t,c] = bias[c] + sum_j w[c][flip ? k-1-j : j] * x[b, t + j - half, c]      (zero padding)
+// flip = 1 with bias = NULL is the data gradient of the same op.
+__global__ void dwconv_time_kernel(const float* __restrict__ x, int B, int T, int d, int ksz, const float* __restrict__ w,
+                                   const float* __restrict__ bias, int flip, float* __restrict__ y) {
+    extern __shared__ float sg[];
+    const int ntt = (T + DW_TT - 1) / DW_TT;
+    const int b = blockIdx.x / ntt, t0 = (blockIdx.x - b * ntt) * DW_TT;
+    const int ch = threadIdx.x;
+    const int half = (ksz - 1) / 2, rows = DW_TT + ksz - 1;
+    for (int r = 0; r < rows; ++r) {
+        const int t = t0 - half + r;
+        sg[r * d + ch] = (t >= 0 && t < T) ? x[((size_t)b * T + t) * d + ch] : 0.f;
+    }
+    __syncthreads();
+    float wr[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) wr[j] = (j < ksz) ? w[ch * ksz + (flip ? ksz - 1 - j : j)] : 0.f;
+    const float bb = bias ? bias[ch] : 0.f;
+    for (int i = 0; i < DW_TT; ++i) {
+        const int t = t0 + i;
+        if (t >= T) break;
+        float acc = bb;
+#pragma unroll
+        for (int j = 0; j < 32; ++j)
+            if (j < ksz) acc += wr[j] * sg[(i + j) * d + ch];
+        y[((size_t)b * T + t) * d + ch] = acc;
+    }
+}
+
+// Weight / bias gradient of the depthwise conv: dw[c][j] += sum_{b,t} dy[b,t,c] x[b,t+j-half,c]; db[c] += sum dy.
+__global__ void dwconv_time_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, int B, int T, int d,
+                                         int ksz, float* __restrict__ dw, float* __restrict__ db) {
+    extern __shared__ float sg[];
+    const int ntt = (T + DW_TT - 1) / DW_TT;
+    const int b = blockIdx.x / ntt, t0 = (blockIdx.x - b * ntt) * DW_TT;
+    const int ch = threadIdx.x;
+    const int half = (ksz - 1) / 2, rows = DW_TT + ksz - 1;
+    for (int r = 0; r < rows; ++r) {
+        const int t = t0 - half + r;
+        sg[r * d + ch] = (t >= 0 && t < T) ? x[((size_t)b * T + t) * d + ch] : 0.f;
+    }
+    __syncthreads();
+    float acc[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) acc[j] = 0.f;
+    float sb = 0.f;
+    for (int i = 0; i < DW_TT; ++i) {
+        const int t = t0 + i;
+        if (t >= T) break;
+        const float g = dy[((size_t)b * T + t) * d + ch];
+        sb += g;
+#pragma unroll
+        for (int j = 0; j < 32; ++j)
+            if (j < ksz) acc[j] += g * sg[(i + j) * d + ch];
+    }
+#pragma unroll
+    for (int j = 0; j < 32; ++j)
+        if (j < ksz) atomicAdd(dw + ch * ksz + j, acc[j]);
+    if (db) atomicAdd(db + ch, sb);
+}
+
 // ------------------------------------------------------------------------------------------------ BatchNorm + SiLU
 __global__ __launch_bounds__(256) void bn_silu_kernel(const float* __restrict__ z, int64_t n_rows, int d,
                                                       const float* __restrict__ bn_sum, const float* __restrict__ bn_sumsq,
@@ -236,5 +298,35 @@ extern "C" int ia_bn_silu(const float* z, int64_t n_rows, int d, const float* bn
                            running_mean, running_var, num_batches_tracked, momentum);
         IA_RETURN_IF_LAUNCH_FAILED();
     }
+    return IA_OK;
+}
+
+extern "C" int ia_dwconv_time(const float* x, int B, int T, int d, int ksz, const float* w, const float* bias, int flip,
+                              float* y, ia_stream_t stream) {
+    if (!x || !w || !y || B <= 0 || T <= 0) return IA_INVALID_VALUE;
+    if (d <= 0 || d > 1024 || ksz < 1 || ksz > 32 || (ksz & 1) == 0) return IA_UNSUPPORTED;
+    const size_t lds = (size_t)(DW_TT + ksz - 1) * d * sizeof(float);
+    if (lds > 160 * 1024) return IA_UNSUPPORTED;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)dwconv_time_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return IA_LAUNCH_FAILED;
+    const int ntt = (T + DW_TT - 1) / DW_TT;
+    hipLaunchKernelGGL(dwconv_time_kernel, dim3(B * ntt), dim3(d), lds, (hipStream_t)stream, x, B, T, d, ksz, w, bias, flip, y);
+    IA_RETURN_IF_LAUNCH_FAILED();
+    return IA_OK;
+}
+
+extern "C" int ia_dwconv_time_wgrad(const float* x, const float* dy, int B, int T, int d, int ksz, float* dw, float* db,
+                                    ia_stream_t stream) {
+    if (!x || !dy || !dw || B <= 0 || T <= 0) return IA_INVALID_VALUE;
+    if (d <= 0 || d > 1024 || ksz < 1 || ksz > 32 || (ksz & 1) == 0) return IA_UNSUPPORTED;
+    const size_t lds = (size_t)(DW_TT + ksz - 1) * d * sizeof(float);
+    if (lds > 160 * 1024) return IA_UNSUPPORTED;
+    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)dwconv_time_wgrad_kernel,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return IA_LAUNCH_FAILED;
+    const int ntt = (T + DW_TT - 1) / DW_TT;
+    hipLaunchKernelGGL(dwconv_time_wgrad_kernel, dim3(B * ntt), dim3(d), lds, (hipStream_t)stream, x, dy, B, T, d, ksz, dw, db);
+    IA_RETURN_IF_LAUNCH_FAILED();
     return IA_OK;
 }

@@ -122,10 +122,10 @@ class ConformerConvolution(nn.Module):
 
     def forward(self, x, pad_mask):
         # k=1 convolutions are plain projections over the feature axis: keep [B,T,d] and skip two transposes
-        x2 = F.linear(x, self.pointwise_conv1.weight.squeeze(-1), self.pointwise_conv1.bias).transpose(1, 2)
+        x2 = F.linear(x, self.pointwise_conv1.weight.squeeze(-1), self.pointwise_conv1.bias)
         y = ops.glu_dwconv_bn_silu(x2, pad_mask, self.depthwise_conv.weight, self.depthwise_conv.bias, self.batch_norm,
                                    self.training)
-        y = y.transpose(1, 2).to(x.dtype)
+        y = y.to(x.dtype)
         return F.linear(y, self.pointwise_conv2.weight.squeeze(-1), self.pointwise_conv2.bias)
 
 
