@@ -179,40 +179,48 @@ template <bool DROPOUT>
 __global__ __launch_bounds__(256) void joint_hidden_t_kernel(const _Float16* __restrict__ f, const _Float16* __restrict__ g,
                                                              _Float16* __restrict__ ht, int T, int U1, int H, int LDH,
                                                              int64_t cells, int S, int Kc, unsigned seed, unsigned thr) {
-    const int kv = Kc / 8;
-    const int64_t nitems = (int64_t)S * LDH * kv;
+    // one thread = 8 consecutive cells x 8 consecutive hidden units: 16-byte f/g row loads, ONE dropout mask per cell
+    // (the forward's (cell, unit/8) key), 8x8 register transpose, 16-byte stores along the cell axis.
+    const int kv = Kc / 8, hg = LDH / 8;
+    const int64_t nitems = (int64_t)S * hg * kv;
+    const h2 zero2 = {(_Float16)0, (_Float16)0};
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nitems; i += (int64_t)gridDim.x * 256) {
         const int k8 = (int)(i % kv);
         const int64_t r = i / kv;
-        const int hh = (int)(r % LDH);
-        const int s_idx = (int)(r / LDH);
+        const int hgi = (int)(r % hg);
+        const int s_idx = (int)(r / hg);
+        const int hh0 = hgi * 8;
         const int64_t cell0 = (int64_t)s_idx * Kc + (int64_t)k8 * 8;
-        union { uint4 u; _Float16 h[8]; } o;
-        o.u = make_uint4(0, 0, 0, 0);
-        if (hh <= H && cell0 < cells) {
-            int u = (int)(cell0 % U1);
-            int64_t bt = cell0 / U1;
+        union { h8 v; h2 p[4]; _Float16 h[8]; } val[8];
+        int u = (int)(cell0 % U1);
+        int64_t bt = cell0 / U1;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int64_t cell = cell0 + j;
-                if (cell < cells) {
-                    if (hh == H) {
-                        o.h[j] = (_Float16)1.f;
-                    } else {
-                        const int64_t b = bt / T;
-                        const _Float16 pre = f[bt * H + hh] + g[(b * U1 + u) * H + hh];
-                        _Float16 val = pre > (_Float16)0.f ? pre : (_Float16)0.f;
-                        if (DROPOUT) {
-                            const unsigned m = dropout_keep8(seed, (unsigned)cell, (unsigned)(hh >> 3), thr);
-                            if (!((m >> (hh & 7)) & 1u)) val = (_Float16)0.f;
-                        }
-                        o.h[j] = val;
-                    }
+        for (int j = 0; j < 8; ++j) {
+            const int64_t cell = cell0 + j;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) val[j].p[e] = zero2;
+            if (cell < cells) {
+                if (hh0 < H) {
+                    const int64_t b = bt / T;
+                    union { h8 v; h2 p[4]; } x, y;
+                    x.v = *reinterpret_cast<const h8*>(f + bt * H + hh0);
+                    y.v = *reinterpret_cast<const h8*>(g + (b * U1 + u) * H + hh0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) val[j].p[e] = __builtin_elementwise_max(x.p[e] + y.p[e], zero2);
+                    if (DROPOUT) val[j].v = apply_keep8(val[j].v, dropout_keep8(seed, (unsigned)cell, (unsigned)hgi, thr));
+                } else if (hh0 == H) {
+                    val[j].h[0] = (_Float16)1.f;  // ones row -> dbias
                 }
-                if (++u == U1) { u = 0; ++bt; }
             }
+            if (++u == U1) { u = 0; ++bt; }
         }
-        *reinterpret_cast<uint4*>(ht + ((size_t)s_idx * LDH + hh) * Kc + (size_t)k8 * 8) = o.u;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            union { uint4 u4; _Float16 h[8]; } o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o.h[j] = val[j].h[e];
+            *reinterpret_cast<uint4*>(ht + ((size_t)s_idx * LDH + hh0 + e) * Kc + (size_t)k8 * 8) = o.u4;
+        }
     }
 }
 
@@ -299,7 +307,8 @@ extern "C" int ia_joint_hidden_t(const void* f, const void* g, void* hidden_t, i
     const int64_t cells = (int64_t)B * T * U1;
     if ((int64_t)S * Kc < cells || !ia_is_aligned(hidden_t, 16)) return IA_INVALID_VALUE;
     const unsigned thr = (unsigned)(dropout_p * 256.f + 0.5f);
-    const int64_t nitems = (int64_t)S * LDH * (Kc / 8);
+    if (LDH % 8 != 0 || H % 8 != 0) return IA_UNSUPPORTED;
+    const int64_t nitems = (int64_t)S * (LDH / 8) * (Kc / 8);
     const dim3 grid(grid_for(nitems)), blk(256);
     if (thr > 0)
         hipLaunchKernelGGL((joint_hidden_t_kernel<true>), grid, blk, 0, (hipStream_t)stream, (const _Float16*)f,
