@@ -180,6 +180,28 @@ int ia_relpos_attention(const void* qkv, const void* pos_proj, const float* bias
                         void* vt_scratch, void* ctx, ia_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Persistent single-layer LSTM: the recurrence of the RNNT prediction network (RNNTDecoder.predict
+ * A/modules/rnnt.py:683-792 -> LSTMDropout C/parts/rnn.py:151-235 -> torch.nn.LSTM, gate order i,f,g,o, zero initial
+ * state) as ONE launch per direction instead of ~6 launches per time step.
+ *   ia_lstm_forward : Gx [U,B,4H] f32 = x W_ih^T + b_ih + b_hh (a GEMM by the caller), Whh [4H,H] bf16
+ *                     -> Hout [U,B,H] f32; gates [U,B,4H] f32 (activated) and Cs [U,B,H] f32 are saved for the backward
+ *                     (both NULL for inference).
+ *   ia_lstm_backward: dHout [U,B,H] f32, saved gates/Cs, WhhT [H,4H] bf16 (W_hh transposed)
+ *                     -> dG [U,B,4H] f32 = gradient w.r.t. the gate pre-activations; dW_ih = dG^T x, dW_hh = dG[1:]^T Hout[:-1],
+ *                     db = sum dG, dx = dG W_ih are GEMMs/reductions by the caller.
+ *   scratch: ia_lstm_scratch_bytes(B,H), 256-byte aligned, caller-owned (hand-off buffers + arrival counter; the
+ *            launcher zeroes the counter words on the stream).  After completion scratch word [1] != 0 means a bounded
+ *            spin gave up (results invalid) -- the kernels cannot hang.
+ *   Limits: B <= 32 per call (split larger batches: rows are independent), H % 32 == 0, H/16 workgroups must be
+ *           co-resident (H <= 4096).  One workgroup per 16 hidden units keeps its W_hh slice in LDS for the whole sequence.
+ */
+size_t ia_lstm_scratch_bytes(int B, int H);
+int ia_lstm_forward(const float* Gx, const void* Whh_bf16, float* Hout, float* gates, float* Cs, int U, int B, int H,
+                    void* scratch, size_t scratch_bytes, ia_stream_t stream);
+int ia_lstm_backward(const float* dHout, const float* gates, const float* Cs, const void* WhhT_bf16, float* dG, int U,
+                     int B, int H, void* scratch, size_t scratch_bytes, ia_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Continual-learning regularisers and optimizer over ONE flat fp32 buffer holding every trainable parameter
  * (tensor k occupies [off_k, off_k + numel_k), off_k a multiple of 64 floats, gaps zero-filled).
  *

@@ -32,9 +32,14 @@ class LSTMDropout(nn.Module):
             self.lstm.bias_ih_l0[hidden_size:2 * hidden_size].fill_(forget_gate_bias)
             self.lstm.bias_hh_l0[hidden_size:2 * hidden_size] *= 0.0
         self.dropout = nn.Dropout(dropout) if dropout else None
+        self.use_hip = False  # set by RNNTDecoder in the bf16 configuration (persistent HIP LSTM, ops/lstm.py)
 
     def forward(self, x, h=None):
-        x, h = self.lstm(x, h)
+        from .ops import lstm as hip_lstm
+        if self.use_hip and h is None and hip_lstm.lstm_supported(x, self.lstm.hidden_size):
+            x, h = hip_lstm.lstm_forward(x, self.lstm), None
+        else:
+            x, h = self.lstm(x, h)
         if self.dropout:
             x = self.dropout(x)
         return x, h
@@ -51,6 +56,7 @@ class RNNTDecoder(nn.Module):
             "embed": nn.Embedding(vocab + 1, cfg.pred_hidden, padding_idx=vocab),
             "dec_rnn": LSTMDropout(cfg.pred_hidden, cfg.pred_hidden, cfg.pred_dropout),
         })
+        self.prediction["dec_rnn"].use_hip = (cfg.compute_dtype == "bf16")
 
     def predict(self, y=None, state=None, add_sos=True, batch_size=None):
         p = next(self.parameters())

@@ -1,0 +1,96 @@
+"""Prediction-network LSTM on the persistent HIP kernels (csrc/lstm.hip); autograd wrapper.
+
+Same arithmetic as torch.nn.LSTM(num_layers=1) with zero initial state (gate order i,f,g,o): bf16 operands for the
+two projections (like the rest of the bf16 path), fp32 gates / cell state / outputs.
+"""
+import torch
+
+from .. import _lib
+from . import fast
+
+MAXB = 32
+
+
+def lstm_supported(x, H):
+    return x.is_cuda and H % 64 == 0 and H <= 4096
+
+
+def _scratch(B, H, dev):
+    n = _lib.lib().ia_lstm_scratch_bytes(B, H)
+    return torch.empty(n, dtype=torch.uint8, device=dev), n
+
+
+class _LSTMHip(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh):
+        L = _lib.lib()
+        U, B, H = x.shape
+        dev = x.device
+        xb = x.detach().to(torch.bfloat16).contiguous()
+        wih = w_ih.detach().to(torch.bfloat16).contiguous()
+        whh = w_hh.detach().to(torch.bfloat16).contiguous()
+        bias = (b_ih.detach().float() + b_hh.detach().float()).contiguous()
+        Gx = torch.empty(U * B, 4 * H, dtype=torch.float32, device=dev)
+        fast.gemm(xb.view(U * B, H), wih, bias, out_f32=Gx, want_bf16=False)
+        Gx = Gx.view(U, B, 4 * H)
+        need = any(ctx.needs_input_grad)
+        Hout = torch.empty(U, B, H, dtype=torch.float32, device=dev)
+        gates = torch.empty(U, B, 4 * H, dtype=torch.float32, device=dev) if need else None
+        Cs = torch.empty(U, B, H, dtype=torch.float32, device=dev) if need else None
+        for b0 in range(0, B, MAXB):
+            b1 = min(B, b0 + MAXB)
+            sl = slice(b0, b1)
+            whole = (b0 == 0 and b1 == B)
+            gx = Gx if whole else Gx[:, sl].contiguous()
+            ho = Hout if whole else torch.empty(U, b1 - b0, H, dtype=torch.float32, device=dev)
+            ga = gates if (whole or not need) else torch.empty(U, b1 - b0, 4 * H, dtype=torch.float32, device=dev)
+            cs = Cs if (whole or not need) else torch.empty(U, b1 - b0, H, dtype=torch.float32, device=dev)
+            sc, n = _scratch(b1 - b0, H, dev)
+            st = L.ia_lstm_forward(_lib.ptr(gx), _lib.ptr(whh), _lib.ptr(ho), _lib.ptr(ga), _lib.ptr(cs), U, b1 - b0, H,
+                                   _lib.ptr(sc), n, _lib.stream_ptr())
+            _lib.check(st, "ia_lstm_forward")
+            if not whole:
+                Hout[:, sl] = ho
+                if need:
+                    gates[:, sl] = ga
+                    Cs[:, sl] = cs
+        if need:
+            ctx.save_for_backward(xb, wih, whh, Hout, gates, Cs)
+            ctx.dt = (x.dtype, w_ih.dtype, w_hh.dtype, b_ih.dtype, b_hh.dtype)
+        return Hout
+
+    @staticmethod
+    def backward(ctx, dH):
+        L = _lib.lib()
+        xb, wih, whh, Hout, gates, Cs = ctx.saved_tensors
+        U, B, H = xb.shape
+        dev = xb.device
+        dH = dH.float().contiguous()
+        whhT = whh.t().contiguous()
+        dG = torch.empty(U, B, 4 * H, dtype=torch.float32, device=dev)
+        for b0 in range(0, B, MAXB):
+            b1 = min(B, b0 + MAXB)
+            sl = slice(b0, b1)
+            whole = (b0 == 0 and b1 == B)
+            args = [t if whole else t[:, sl].contiguous() for t in (dH, gates, Cs)]
+            out = dG if whole else torch.empty(U, b1 - b0, 4 * H, dtype=torch.float32, device=dev)
+            sc, n = _scratch(b1 - b0, H, dev)
+            st = L.ia_lstm_backward(_lib.ptr(args[0]), _lib.ptr(args[1]), _lib.ptr(args[2]), _lib.ptr(whhT), _lib.ptr(out), U,
+                                    b1 - b0, H, _lib.ptr(sc), n, _lib.stream_ptr())
+            _lib.check(st, "ia_lstm_backward")
+            if not whole:
+                dG[:, sl] = out
+        xdt, wihdt, whhdt, bihdt, bhhdt = ctx.dt
+        dGb = dG.view(U * B, 4 * H).to(torch.bfloat16)
+        dx = torch.mm(dGb, wih).view(U, B, H).to(xdt) if ctx.needs_input_grad[0] else None
+        dWih = torch.mm(dGb.t(), xb.view(U * B, H), out_dtype=torch.float32).to(wihdt)
+        hprev = Hout[:-1].reshape((U - 1) * B, H).to(torch.bfloat16)
+        dWhh = (torch.mm(dGb[B:].t(), hprev, out_dtype=torch.float32) if U > 1
+                else torch.zeros(4 * H, H, dtype=torch.float32, device=dev)).to(whhdt)
+        db = dG.view(U * B, 4 * H).sum(0)
+        return dx, dWih, dWhh, db.to(bihdt), db.to(bhhdt)
+
+
+def lstm_forward(x, lstm: torch.nn.LSTM):
+    """x [U,B,H] -> (y [U,B,H] f32, (h_n, c_n) = None: the training step does not use the final state)."""
+    return _LSTMHip.apply(x, lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0)
