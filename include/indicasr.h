@@ -157,6 +157,8 @@ int ia_layernorm(const float* x, int ldx, int N, int d, const float* g1, const f
                  int ldf, const float* g2, const float* b2, void* outH, int ldh, ia_stream_t stream);
 int ia_glu_dwconv(const void* x2, const int64_t* lens, int B, int T, int d, int ksz, const float* w, const float* bias,
                   float* z, float* bn_sum, float* bn_sumsq, ia_stream_t stream);
+/* ia_colsum_bf16: out[n] += sum_m x[m,n] (f32 atomics, caller zeroes): bias gradient of a projection. */
+int ia_colsum_bf16(const void* x, int M, int N, int ld, float* out, ia_stream_t stream);
 /* Depthwise conv over time on fp32 [B,T,d] with autograd pieces (CausalConv1D as configured by the Conformer conv
  * module, causal_convs.py:72-150): y = bias + sum_j w[c][j] x[t+j-half]; flip=1 (bias NULL) gives the data gradient;
  * ia_dwconv_time_wgrad accumulates dw [d,ksz] and db [d] (f32 atomics; caller zeroes). */

@@ -36,6 +36,7 @@ SIGNATURES = {
     "ia_gemm_bf16": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _f, _c.c_uint, _f, _vp, _i, _vp, _i, _vp, _i, _vp]),
     "ia_layernorm": (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _vp, _i, _vp, _vp, _vp, _i, _vp]),
     "ia_glu_dwconv": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ia_colsum_bf16": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "ia_dwconv_time": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "ia_dwconv_time_wgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "ia_bn_silu": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp]),

@@ -95,13 +95,16 @@ class FlatParams:
     def weights(self, other: FlatDict):
         """Run with the parameters temporarily pointing at another flat buffer (LwF teacher forward) -- no
         torch.save/torch.load ping-pong and no barriers (R/cl_baseline_lwf.py:220-234 does both per batch)."""
+        from .ops import fast
         try:
             for n, p in zip(self.names, self.params):
                 p.data = other[n]
+            fast.bump_weight_epoch()
             yield
         finally:
             for n, p in zip(self.names, self.params):
                 p.data = self._theta_views[n]
+            fast.bump_weight_epoch()
 
 
 def flat_of(model) -> FlatParams:
@@ -305,3 +308,5 @@ class FusedAdamW:
                                       float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), self.step_count,
                                       float(scale), _lib.ptr(self.shadow), _lib.stream_ptr())
         _lib.check(st, "ia_adamw_step")
+        from .ops import fast
+        fast.bump_weight_epoch()  # the kernel rewrote theta by raw pointer: bf16 weight shadows are stale now

@@ -242,7 +242,31 @@ __global__ void bn_running_update_kernel(const float* __restrict__ bn_sum, const
     if (c == 0 && num_batches) num_batches[0] += 1;
 }
 
+// Column sums of a bf16 [M,N] matrix into fp32 (bias gradients): block = 64 columns x 4 row-quarters of a row chunk.
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const __bf16* __restrict__ x, int M, int N, int ld,
+                                                          float* __restrict__ out, int rows_per_block) {
+    __shared__ float sh[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * rows_per_block;
+    const int r1 = (r0 + rows_per_block < M) ? (r0 + rows_per_block) : M;
+    float s = 0.f;
+    if (col < N)
+        for (int r = r0 + part; r < r1; r += 4) s += (float)x[(size_t)r * ld + col];
+    sh[part][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (part == 0 && col < N) atomicAdd(out + col, sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+
 }  // namespace
+
+extern "C" int ia_colsum_bf16(const void* x, int M, int N, int ld, float* out, ia_stream_t stream) {
+    if (!x || !out || M <= 0 || N <= 0 || ld < N) return IA_INVALID_VALUE;
+    const int rpb = 512;
+    hipLaunchKernelGGL(colsum_bf16_kernel, dim3((N + 63) / 64, (M + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream,
+                       (const __bf16*)x, M, N, ld, out, rpb);
+    IA_RETURN_IF_LAUNCH_FAILED();
+    return IA_OK;
+}
 
 extern "C" int ia_layernorm(const float* x, int ldx, int N, int d, const float* g1, const float* b1, float eps,
                             float* outF, int ldf, const float* g2, const float* b2, void* outH, int ldh,

@@ -22,6 +22,14 @@ def subsampled_length(n):
     return (n - 1) // 2 + 1
 
 
+class FastLinear(nn.Linear):
+    """nn.Linear (same parameter names) whose forward/backward run on the HIP GEMM path inside the bf16 region."""
+
+    def forward(self, x):
+        from .ops import fast
+        return fast.linear(x, self.weight, self.bias)
+
+
 class ConvSubsampling(nn.Module):
     def __init__(self, feat_in, feat_out, conv_channels):
         super().__init__()
@@ -74,11 +82,11 @@ class RelPositionMultiHeadAttention(nn.Module):
     def __init__(self, n_head, n_feat, dropout_rate):
         super().__init__()
         self.d_k, self.h = n_feat // n_head, n_head
-        self.linear_q = nn.Linear(n_feat, n_feat)
-        self.linear_k = nn.Linear(n_feat, n_feat)
-        self.linear_v = nn.Linear(n_feat, n_feat)
-        self.linear_out = nn.Linear(n_feat, n_feat)
-        self.linear_pos = nn.Linear(n_feat, n_feat, bias=False)
+        self.linear_q = FastLinear(n_feat, n_feat)
+        self.linear_k = FastLinear(n_feat, n_feat)
+        self.linear_v = FastLinear(n_feat, n_feat)
+        self.linear_out = FastLinear(n_feat, n_feat)
+        self.linear_pos = FastLinear(n_feat, n_feat, bias=False)
         self.pos_bias_u = nn.Parameter(torch.zeros(self.h, self.d_k))
         self.pos_bias_v = nn.Parameter(torch.zeros(self.h, self.d_k))
         self.dropout_rate = dropout_rate
@@ -96,9 +104,9 @@ class RelPositionMultiHeadAttention(nn.Module):
 class ConformerFeedForward(nn.Module):
     def __init__(self, d_model, d_ff, dropout):
         super().__init__()
-        self.linear1 = nn.Linear(d_model, d_ff)
+        self.linear1 = FastLinear(d_model, d_ff)
         self.dropout = nn.Dropout(dropout)
-        self.linear2 = nn.Linear(d_ff, d_model)
+        self.linear2 = FastLinear(d_ff, d_model)
 
     def forward(self, x):
         return self.linear2(self.dropout(F.silu(self.linear1(x))))
@@ -122,11 +130,12 @@ class ConformerConvolution(nn.Module):
 
     def forward(self, x, pad_mask):
         # k=1 convolutions are plain projections over the feature axis: keep [B,T,d] and skip two transposes
-        x2 = F.linear(x, self.pointwise_conv1.weight.squeeze(-1), self.pointwise_conv1.bias)
+        from .ops import fast
+        x2 = fast.linear(x, self.pointwise_conv1.weight, self.pointwise_conv1.bias)
         y = ops.glu_dwconv_bn_silu(x2, pad_mask, self.depthwise_conv.weight, self.depthwise_conv.bias, self.batch_norm,
                                    self.training)
         y = y.to(x.dtype)
-        return F.linear(y, self.pointwise_conv2.weight.squeeze(-1), self.pointwise_conv2.bias)
+        return fast.linear(y, self.pointwise_conv2.weight, self.pointwise_conv2.bias)
 
 
 class ConformerLayer(nn.Module):

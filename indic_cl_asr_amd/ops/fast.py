@@ -5,13 +5,23 @@ import torch
 from .. import _lib
 
 _SHADOW = {}
+# Bumped whenever trainable weights change behind autograd's back (the fused AdamW kernel writes the flat buffer by
+# raw pointer, so tensor._version does not move; cl.FlatParams.weights() re-points .data).
+WEIGHT_EPOCH = 0
+
+
+def bump_weight_epoch():
+    global WEIGHT_EPOCH
+    WEIGHT_EPOCH += 1
+
 
 
 def bf16_shadow(*params):
     """bf16 copy of a parameter (or of several concatenated along dim 0), re-made only when a source version changes.
     Frozen layers therefore pay the fp32->bf16 cast once, not once per step as autocast does."""
     key = tuple(id(p) for p in params)
-    ver = tuple(p._version for p in params) + tuple(p.data_ptr() for p in params)
+    ver = tuple(p._version for p in params) + tuple(p.data_ptr() for p in params) + \
+        ((WEIGHT_EPOCH,) if any(p.requires_grad for p in params) else ())
     hit = _SHADOW.get(key)
     if hit is not None and hit[0] == ver:
         return hit[1]
@@ -25,7 +35,8 @@ def bf16_shadow(*params):
 
 def f32_cat(*params):
     key = ("f32",) + tuple(id(p) for p in params)
-    ver = tuple(p._version for p in params) + tuple(p.data_ptr() for p in params)
+    ver = tuple(p._version for p in params) + tuple(p.data_ptr() for p in params) + \
+        ((WEIGHT_EPOCH,) if any(p.requires_grad for p in params) else ())
     hit = _SHADOW.get(key)
     if hit is not None and hit[0] == ver:
         return hit[1]
@@ -107,3 +118,58 @@ def relpos_attention(qkv_bf16, pos_proj_bf16, bias_u, bias_v, lens, B, T, H, dk,
                                _lib.ptr(ctx), _lib.stream_ptr())
     _lib.check(st, "ia_relpos_attention")
     return ctx
+
+
+def colsum(x_bf16):
+    M, N = x_bf16.shape
+    out = torch.zeros(N, dtype=torch.float32, device=x_bf16.device)
+    st = _lib.lib().ia_colsum_bf16(_lib.ptr(x_bf16), M, N, x_bf16.stride(0), _lib.ptr(out), _lib.stream_ptr())
+    _lib.check(st, "ia_colsum_bf16")
+    return out
+
+
+class _LinearHip(torch.autograd.Function):
+    """y = x W^T + b for the trainable blocks: forward on the HIP GEMM (bias in the epilogue, bf16 out), data gradient
+    as a library GEMM, weight gradient as a batched split-K GEMM over row chunks (hipBLASLt's single TN GEMM launches
+    16-40 workgroups for these [256..1024 x 256..1024 x 12032] shapes: 70-80 us vs 28 us), bias gradient by ia_colsum."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        xb = x2.to(torch.bfloat16).contiguous()
+        wb = bf16_shadow(weight)
+        _, y = gemm(xb, wb, bias.detach().float() if bias is not None else None)
+        ctx.save_for_backward(xb, wb)
+        ctx.meta = (shp, x.dtype, weight.dtype, weight.shape, bias.dtype if bias is not None else None)
+        return y.view(*shp[:-1], wb.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        xb, wb = ctx.saved_tensors
+        shp, xdt, wdt, wshape, bdt = ctx.meta
+        dyb = dy.reshape(-1, wb.shape[0]).to(torch.bfloat16).contiguous()
+        M, N = dyb.shape
+        K = xb.shape[1]
+        dx = dW = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.mm(dyb, wb).view(shp).to(xdt)
+        if ctx.needs_input_grad[1]:
+            S = next((s for s in (8, 4, 2) if M % s == 0 and M // s >= 256), 1)
+            if S > 1:
+                dW = torch.bmm(dyb.view(S, M // S, N).transpose(1, 2), xb.view(S, M // S, K), out_dtype=torch.float32).sum(0)
+            else:
+                dW = torch.mm(dyb.t(), xb, out_dtype=torch.float32)
+            dW = dW.view(wshape).to(wdt)
+        if bdt is not None and ctx.needs_input_grad[2]:
+            db = colsum(dyb).to(bdt)
+        return dx, dW, db
+
+
+def linear(x, weight, bias=None):
+    """Drop-in for F.linear inside the bf16 (autocast) region of the trainable blocks."""
+    w2 = weight if weight.dim() == 2 else weight.reshape(weight.shape[0], -1)
+    if (x.is_cuda and torch.is_autocast_enabled() and gemm_supported(w2.shape[1], w2.shape[0])
+            and (x.requires_grad or weight.requires_grad)):
+        return _LinearHip.apply(x, weight, bias)
+    return torch.nn.functional.linear(x, w2, bias)

@@ -314,3 +314,33 @@ def test_fast_encoder_prefix_matches_aten_path_and_oracle():
     assert ((outs[0] - eo) * valid).abs().max().item() < 0.06 * ref_scale           # fused path vs fp32 oracle
     assert torch.allclose(stats[0], stats[1], rtol=2e-2, atol=1e-4)                  # BN running stats updated alike
     assert torch.allclose(stats[0], o.encoder.layers[2].conv.batch_norm.running_var, rtol=3e-2, atol=1e-4)
+
+
+def test_bf16_weight_shadows_follow_the_fused_optimizer():
+    """The AdamW kernel rewrites the flat parameter buffer by raw pointer (tensor._version does not move): the bf16
+    weight shadows used by the HIP GEMM paths must still be refreshed after every step and inside cl.weights()."""
+    from indic_cl_asr_amd import cl
+    from indic_cl_asr_amd.config import model_config
+    from indic_cl_asr_amd.model import EncDecHybridRNNTCTCModel
+    from indic_cl_asr_amd.ops import fast
+    torch.manual_seed(0)
+    m = EncDecHybridRNNTCTCModel(model_config('tiny', d_model=64, n_layers=2, pred_hidden=64, joint_hidden=64,
+                                              compute_dtype='bf16', dither=0.0)).disable_dropout().cuda().train()
+    flat = cl.FlatParams(m)
+    opt = cl.FusedAdamW(flat, lr=1e-2)
+    w = m.encoder.layers[1].feed_forward1.linear1.weight
+    s0 = fast.bf16_shadow(w).clone()
+    batch = tuple(t.cuda() for t in _batch())
+    losses = []
+    for _ in range(4):
+        opt.zero_grad()
+        loss, mon = m.training_step(batch, ['hi'] * 5)
+        loss.backward(); opt.step()
+        losses.append(mon['train_loss'])
+        assert torch.equal(fast.bf16_shadow(w), w.detach().bfloat16())
+    assert not torch.equal(fast.bf16_shadow(w), s0)
+    assert losses[-1] < losses[0]                     # the model actually trains through the shadowed weights
+    teacher = cl.get_zero_params(m)
+    with flat.weights(teacher):
+        assert fast.bf16_shadow(w).abs().max().item() == 0.0
+    assert torch.equal(fast.bf16_shadow(w), w.detach().bfloat16())

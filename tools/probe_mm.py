@@ -1,21 +1,26 @@
 import torch, time
 def bench(name, fn, fl):
     try:
-        for _ in range(2): fn()
+        for _ in range(3): fn()
         torch.cuda.synchronize(); t=time.time()
-        for _ in range(5): fn()
-        torch.cuda.synchronize(); dt=(time.time()-t)/5; print(f"{name}: {dt*1e3:.3f} ms  {fl/dt/1e12:.1f} TF/s")
+        for _ in range(20): fn()
+        torch.cuda.synchronize(); dt=(time.time()-t)/20; print(f"{name}: {dt*1e6:.1f} us  {fl/dt/1e12:.1f} TF/s")
     except Exception as e: print(name, "fail", repr(e)[:200])
-K=1275392
-GT=torch.randn(264,K,device='cuda',dtype=torch.float16); HT=torch.randn(648,K,device='cuda',dtype=torch.float16)
-G=GT.t().contiguous(); Hd=HT.t().contiguous()
-fl=2*264*648*K
-bench("TN  G.t() @ hid          ", lambda: torch.mm(G.t(), Hd, out_dtype=torch.float32), fl)
-bench("NT  GT @ HT.t()          ", lambda: torch.mm(GT, HT.t(), out_dtype=torch.float32), fl)
-bench("NT f16 out               ", lambda: torch.mm(GT, HT.t()), fl)
-GTb=GT.bfloat16(); HTb=HT.bfloat16()
-bench("NT bf16                  ", lambda: torch.mm(GTb, HTb.t(), out_dtype=torch.float32), fl)
-# split-K by hand: bmm over 64 chunks
-S=64; Kc=K//S
-GTc=GT[:,:S*Kc].reshape(264,S,Kc).permute(1,0,2).contiguous(); HTc=HT[:,:S*Kc].reshape(648,S,Kc).permute(1,0,2).contiguous()
-bench("bmm split-K 64           ", lambda: torch.bmm(GTc, HTc.transpose(1,2), out_dtype=torch.float32).sum(0), fl)
+M=12032
+for N,K in [(1024,256),(256,1024),(256,256),(768,256)]:
+    dY=torch.randn(M,N,device='cuda',dtype=torch.bfloat16); X=torch.randn(M,K,device='cuda',dtype=torch.bfloat16)
+    fl=2*M*N*K
+    print(f"--- dW[{N},{K}] = dY^T X, M={M}")
+    bench("TN mm              ", lambda: torch.mm(dY.t(), X), fl)
+    bench("TN mm f32 out      ", lambda: torch.mm(dY.t(), X, out_dtype=torch.float32), fl)
+    def tr_bmm(S):
+        dYt=dY.t().contiguous().view(N,S,M//S).transpose(0,1); Xt=X.t().contiguous().view(K,S,M//S).transpose(0,1)
+        return torch.bmm(dYt, Xt.transpose(1,2), out_dtype=torch.float32).sum(0)
+    for S in (4,8,16):
+        bench(f"transposes+bmm S={S:2d} ", lambda: tr_bmm(S), fl)
+    def view_bmm(S):
+        a=dY.view(S,M//S,N).transpose(1,2); b=X.view(S,M//S,K)
+        return torch.bmm(a,b,out_dtype=torch.float32).sum(0)
+    for S in (4,8,16,47):
+        bench(f"view bmm (TN) S={S:2d}   ", lambda: view_bmm(S), fl)
+    bench("transpose only      ", lambda: (dY.t().contiguous(), X.t().contiguous()), 0)
