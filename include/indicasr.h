@@ -204,6 +204,33 @@ int ia_lstm_backward(const float* dHout, const float* gates, const float* Cs, co
                      int B, int H, void* scratch, size_t scratch_bytes, ia_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Feature normalisation + SpecAugment in one pass over the log-mel tensor.
+ * Replaces normalize_batch('per_feature') A/parts/preprocessing/features.py:59-76 (a Python loop over the batch),
+ * the length masking :458-462 and spec_augment_kernel A/parts/numba/spec_augment/spec_aug_numba.py:26-95.
+ *   x, y [B,F,T] f32 (y may alias x); seq_len [B] i64; eps = 1e-5 added to the (unbiased) std.
+ *   freq_starts/widths [B,n_freq_masks] i32, time_starts/widths [B,n_time_masks] i32 (device; counts may be 0):
+ *   frequency spans mask whole rows, time spans only frames below seq_len[b].  Limit: T <= 4096. */
+int ia_feat_normalize(const float* x, const int64_t* seq_len, int B, int F, int T, float eps, const int* freq_starts,
+                      const int* freq_widths, int n_freq_masks, const int* time_starts, const int* time_widths,
+                      int n_time_masks, float mask_value, float* y, ia_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * CTC loss (ATen nn.CTCLoss semantics as used by A/losses/ctc.py:45-82: blank = num_classes, reduction 'none',
+ * zero_infinity): log_probs [B,T,V] f32 batch-major (what ConvASRDecoder.forward returns, conv_asr.py:459-490 -- the
+ * reference transposes to [T,B,V] first), targets [B,S] i64 padded, lens i64.
+ *   ia_ctc_forward : nll [B] f32 (0 for infeasible alignments under zero_infinity); alpha/beta stay in `workspace`.
+ *   ia_ctc_backward: grad [B,T,V] f32 = nll_grad[b] * (exp(lp) - exp(log sum_{s: l'_s = v} alpha_t(s) beta_t(s) + nll - lp)),
+ *                    zero for t >= input_lens[b] and for infeasible alignments (nll_grad NULL = ones).
+ *   workspace: ia_ctc_workspace_bytes(B,T,S), 256-byte aligned.  Limit: S <= 255 (extended length 2S+1 <= 512). */
+size_t ia_ctc_workspace_bytes(int B, int T, int S);
+int ia_ctc_forward(const float* log_probs, const int64_t* targets, const int64_t* input_lens, const int64_t* target_lens,
+                   int B, int T, int V, int S, int blank, int zero_infinity, float* nll, void* workspace,
+                   size_t workspace_bytes, ia_stream_t stream);
+int ia_ctc_backward(const float* log_probs, const int64_t* targets, const int64_t* input_lens, const int64_t* target_lens,
+                    int B, int T, int V, int S, int blank, const float* nll_grad, float* grad, void* workspace,
+                    size_t workspace_bytes, ia_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Continual-learning regularisers and optimizer over ONE flat fp32 buffer holding every trainable parameter
  * (tensor k occupies [off_k, off_k + numel_k), off_k a multiple of 64 floats, gaps zero-filled).
  *

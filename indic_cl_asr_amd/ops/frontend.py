@@ -18,19 +18,25 @@ def log_mel(signal, window, fb, n_fft=512, hop=160, preemph=0.97, dither=0.0, se
         return torch.log(mel + log_guard)
 
 
-def normalize_mask(x, seq_len, spec_aug=None, eps=1e-5):
+def normalize_mask(x, seq_len, spec_aug=None, eps=1e-5, mask_value=0.0):
     """Per-utterance per-feature mean / unbiased std over the valid frames, +1e-5, zero beyond seq_len
-    (features.py:59-76,458-462), no Python loop over the batch; optional SpecAugment fill in the same pass."""
+    (features.py:59-76,458-462) with the SpecAugment fill in the same pass: one HIP launch (csrc/frontend.hip)."""
+    from .. import _lib
     B, F, T = x.shape
-    valid = (torch.arange(T, device=x.device)[None, :] < seq_len[:, None])  # [B,T]
-    vf = valid.unsqueeze(1).to(x.dtype)
-    n = seq_len.to(x.dtype).view(B, 1, 1)
-    mean = (x * vf).sum(-1, keepdim=True) / n
-    var = (((x - mean) * vf) ** 2).sum(-1, keepdim=True) / (n - 1.0)
-    y = (x - mean) / (var.sqrt() + eps)
-    y = y * vf
+    if not x.is_cuda or T > 4096:
+        raise RuntimeError("normalize_mask: device tensor with Tm <= 4096 required")
+    x = x.float().contiguous()
+    y = torch.empty_like(x)
     if spec_aug is not None:
-        y = spec_augment_(y, seq_len, spec_aug, 0.0)
+        fs, fw, ts, tw = (t.int().contiguous() for t in spec_aug)
+        nf, nt = fs.shape[1], ts.shape[1]
+    else:
+        fs = fw = ts = tw = None
+        nf = nt = 0
+    st = _lib.lib().ia_feat_normalize(_lib.ptr(x), _lib.ptr(seq_len.long().contiguous()), B, F, T, float(eps), _lib.ptr(fs),
+                                      _lib.ptr(fw), nf, _lib.ptr(ts), _lib.ptr(tw), nt, float(mask_value), _lib.ptr(y),
+                                      _lib.stream_ptr())
+    _lib.check(st, "ia_feat_normalize")
     return y
 
 
