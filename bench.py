@@ -69,12 +69,14 @@ class HipEvents:
         assert self.hip.hipEventCreate(ctypes.byref(e)) == 0
         return e
 
-    def hook(self, B, T, U1, V, elem_bytes=4):
+    def hook(self, B, T, U1, V, elem_bytes=4, passes=2):
+        """passes = lattice-sized streams the kernel must move: fp32 path read logits + write grads (2);
+        fused f16 path read logits + write G in place + write G^T for the split-K weight-gradient GEMM (3)."""
         if not self.enabled:
             return None
         a, b = self._new(), self._new()
         self.pairs.append((a, b))
-        self.shapes.append((B, T, U1, V, elem_bytes))
+        self.shapes.append((B, T, U1, V, elem_bytes * passes / 2.0))
         return a, b
 
     def summary(self):
@@ -167,7 +169,7 @@ def main():
     events = HipEvents()
     rnnt_mod.PROFILE_HOOK = events.hook
     if model.joint.use_fused and args.dtype == "bf16":
-        events.kernel_name = "joint_grad_h_kernel"  # the fused path's f16 in-place gradient kernel
+        events.kernel_name = "joint_grad_h_t_kernel"  # the fused path's f16 gradient kernel (in place + transposed copy)
 
     def step():
         opt.zero_grad()
@@ -215,8 +217,15 @@ def main():
         if s is not None:
             avg_ms, avg_bytes, n = s
             ach = avg_bytes / (avg_ms * 1e-3) / 1e9
+            traffic = None
+            try:  # HBM bytes per launch from the committed PMC passes of the same command (profiles/r01_pmc_traffic.json)
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+                if args.batch == 32 and args.seconds == 15.0 and args.preset == "medium":
+                    traffic = pmc["kernels"].get(events.kernel_name, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
             out["roofline"] = {"kernel": events.kernel_name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                               "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                                "launches": n, "avg_launch_ms": round(avg_ms, 4),
                                "algorithmic_bytes_per_launch": int(avg_bytes)}
         if not args.no_cpu_baseline and world == 1:

@@ -68,7 +68,7 @@ class _FusedJointRNNT(torch.autograd.Function):
         ctx.saved = None
         dev = f16.device
         cg = gcosts.reshape(-1).float().contiguous()
-        hook = rl.PROFILE_HOOK(B, T, U1, V, 2) if rl.PROFILE_HOOK is not None else None
+        hook = rl.PROFILE_HOOK(B, T, U1, V, 2, 3) if rl.PROFILE_HOOK is not None else None
         ev0, ev1 = hook if hook is not None else (None, None)
         # split-K layout for the weight gradient: S chunks of Kc lattice cells, both GEMM operands K-contiguous
         cells = B * T * U1
