@@ -210,6 +210,21 @@ int ia_lstm_backward(const float* dHout, const float* gates, const float* Cs, co
  *   x, y [B,F,T] f32 (y may alias x); seq_len [B] i64; eps = 1e-5 added to the (unbiased) std.
  *   freq_starts/widths [B,n_freq_masks] i32, time_starts/widths [B,n_time_masks] i32 (device; counts may be 0):
  *   frequency spans mask whole rows, time spans only frames below seq_len[b].  Limit: T <= 4096. */
+/* Log-mel front end (FilterbankFeatures.forward A/parts/preprocessing/features.py:400-444) as five launches:
+ *   ia_feat_frames   dither (counter-based N(0,1) keyed by (seed,b,sample)) + pre-emphasis (first sample kept, :414) +
+ *                    centred, reflect-padded framing: frames [B*Tm, ldf] f32 (columns >= win zero)
+ *   ia_gemm_f32      spec = frames @ basis^T   -- windowed real DFT as an exact-fp32 matrix-core GEMM
+ *                    (basis [2*half, ldf]: rows k < half: w[n] cos(2 pi k (n+off)/n_fft), rows half+k: the sines)
+ *   ia_feat_power    power [M, ldp] = re^2 + im^2 (:424-433), columns >= nbins zero
+ *   ia_gemm_f32      mel = power @ fb^T        -- fb [n_mels, ldp] (Slaney filterbank, :327-333,440)
+ *   ia_feat_logmel_t out [B, n_mels, Tm] = log(mel + guard) (:444)
+ * ia_gemm_f32: C[M,N] = A[M,K] @ W[N,K]^T in exact fp32 (v_mfma_f32_16x16x4_f32); K % 16 == 0. */
+int ia_feat_frames(const float* audio, int B, int L, int Tm, int win, int hop, float preemph, float dither, unsigned seed,
+                   float* frames, int ldf, ia_stream_t stream);
+int ia_gemm_f32(const float* A, int lda, const float* W, int ldw, int M, int N, int K, float* C, int ldc,
+                ia_stream_t stream);
+int ia_feat_power(const float* spec, int64_t M, int lds, int half, int nbins, float* power, int ldp, ia_stream_t stream);
+int ia_feat_logmel_t(const float* mel, int B, int Tm, int F, int ldm, float guard, float* out, ia_stream_t stream);
 int ia_feat_normalize(const float* x, const int64_t* seq_len, int B, int F, int T, float eps, const int* freq_starts,
                       const int* freq_widths, int n_freq_masks, const int* time_starts, const int* time_widths,
                       int n_time_masks, float mask_value, float* y, ia_stream_t stream);

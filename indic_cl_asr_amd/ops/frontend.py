@@ -1,21 +1,73 @@
 """Front-end ops: log-mel features, per-feature normalisation + length masking + SpecAugment fill."""
+import math
+
 import torch
 
 
+_BASIS = {}
+
+
+def _dft_basis(window, n_fft, ldf, device):
+    """[2*half, ldf] f32: Hann-windowed cos / sin rows of the centred n_fft-point real DFT restricted to the window's
+    support (torch.stft pads the window to n_fft centred: sample n of the window sits at n + (n_fft - win)//2)."""
+    key = (window.data_ptr(), window._version, n_fft, ldf, str(device))
+    hit = _BASIS.get(key)
+    if hit is not None:
+        return hit
+    win = window.numel()
+    nb = n_fft // 2 + 1
+    half = (nb + 15) // 16 * 16
+    off = (n_fft - win) // 2
+    n = torch.arange(win, dtype=torch.float64)
+    k = torch.arange(nb, dtype=torch.float64).unsqueeze(1)
+    ang = 2.0 * math.pi * k * (n + off) / n_fft
+    w = window.detach().double().cpu()
+    basis = torch.zeros(2 * half, ldf, dtype=torch.float64)
+    basis[:nb, :win] = torch.cos(ang) * w
+    basis[half:half + nb, :win] = torch.sin(ang) * w
+    out = (basis.float().to(device).contiguous(), half, nb)
+    _BASIS[key] = out
+    return out
+
+
 def log_mel(signal, window, fb, n_fft=512, hop=160, preemph=0.97, dither=0.0, seed=0, log_guard=2 ** -24):
-    """[B,L] f32 audio -> [B,n_mels,Tm] f32 log-mel power (features.py:408-444)."""
-    x = signal
-    if dither > 0.0:
-        g = torch.Generator(device=x.device)
-        g.manual_seed(int(seed))
-        x = x + dither * torch.randn(x.shape, device=x.device, dtype=x.dtype, generator=g)
-    x = torch.cat((x[:, :1], x[:, 1:] - preemph * x[:, :-1]), dim=1)
-    with torch.autocast(device_type=x.device.type, enabled=False):
-        spec = torch.stft(x.float(), n_fft=n_fft, hop_length=hop, win_length=window.numel(), center=True,
-                          window=window.float(), return_complex=True)
-        power = spec.real.square() + spec.imag.square()
-        mel = torch.matmul(fb.float(), power)
-        return torch.log(mel + log_guard)
+    """[B,L] f32 audio -> [B,n_mels,Tm] f32 log-mel power (features.py:408-444) on the HIP front end
+    (csrc/frontend.hip + csrc/gemm_f32.hip): framing kernel, exact-fp32 MFMA DFT, power, exact-fp32 MFMA mel
+    projection, log + transpose."""
+    from .. import _lib
+    L_ = _lib.lib()
+    if not signal.is_cuda:
+        raise RuntimeError("log_mel: device tensor required (no CPU path in the product)")
+    x = signal.float().contiguous()
+    B, L = x.shape
+    win = window.numel()
+    Tm = (L + (n_fft // 2) * 2 - n_fft) // hop + 1
+    ldf = (win + 15) // 16 * 16
+    basis, half, nb = _dft_basis(window, n_fft, ldf, x.device)
+    M = B * Tm
+    dev = x.device
+    frames = torch.empty(M, ldf, dtype=torch.float32, device=dev)
+    _lib.check(L_.ia_feat_frames(_lib.ptr(x), B, L, Tm, win, hop, float(preemph), float(dither), int(seed) & 0xFFFFFFFF,
+                                 _lib.ptr(frames), ldf, _lib.stream_ptr()), "ia_feat_frames")
+    spec = torch.empty(M, 2 * half, dtype=torch.float32, device=dev)
+    _lib.check(L_.ia_gemm_f32(_lib.ptr(frames), ldf, _lib.ptr(basis), ldf, M, 2 * half, ldf, _lib.ptr(spec), 2 * half,
+                              _lib.stream_ptr()), "ia_gemm_f32")
+    power = torch.empty(M, half, dtype=torch.float32, device=dev)
+    _lib.check(L_.ia_feat_power(_lib.ptr(spec), M, 2 * half, half, nb, _lib.ptr(power), half, _lib.stream_ptr()),
+               "ia_feat_power")
+    nm = fb.shape[0]
+    fbp = _BASIS.get(("fb", fb.data_ptr(), fb._version, half))
+    if fbp is None:
+        fbp = torch.zeros(nm, half, dtype=torch.float32, device=dev)
+        fbp[:, :nb] = fb.float()
+        _BASIS[("fb", fb.data_ptr(), fb._version, half)] = fbp
+    mel = torch.empty(M, nm, dtype=torch.float32, device=dev)
+    _lib.check(L_.ia_gemm_f32(_lib.ptr(power), half, _lib.ptr(fbp), half, M, nm, half, _lib.ptr(mel), nm,
+                              _lib.stream_ptr()), "ia_gemm_f32")
+    out = torch.empty(B, nm, Tm, dtype=torch.float32, device=dev)
+    _lib.check(L_.ia_feat_logmel_t(_lib.ptr(mel), B, Tm, nm, nm, float(log_guard), _lib.ptr(out), _lib.stream_ptr()),
+               "ia_feat_logmel_t")
+    return out
 
 
 def normalize_mask(x, seq_len, spec_aug=None, eps=1e-5, mask_value=0.0):
