@@ -153,6 +153,19 @@ int ia_joint_dh_reduce(const void* dh, const void* f, const void* g, const int64
 int ia_gemm_bf16(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const float* bias, int act,
                  float dropout_p, unsigned seed, float alpha, const float* R, int ldr, float* outF, int ldof,
                  void* outH, int ldoh, ia_stream_t stream);
+/* ConvSubsampling 'striding' x4 (A/parts/submodules/subsampling.py:217-253,385-437), channels-last, no transposes:
+ *   ia_subsample_conv1: feats [B,Fm,Tm] f32 (preprocessor layout) -> relu(conv 1->C, 3x3, s2, p1) as [B,T1,F1,C] bf16
+ *                       (w1 [C,9] f32 = conv.0.weight, b1 [C]); T1 = (Tm-1)/2+1, F1 = (Fm-1)/2+1.
+ *   ia_subsample_conv2: implicit-GEMM 3x3 / s2 / p1 convolution C -> N on the matrix cores (A fragments gathered from
+ *                       the channels-last image, zero padding by predication, bias + ReLU epilogue):
+ *                       in [B,T1,F1,C] bf16, w2r [N, 9*C] bf16 with k = (dt*3+df)*C + ci (= conv.2.weight permuted
+ *                       to [N,3,3,C]), out [B,T2,F2,N] bf16.  C % 64 == 0.
+ *   The final Linear(C*F2 -> d) is ia_gemm_bf16 on the [B*T2, F2*N] view with the weight's columns permuted from the
+ *   reference's (c,f) order to (f,c). */
+int ia_subsample_conv1(const float* feats, int B, int Fm, int Tm, int C, const float* w1, const float* b1, void* out,
+                       ia_stream_t stream);
+int ia_subsample_conv2(const void* in_cl, int B, int T1, int F1, int C, const void* w2r, const float* b2, int N, void* out,
+                       ia_stream_t stream);
 int ia_layernorm(const float* x, int ldx, int N, int d, const float* g1, const float* b1, float eps, float* outF,
                  int ldf, const float* g2, const float* b2, void* outH, int ldh, ia_stream_t stream);
 int ia_glu_dwconv(const void* x2, const int64_t* lens, int B, int T, int d, int ksz, const float* w, const float* bias,

@@ -34,6 +34,8 @@ SIGNATURES = {
     "ia_joint_hidden": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _c.c_uint, _vp]),
     "ia_joint_dh_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _c.c_uint, _vp]),
     "ia_gemm_bf16": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _f, _c.c_uint, _f, _vp, _i, _vp, _i, _vp, _i, _vp]),
+    "ia_subsample_conv1": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "ia_subsample_conv2": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "ia_layernorm": (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _vp, _i, _vp, _vp, _vp, _i, _vp]),
     "ia_glu_dwconv": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ia_colsum_bf16": (_i, [_vp, _i, _i, _i, _vp, _vp]),

@@ -31,6 +31,9 @@ struct GemmArgs {
     float alpha;
     unsigned seed, thr; // dropout keep if byte >= thr (thr = round(256 p)); scale 1/(1-thr/256) folded in `alpha_keep`
     float keep_scale;
+    // implicit-GEMM mode (CONV): A is a channels-last image [cB, cT1, cF1, cC]; row m = (b, t2, f2) of the 3x3 / stride-2 /
+    // pad-1 convolution output [cB, cT2, cF2, N]; k = tap*cC + ci.
+    int cT1, cF1, cC, cT2, cF2;
 };
 
 __device__ __forceinline__ unsigned g_hash32(unsigned x) {
@@ -38,7 +41,17 @@ __device__ __forceinline__ unsigned g_hash32(unsigned x) {
     return x;
 }
 
-template <int BM, int BN>
+struct ConvRow { int b, t2, f2; };  // output pixel of a tile row (t2 < 0: row past M)
+
+__device__ __forceinline__ uint4 conv_a_load(const GemmArgs& a, const ConvRow& r, int k0, int kv) {
+    const int tap = k0 / a.cC, c0 = k0 - tap * a.cC;
+    const int dt = tap / 3, df = tap - dt * 3;
+    const int t1 = 2 * r.t2 + dt - 1, f1 = 2 * r.f2 + df - 1;
+    if (r.t2 < 0 || t1 < 0 || t1 >= a.cT1 || f1 < 0 || f1 >= a.cF1) return make_uint4(0, 0, 0, 0);
+    return *reinterpret_cast<const uint4*>(a.A + (((size_t)r.b * a.cT1 + t1) * a.cF1 + f1) * a.cC + c0 + kv * 8);
+}
+
+template <int BM, int BN, bool CONV = false>
 __global__ __launch_bounds__(G_THREADS) void gemm_bf16_nt_kernel(GemmArgs a) {
     constexpr int WM = BM / 2, WN = BN / 2, TI = WM / 16, TJ = WN / 16;
     constexpr int A_BYTES = BM * G_ROWB, B_BYTES = BN * G_ROWB, STAGE = A_BYTES + B_BYTES;
@@ -53,14 +66,23 @@ __global__ __launch_bounds__(G_THREADS) void gemm_bf16_nt_kernel(GemmArgs a) {
     const int m0 = (blockIdx.x / ntn) * BM, n0 = (blockIdx.x % ntn) * BN;
 
     static_assert(BV == 4 && (AV == 2 || AV == 4), "staging registers are named (arrays end up in scratch)");
+    ConvRow crow[4];
+    if constexpr (CONV) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + ((tid + i * G_THREADS) >> 3);
+            const int f2 = m % a.cF2, bt = m / a.cF2;
+            crow[i].f2 = f2; crow[i].t2 = (m < a.M) ? (bt % a.cT2) : -1; crow[i].b = bt / a.cT2;
+        }
+    }
     uint4 ra0, ra1, ra2 = make_uint4(0, 0, 0, 0), ra3 = make_uint4(0, 0, 0, 0), rb0, rb1, rb2, rb3;
 #define G_LOAD(k0_) \
     do { \
-        { const int idx_ = tid + 0 * G_THREADS, row_ = idx_ >> 3, kv_ = idx_ & 7; const int gr_ = (m0 + row_ < a.M) ? (m0 + row_) : (a.M - 1); ra0 = *reinterpret_cast<const uint4*>(a.A + (size_t)gr_ * a.lda + (k0_) + kv_ * 8); } \
-        { const int idx_ = tid + 1 * G_THREADS, row_ = idx_ >> 3, kv_ = idx_ & 7; const int gr_ = (m0 + row_ < a.M) ? (m0 + row_) : (a.M - 1); ra1 = *reinterpret_cast<const uint4*>(a.A + (size_t)gr_ * a.lda + (k0_) + kv_ * 8); } \
+        { const int idx_ = tid + 0 * G_THREADS, kv_ = idx_ & 7; if constexpr (CONV) { ra0 = conv_a_load(a, crow[0], (k0_), kv_); } else { const int row_ = idx_ >> 3; const int gr_ = (m0 + row_ < a.M) ? (m0 + row_) : (a.M - 1); ra0 = *reinterpret_cast<const uint4*>(a.A + (size_t)gr_ * a.lda + (k0_) + kv_ * 8); } } \
+        { const int idx_ = tid + 1 * G_THREADS, kv_ = idx_ & 7; if constexpr (CONV) { ra1 = conv_a_load(a, crow[1], (k0_), kv_); } else { const int row_ = idx_ >> 3; const int gr_ = (m0 + row_ < a.M) ? (m0 + row_) : (a.M - 1); ra1 = *reinterpret_cast<const uint4*>(a.A + (size_t)gr_ * a.lda + (k0_) + kv_ * 8); } } \
         if constexpr (AV == 4) { \
-        { const int idx_ = tid + 2 * G_THREADS, row_ = idx_ >> 3, kv_ = idx_ & 7; const int gr_ = (m0 + row_ < a.M) ? (m0 + row_) : (a.M - 1); ra2 = *reinterpret_cast<const uint4*>(a.A + (size_t)gr_ * a.lda + (k0_) + kv_ * 8); } \
-        { const int idx_ = tid + 3 * G_THREADS, row_ = idx_ >> 3, kv_ = idx_ & 7; const int gr_ = (m0 + row_ < a.M) ? (m0 + row_) : (a.M - 1); ra3 = *reinterpret_cast<const uint4*>(a.A + (size_t)gr_ * a.lda + (k0_) + kv_ * 8); } \
+        { const int idx_ = tid + 2 * G_THREADS, kv_ = idx_ & 7; if constexpr (CONV) { ra2 = conv_a_load(a, crow[2], (k0_), kv_); } else { const int row_ = idx_ >> 3; const int gr_ = (m0 + row_ < a.M) ? (m0 + row_) : (a.M - 1); ra2 = *reinterpret_cast<const uint4*>(a.A + (size_t)gr_ * a.lda + (k0_) + kv_ * 8); } } \
+        { const int idx_ = tid + 3 * G_THREADS, kv_ = idx_ & 7; if constexpr (CONV) { ra3 = conv_a_load(a, crow[3], (k0_), kv_); } else { const int row_ = idx_ >> 3; const int gr_ = (m0 + row_ < a.M) ? (m0 + row_) : (a.M - 1); ra3 = *reinterpret_cast<const uint4*>(a.A + (size_t)gr_ * a.lda + (k0_) + kv_ * 8); } } \
         } \
         { const int idx_ = tid + 0 * G_THREADS, row_ = idx_ >> 3, kv_ = idx_ & 7; const int gr_ = (n0 + row_ < a.N) ? (n0 + row_) : (a.N - 1); rb0 = *reinterpret_cast<const uint4*>(a.W + (size_t)gr_ * a.ldw + (k0_) + kv_ * 8); } \
         { const int idx_ = tid + 1 * G_THREADS, row_ = idx_ >> 3, kv_ = idx_ & 7; const int gr_ = (n0 + row_ < a.N) ? (n0 + row_) : (a.N - 1); rb1 = *reinterpret_cast<const uint4*>(a.W + (size_t)gr_ * a.ldw + (k0_) + kv_ * 8); } \
@@ -180,15 +202,15 @@ __global__ __launch_bounds__(G_THREADS) void gemm_bf16_nt_kernel(GemmArgs a) {
     }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool CONV = false>
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
     constexpr int STAGE = (BM + BN) * G_ROWB;
     const size_t lds = 2 * (size_t)STAGE;
     const int grid = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     if (lds > 64 * 1024 &&
-        hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<BM, BN, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return IA_LAUNCH_FAILED;
-    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN>), dim3(grid), dim3(G_THREADS), lds, st, a);
+    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, CONV>), dim3(grid), dim3(G_THREADS), lds, st, a);
     IA_RETURN_IF_LAUNCH_FAILED();
     return IA_OK;
 }
@@ -211,9 +233,71 @@ extern "C" int ia_gemm_bf16(const void* A, int lda, const void* W, int ldw, int 
     a.act = act; a.alpha = alpha; a.seed = seed;
     a.thr = (unsigned)(dropout_p * 256.f + 0.5f);
     a.keep_scale = a.thr > 0 ? 256.f / (256.f - (float)a.thr) : 1.f;
+    a.cT1 = a.cF1 = a.cC = a.cT2 = a.cF2 = 0;
     hipStream_t st = (hipStream_t)stream;
     // tile choice: 128x128 tiles when they already give every CU work, else 64-row tiles (twice the workgroups)
     const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     if (tiles128 >= 256) return launch_gemm<128, 128>(a, st);
     return launch_gemm<64, 128>(a, st);
+}
+
+// ---- ConvSubsampling ('striding', x4): A/parts/submodules/subsampling.py:217-253,385-437 --------------------------
+namespace {
+// First convolution (1 -> C channels, 3x3, stride 2, pad 1) + ReLU, channels-last bf16 output [B,T1,F1,C]; the input
+// is the feature tensor as the preprocessor emits it, x[b][f][t] (reference: x.transpose(1,2).unsqueeze(1)).
+__global__ __launch_bounds__(256) void conv1_relu_cl_kernel(const float* __restrict__ x, int B, int Fm, int Tm, int T1, int F1,
+                                                            int C, const float* __restrict__ w, const float* __restrict__ bias,
+                                                            __bf16* __restrict__ out) {
+    const int cg = C / 8;
+    const int64_t total = (int64_t)B * T1 * F1 * cg;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c0 = (int)(i % cg) * 8;
+        int64_t p = i / cg;
+        const int f1 = (int)(p % F1); p /= F1;
+        const int t1 = (int)(p % T1);
+        const int b = (int)(p / T1);
+        float px[9];
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+            for (int df = 0; df < 3; ++df) {
+                const int t = 2 * t1 + dt - 1, f = 2 * f1 + df - 1;
+                px[dt * 3 + df] = (t >= 0 && t < Tm && f >= 0 && f < Fm) ? x[((size_t)b * Fm + f) * Tm + t] : 0.f;
+            }
+        union { uint4 u; __bf16 h[8]; } o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float acc = bias[c0 + j];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc += w[(c0 + j) * 9 + k] * px[k];
+            o.h[j] = (__bf16)fmaxf(acc, 0.f);
+        }
+        *reinterpret_cast<uint4*>(out + (size_t)(i / cg) * C + c0) = o.u;
+    }
+}
+}  // namespace
+
+extern "C" int ia_subsample_conv1(const float* feats, int B, int Fm, int Tm, int C, const float* w1, const float* b1,
+                                  void* out, ia_stream_t stream) {
+    if (!feats || !w1 || !b1 || !out || B <= 0 || Fm <= 0 || Tm <= 0 || C <= 0 || C % 8 != 0) return IA_INVALID_VALUE;
+    const int T1 = (Tm - 1) / 2 + 1, F1 = (Fm - 1) / 2 + 1;
+    const int64_t total = (int64_t)B * T1 * F1 * (C / 8);
+    const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipLaunchKernelGGL(conv1_relu_cl_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, feats, B, Fm, Tm, T1, F1, C, w1, b1,
+                       (__bf16*)out);
+    IA_RETURN_IF_LAUNCH_FAILED();
+    return IA_OK;
+}
+
+extern "C" int ia_subsample_conv2(const void* in_cl, int B, int T1, int F1, int C, const void* w2r, const float* b2, int N,
+                                  void* out, ia_stream_t stream) {
+    if (!in_cl || !w2r || !b2 || !out || B <= 0 || T1 <= 0 || F1 <= 0) return IA_INVALID_VALUE;
+    if (C % G_BK != 0 || N % 8 != 0 || !ia_is_aligned(in_cl, 16) || !ia_is_aligned(w2r, 16) || !ia_is_aligned(out, 16))
+        return IA_UNSUPPORTED;
+    GemmArgs a;
+    a.A = (const __bf16*)in_cl; a.W = (const __bf16*)w2r; a.bias = b2; a.R = nullptr; a.outF = nullptr; a.outH = (__bf16*)out;
+    a.cT1 = T1; a.cF1 = F1; a.cC = C; a.cT2 = (T1 - 1) / 2 + 1; a.cF2 = (F1 - 1) / 2 + 1;
+    a.M = B * a.cT2 * a.cF2; a.N = N; a.K = 9 * C; a.lda = 0; a.ldw = 9 * C; a.ldr = 0; a.ldof = 0; a.ldoh = N;
+    a.act = 2; a.alpha = 1.f; a.seed = 0; a.thr = 0; a.keep_scale = 1.f;
+    return launch_gemm<128, 128, true>(a, (hipStream_t)stream);
 }

@@ -246,8 +246,16 @@ class ConformerEncoder(nn.Module):
         """audio_signal [B,feat,Tm] f32, length [B] i64 -> (encoded [B,d,T'], encoded_len [B] i64)."""
         with self._amp(audio_signal):
             with (torch.no_grad() if self.encoder_frozen_till > 0 else nullcontext()):
-                x = audio_signal.transpose(1, 2)
-                x, length = self.pre_encode(x, length)
+                from .ops import fast
+                pe = self.pre_encode
+                if (self.use_fast_path and self.cfg.compute_dtype == "bf16" and audio_signal.is_cuda
+                        and not (torch.is_grad_enabled() and any(p.requires_grad for p in pe.parameters()))
+                        and fast.subsample_supported(pe.conv[0].weight.shape[0], self.d_model, self.cfg.feat_in)):
+                    x = fast.conv_subsampling(audio_signal, pe.conv[0], pe.conv[2], pe.out)
+                    length = subsampled_length(length)
+                else:
+                    x = audio_signal.transpose(1, 2)
+                    x, length = pe(x, length)
                 length = length.to(torch.int64)
                 T = x.size(1)
                 x, pos_emb = self.pos_enc(x)

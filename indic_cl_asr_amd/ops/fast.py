@@ -173,3 +173,47 @@ def linear(x, weight, bias=None):
             and (x.requires_grad or weight.requires_grad)):
         return _LinearHip.apply(x, weight, bias)
     return torch.nn.functional.linear(x, w2, bias)
+
+
+def _cached(key, params, make):
+    ver = tuple(p._version for p in params) + tuple(p.data_ptr() for p in params) + \
+        ((WEIGHT_EPOCH,) if any(p.requires_grad for p in params) else ())
+    hit = _SHADOW.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    with torch.no_grad():
+        val = make()
+    _SHADOW[key] = (ver, val)
+    return val
+
+
+def subsample_supported(C, d, feat_in):
+    return C % 64 == 0 and d % 8 == 0 and (C * (((feat_in - 1) // 2 + 1 - 1) // 2 + 1)) % 64 == 0
+
+
+def conv_subsampling(feats_bft, conv1, conv2, lin):
+    """feats [B,feat_in,Tm] f32 -> [B*T2, d] f32 (ConvSubsampling.forward, subsampling.py:385-437) on the HIP path:
+    direct conv1+ReLU (channels-last), implicit-GEMM conv2+ReLU on the matrix cores, Linear on the bf16 GEMM."""
+    L = _lib.lib()
+    x = feats_bft.float().contiguous()
+    B, Fm, Tm = x.shape
+    C = conv1.weight.shape[0]
+    T1, F1 = (Tm - 1) // 2 + 1, (Fm - 1) // 2 + 1
+    T2, F2 = (T1 - 1) // 2 + 1, (F1 - 1) // 2 + 1
+    dev = x.device
+    w1 = _cached(("sub_w1", id(conv1.weight)), [conv1.weight], lambda: conv1.weight.detach().float().reshape(C, 9).contiguous())
+    o1 = torch.empty(B * T1 * F1, C, dtype=torch.bfloat16, device=dev)
+    _lib.check(L.ia_subsample_conv1(_lib.ptr(x), B, Fm, Tm, C, _lib.ptr(w1), _lib.ptr(conv1.bias), _lib.ptr(o1),
+                                    _lib.stream_ptr()), "ia_subsample_conv1")
+    N = conv2.weight.shape[0]
+    w2r = _cached(("sub_w2", id(conv2.weight)), [conv2.weight],
+                  lambda: conv2.weight.detach().permute(0, 2, 3, 1).reshape(N, 9 * C).to(torch.bfloat16).contiguous())
+    o2 = torch.empty(B * T2 * F2, N, dtype=torch.bfloat16, device=dev)
+    _lib.check(L.ia_subsample_conv2(_lib.ptr(o1), B, T1, F1, C, _lib.ptr(w2r), _lib.ptr(conv2.bias), N, _lib.ptr(o2),
+                                    _lib.stream_ptr()), "ia_subsample_conv2")
+    d = lin.weight.shape[0]
+    wl = _cached(("sub_wl", id(lin.weight)), [lin.weight],
+                 lambda: lin.weight.detach().view(d, N, F2).permute(0, 2, 1).reshape(d, F2 * N).to(torch.bfloat16).contiguous())
+    y = torch.empty(B * T2, d, dtype=torch.float32, device=dev)
+    gemm(o2.view(B * T2, F2 * N), wl, lin.bias, out_f32=y, want_bf16=False)
+    return y.view(B, T2, d)
