@@ -248,14 +248,24 @@ namespace {
 __global__ __launch_bounds__(256) void conv1_relu_cl_kernel(const float* __restrict__ x, int B, int Fm, int Tm, int T1, int F1,
                                                             int C, const float* __restrict__ w, const float* __restrict__ bias,
                                                             __bf16* __restrict__ out) {
+    // thread = 8 fixed output channels (weights in registers) x a strided set of output pixels; the C/8 threads that
+    // share a pixel read the same 9 inputs (L1 broadcast) and write one contiguous C*2-byte row.
     const int cg = C / 8;
-    const int64_t total = (int64_t)B * T1 * F1 * cg;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int c0 = (int)(i % cg) * 8;
-        int64_t p = i / cg;
-        const int f1 = (int)(p % F1); p /= F1;
-        const int t1 = (int)(p % T1);
-        const int b = (int)(p / T1);
+    const int c0 = (threadIdx.x % cg) * 8;
+    float wr[8][9], br[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        br[j] = bias[c0 + j];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wr[j][k] = w[(c0 + j) * 9 + k];
+    }
+    const int ppb = 256 / cg;  // pixels per workgroup pass (blockDim is a multiple of cg)
+    const int64_t npix = (int64_t)B * T1 * F1;
+    for (int64_t p = (int64_t)blockIdx.x * ppb + threadIdx.x / cg; p < npix; p += (int64_t)gridDim.x * ppb) {
+        int64_t q = p;
+        const int f1 = (int)(q % F1); q /= F1;
+        const int t1 = (int)(q % T1);
+        const int b = (int)(q / T1);
         float px[9];
 #pragma unroll
         for (int dt = 0; dt < 3; ++dt)
@@ -267,12 +277,12 @@ __global__ __launch_bounds__(256) void conv1_relu_cl_kernel(const float* __restr
         union { uint4 u; __bf16 h[8]; } o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float acc = bias[c0 + j];
+            float acc = br[j];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) acc += w[(c0 + j) * 9 + k] * px[k];
+            for (int k = 0; k < 9; ++k) acc += wr[j][k] * px[k];
             o.h[j] = (__bf16)fmaxf(acc, 0.f);
         }
-        *reinterpret_cast<uint4*>(out + (size_t)(i / cg) * C + c0) = o.u;
+        *reinterpret_cast<uint4*>(out + (size_t)p * C + c0) = o.u;
     }
 }
 }  // namespace
@@ -280,9 +290,10 @@ __global__ __launch_bounds__(256) void conv1_relu_cl_kernel(const float* __restr
 extern "C" int ia_subsample_conv1(const float* feats, int B, int Fm, int Tm, int C, const float* w1, const float* b1,
                                   void* out, ia_stream_t stream) {
     if (!feats || !w1 || !b1 || !out || B <= 0 || Fm <= 0 || Tm <= 0 || C <= 0 || C % 8 != 0) return IA_INVALID_VALUE;
+    if (256 % (C / 8) != 0) return IA_UNSUPPORTED;  // C in {8,16,...,2048} with C/8 dividing 256
     const int T1 = (Tm - 1) / 2 + 1, F1 = (Fm - 1) / 2 + 1;
-    const int64_t total = (int64_t)B * T1 * F1 * (C / 8);
-    const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    const int64_t passes = ((int64_t)B * T1 * F1 + (256 / (C / 8)) - 1) / (256 / (C / 8));
+    const int grid = (int)(passes < 8192 ? passes : 8192);
     hipLaunchKernelGGL(conv1_relu_cl_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, feats, B, Fm, Tm, T1, F1, C, w1, b1,
                        (__bf16*)out);
     IA_RETURN_IF_LAUNCH_FAILED();
