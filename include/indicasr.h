@@ -145,7 +145,8 @@ int ia_joint_dh_reduce(const void* dh, const void* f, const void* g, const int64
  *   (g2,b2) applied to the first one's result; outF receives the FIRST norm's fp32 result, outH the final bf16.
  * ia_glu_dwconv: GLU(dim=channels) -> zero frames >= lens[b] -> depthwise conv1d (ksz odd <= 31, 'same' zero padding)
  *   (conformer_modules.py:345-352, causal_convs.py:72-150).  x2 [B,T,2d] bf16, w [d,ksz] f32, z [B,T,d] f32;
- *   bn_sum/bn_sumsq [d] f32 += per-channel sums over all B*T frames (caller zeroes) for train-mode BatchNorm.
+ *   bn_sum/bn_sumsq [d] f32 = per-channel sums over all B*T frames for train-mode BatchNorm (written, not accumulated:
+ *   workgroup partial rows in `scratch` -- f32 x ia_dwconv_scratch_elems -- then a column-sum pass; deterministic).
  * ia_bn_silu:    BatchNorm1d (train: batch statistics from the sums, running stats updated with `momentum`,
  *   unbiased variance, num_batches_tracked += 1; eval: running stats) followed by SiLU; out [n_rows,d] bf16
  *   (conformer_modules.py:353-362).
@@ -169,16 +170,17 @@ int ia_subsample_conv2(const void* in_cl, int B, int T1, int F1, int C, const vo
 int ia_layernorm(const float* x, int ldx, int N, int d, const float* g1, const float* b1, float eps, float* outF,
                  int ldf, const float* g2, const float* b2, void* outH, int ldh, ia_stream_t stream);
 int ia_glu_dwconv(const void* x2, const int64_t* lens, int B, int T, int d, int ksz, const float* w, const float* bias,
-                  float* z, float* bn_sum, float* bn_sumsq, ia_stream_t stream);
+                  float* z, float* bn_sum, float* bn_sumsq, float* scratch, ia_stream_t stream);
+int64_t ia_dwconv_scratch_elems(int B, int T, int d, int ksz); /* covers ia_glu_dwconv and ia_dwconv_time_wgrad */
 /* ia_colsum_bf16: out[n] += sum_m x[m,n] (f32 atomics, caller zeroes): bias gradient of a projection. */
 int ia_colsum_bf16(const void* x, int M, int N, int ld, float* out, ia_stream_t stream);
 /* Depthwise conv over time on fp32 [B,T,d] with autograd pieces (CausalConv1D as configured by the Conformer conv
  * module, causal_convs.py:72-150): y = bias + sum_j w[c][j] x[t+j-half]; flip=1 (bias NULL) gives the data gradient;
- * ia_dwconv_time_wgrad accumulates dw [d,ksz] and db [d] (f32 atomics; caller zeroes). */
+ * ia_dwconv_time_wgrad writes dw [d,ksz] and db [d] (db may be NULL) through partial rows in `scratch`. */
 int ia_dwconv_time(const float* x, int B, int T, int d, int ksz, const float* w, const float* bias, int flip, float* y,
                    ia_stream_t stream);
 int ia_dwconv_time_wgrad(const float* x, const float* dy, int B, int T, int d, int ksz, float* dw, float* db,
-                         ia_stream_t stream);
+                         float* scratch, ia_stream_t stream);
 int ia_bn_silu(const float* z, int64_t n_rows, int d, const float* bn_sum, const float* bn_sumsq, const float* gamma,
                const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                float momentum, float eps, int training, void* out, ia_stream_t stream);
@@ -257,6 +259,34 @@ int ia_ctc_forward(const float* log_probs, const int64_t* targets, const int64_t
 int ia_ctc_backward(const float* log_probs, const int64_t* targets, const int64_t* input_lens, const int64_t* target_lens,
                     int B, int T, int V, int S, int blank, const float* nll_grad, float* grad, void* workspace,
                     size_t workspace_bytes, ia_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Backward-side kernels of the trainable Conformer blocks (autograd of ConformerLayer.forward,
+ * A/parts/submodules/conformer_modules.py:141-214); the dense contractions in between are bf16 GEMMs.
+ *   ia_layernorm_bwd      dx_out = (dx_in or 0) + dLN/dx; dgamma/dbeta written (block partials in `scratch`, f32 x
+ *                         ia_layernorm_bwd_scratch_elems, then a column-sum pass).  dy as f32 OR bf16.
+ *   ia_silu_dropout       out = dropout(SiLU(h_pre)) (bf16 [M,N]); mask = the GEMM epilogue's counter mask (seed,row,col/8)
+ *   ia_silu_dropout_bwd   out = dh * keep*scale * SiLU'(h_pre)
+ *   ia_scale_dropout_bf16 out = bf16(alpha * keep*scale * dy)   -- gradient entering a residual branch
+ *   ia_bn_silu_bwd        SiLU' and train-mode BatchNorm backward from the forward's per-channel sums: S1 = dbeta,
+ *                         S2 = dgamma (caller zeroes both), dz [n_rows,d] f32
+ *   ia_glu_mask / ia_glu_bwd   G = mask(GLU(c2)) f32;  dc2 bf16 [rows,2d] from dG
+ *   ia_attn_keepmask      attention-dropout keep mask of ia_relpos_attention as a bf16 [B,H,T,T] tensor (0 or 1/(1-p))
+ */
+int ia_layernorm_bwd(const float* x, int ldx, const float* dy_f32, const void* dy_bf16, int ldy, int N, int d,
+                     const float* gamma, float eps, const float* dx_in, float* dx_out, int lddx, float* dgamma,
+                     float* dbeta, float* scratch, ia_stream_t stream);
+int64_t ia_layernorm_bwd_scratch_elems(int N, int d);
+int ia_silu_dropout(const void* h_pre, int64_t M, int N, float dropout_p, unsigned seed, void* out, ia_stream_t stream);
+int ia_silu_dropout_bwd(const void* h_pre, const void* dh, int64_t M, int N, float dropout_p, unsigned seed, void* out,
+                        ia_stream_t stream);
+int ia_scale_dropout_bf16(const float* dy, int64_t M, int N, float alpha, float dropout_p, unsigned seed, void* out,
+                          ia_stream_t stream);
+int ia_bn_silu_bwd(const float* z, const void* dc3, int64_t n_rows, int d, const float* bn_sum, const float* bn_sumsq,
+                   const float* gamma, const float* beta, float eps, float* S1, float* S2, float* dz, ia_stream_t stream);
+int ia_glu_mask(const void* c2, const int64_t* lens, int B, int T, int d, float* G, ia_stream_t stream);
+int ia_glu_bwd(const void* c2, const float* dG, const int64_t* lens, int B, int T, int d, void* dc2, ia_stream_t stream);
+int ia_attn_keepmask(int B, int H, int T, float dropout_p, unsigned seed, void* mask_bf16, ia_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Continual-learning regularisers and optimizer over ONE flat fp32 buffer holding every trainable parameter

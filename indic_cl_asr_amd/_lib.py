@@ -37,10 +37,11 @@ SIGNATURES = {
     "ia_subsample_conv1": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ia_subsample_conv2": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "ia_layernorm": (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _vp, _i, _vp, _vp, _vp, _i, _vp]),
-    "ia_glu_dwconv": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ia_glu_dwconv": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ia_dwconv_scratch_elems": (_i64, [_i, _i, _i, _i]),
     "ia_colsum_bf16": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "ia_dwconv_time": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
-    "ia_dwconv_time_wgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "ia_dwconv_time_wgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ia_bn_silu": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp]),
     "ia_attn_vt_elems": (_sz, [_i, _i, _i]),
     "ia_relpos_attention": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _c.c_uint, _vp, _vp, _vp]),
@@ -55,6 +56,15 @@ SIGNATURES = {
     "ia_ctc_workspace_bytes": (_sz, [_i, _i, _i]),
     "ia_ctc_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "ia_ctc_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "ia_layernorm_bwd": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _f, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "ia_layernorm_bwd_scratch_elems": (_i64, [_i, _i]),
+    "ia_silu_dropout": (_i, [_vp, _i64, _i, _f, _c.c_uint, _vp, _vp]),
+    "ia_silu_dropout_bwd": (_i, [_vp, _vp, _i64, _i, _f, _c.c_uint, _vp, _vp]),
+    "ia_scale_dropout_bf16": (_i, [_vp, _i64, _i, _f, _f, _c.c_uint, _vp, _vp]),
+    "ia_bn_silu_bwd": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
+    "ia_glu_mask": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "ia_glu_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "ia_attn_keepmask": (_i, [_i, _i, _i, _f, _c.c_uint, _vp, _vp]),
     "ia_cl_chunk_elems": (_i, []),
     "ia_cl_penalty": (_i, [_vp, _vp, _vp, _f, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "ia_cl_fisher_accumulate": (_i, [_vp, _vp, _vp, _i64, _vp]),

@@ -1,0 +1,245 @@
+// Depthwise convolution over time of the Conformer convolution module for gfx950 (conformer_modules.py:315-362):
+//   ia_glu_dwconv ......... GLU -> zero padded frames -> depthwise conv1d ('same') + per-channel sum / sum-of-squares
+//                           of the output for the train-mode BatchNorm that follows
+//   ia_dwconv_time ........ plain fp32 depthwise conv (flip = 1: its data gradient)
+//   ia_dwconv_time_wgrad .. weight / bias gradient
+// All three are HBM-bound streams ([B*T, d] in, [B*T, d] out, 31 FMAs per element): lane = channel (coalesced rows),
+// each wave owns DW_TT consecutive frames, loads its (DW_TT + K - 1)-frame window straight into registers with every
+// load issued up front (the window overlap between neighbours is served by L2), and keeps the taps in registers.
+// No LDS staging: the first version staged 32-frame tiles through LDS with one workgroup per tile and ran at one
+// wave per SIMD (46 us for 24 MB); per-channel reductions are block partials + a finishing pass (partials.h) instead
+// of float atomics (200 us for the weight gradient).
+#include <hip/hip_bf16.h>
+
+#include <cstdint>
+
+#include "ia_common.h"
+#include "indicasr.h"
+#include "partials.h"
+
+namespace {
+
+constexpr int DW_TT = 8;          // output frames per wave pass
+constexpr int DW_TB = 4 * DW_TT;  // frames per workgroup (4 waves)
+
+// taps of an odd ksz <= KMAX kernel centred in a KMAX window (zeros outside)
+template <int KMAX>
+__device__ __forceinline__ void load_taps(float (&wt)[KMAX], const float* __restrict__ w, int c, int ksz, int flip) {
+    const int off = (KMAX - 1) / 2 - (ksz - 1) / 2;
+#pragma unroll
+    for (int jj = 0; jj < KMAX; ++jj) {
+        const int j = jj - off;
+        wt[jj] = (j >= 0 && j < ksz) ? w[c * ksz + (flip ? ksz - 1 - j : j)] : 0.f;
+    }
+}
+
+template <int KMAX, bool GLU>
+__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const void* __restrict__ xin, const int64_t* __restrict__ lens, int B,
+                                                         int T, int d, int ksz, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, int flip, float* __restrict__ y,
+                                                         float* __restrict__ part) {
+    constexpr int HM = (KMAX - 1) / 2, WIN = DW_TT + KMAX - 1;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int ntb = (T + DW_TB - 1) / DW_TB;
+    const int b = blockIdx.x / ntb, t0 = (blockIdx.x - b * ntb) * DW_TB + wv * DW_TT;
+    const int c = blockIdx.y * 64 + lane;
+    const bool cok = c < d;
+    const int cc = cok ? c : d - 1;
+    int tmax = T;
+    if (GLU) { const int len = (int)lens[b]; tmax = len < T ? len : T; }  // frames >= len are zeroed AFTER the GLU (:351)
+    float wt[KMAX];
+    load_taps<KMAX>(wt, w, cc, ksz, flip);
+    float win[WIN];
+#pragma unroll
+    for (int r = 0; r < WIN; ++r) {
+        const int t = t0 - HM + r;
+        const bool ok = t >= 0 && t < tmax;
+        const int tt = t < 0 ? 0 : (t >= T ? T - 1 : t);
+        float v;
+        if (GLU) {
+            const __bf16* p = reinterpret_cast<const __bf16*>(xin) + ((size_t)b * T + tt) * (2 * d);
+            const float a = (float)p[cc], gate = (float)p[d + cc];
+            v = a / (1.f + __expf(-gate));
+        } else {
+            v = reinterpret_cast<const float*>(xin)[((size_t)b * T + tt) * d + cc];
+        }
+        win[r] = ok ? v : 0.f;
+    }
+    const float bb = bias ? bias[cc] : 0.f;
+    float s = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < DW_TT; ++i) {
+        float acc = bb;
+#pragma unroll
+        for (int jj = 0; jj < KMAX; ++jj) acc += wt[jj] * win[i + jj];
+        const int t = t0 + i;
+        if (t < T && cok) {
+            y[((size_t)b * T + t) * d + c] = acc;
+            s += acc; s2 += acc * acc;
+        }
+    }
+    if (GLU) {
+        __shared__ float red[4][2][64];
+        red[wv][0][lane] = s; red[wv][1][lane] = s2;
+        __syncthreads();
+        if (wv == 0 && cok) {
+            part[(size_t)blockIdx.x * 2 * d + c] = (red[0][0][lane] + red[1][0][lane]) + (red[2][0][lane] + red[3][0][lane]);
+            part[(size_t)blockIdx.x * 2 * d + d + c] = (red[0][1][lane] + red[1][1][lane]) + (red[2][1][lane] + red[3][1][lane]);
+        }
+    }
+}
+
+// dw[c][j] = sum_{b,t} dy[b,t,c] x[b,t+j-half,c]; db[c] = sum dy.  Workgroup = (b, time split, 64 channels), its 4 waves
+// stride over the split's 8-frame chunks; block partial row = [(KMAX+1)][d].
+template <int KMAX>
+__global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, int B,
+                                                           int T, int d, int nsplit, float* __restrict__ part) {
+    constexpr int HM = (KMAX - 1) / 2, WIN = DW_TT + KMAX - 1;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b = blockIdx.x / nsplit, sp = blockIdx.x - b * nsplit;
+    const int per = (((T + nsplit - 1) / nsplit + DW_TT - 1) / DW_TT) * DW_TT;
+    const int ts = sp * per, te = (ts + per < T) ? ts + per : T;
+    const int c = blockIdx.y * 64 + lane;
+    const bool cok = c < d;
+    const int cc = cok ? c : d - 1;
+    float acc[KMAX];
+#pragma unroll
+    for (int jj = 0; jj < KMAX; ++jj) acc[jj] = 0.f;
+    float sb = 0.f;
+    for (int t0 = ts + wv * DW_TT; t0 < te; t0 += 4 * DW_TT) {
+        float g[DW_TT], win[WIN];
+#pragma unroll
+        for (int i = 0; i < DW_TT; ++i) {
+            const int t = t0 + i;
+            const float v = dy[((size_t)b * T + (t < T ? t : T - 1)) * d + cc];
+            g[i] = (t < te) ? v : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < WIN; ++r) {
+            const int t = t0 - HM + r;
+            const int tt = t < 0 ? 0 : (t >= T ? T - 1 : t);
+            const float v = x[((size_t)b * T + tt) * d + cc];
+            win[r] = (t >= 0 && t < T) ? v : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < DW_TT; ++i) {
+            sb += g[i];
+#pragma unroll
+            for (int jj = 0; jj < KMAX; ++jj) acc[jj] += g[i] * win[i + jj];
+        }
+    }
+    __shared__ float red[3][KMAX + 1][64];
+    if (wv > 0) {
+#pragma unroll
+        for (int jj = 0; jj < KMAX; ++jj) red[wv - 1][jj][lane] = acc[jj];
+        red[wv - 1][KMAX][lane] = sb;
+    }
+    __syncthreads();
+    if (wv == 0 && cok) {
+        float* row = part + (size_t)blockIdx.x * (KMAX + 1) * d;
+#pragma unroll
+        for (int jj = 0; jj < KMAX; ++jj)
+            row[(size_t)jj * d + c] = (acc[jj] + red[0][jj][lane]) + (red[1][jj][lane] + red[2][jj][lane]);
+        row[(size_t)KMAX * d + c] = (sb + red[0][KMAX][lane]) + (red[1][KMAX][lane] + red[2][KMAX][lane]);
+    }
+}
+
+__global__ __launch_bounds__(256) void dwconv_wgrad_finish_kernel(const float* __restrict__ part, int G, int d, int kmax, int ksz,
+                                                                  float* __restrict__ dw, float* __restrict__ db) {
+    const int idx = blockIdx.x * 256 + threadIdx.x, total = (kmax + 1) * d;
+    if (idx >= total) return;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int g = 0;
+    for (; g + 3 < G; g += 4) {
+        a0 += part[(size_t)g * total + idx]; a1 += part[(size_t)(g + 1) * total + idx];
+        a2 += part[(size_t)(g + 2) * total + idx]; a3 += part[(size_t)(g + 3) * total + idx];
+    }
+    for (; g < G; ++g) a0 += part[(size_t)g * total + idx];
+    const float s = (a0 + a1) + (a2 + a3);
+    const int jj = idx / d, c = idx - jj * d;
+    if (jj == kmax) {
+        if (db) db[c] = s;
+    } else {
+        const int j = jj - ((kmax - 1) / 2 - (ksz - 1) / 2);
+        if (j >= 0 && j < ksz) dw[c * ksz + j] = s;
+    }
+}
+
+inline int kmax_for(int ksz) { return ksz <= 9 ? 9 : (ksz <= 15 ? 15 : 31); }
+
+inline int wgrad_splits(int B, int T, int d) {
+    const int cg = (d + 63) / 64;
+    int ns = (256 + B * cg - 1) / (B * cg);
+    const int cap = (T + DW_TB - 1) / DW_TB;
+    if (ns > cap) ns = cap;
+    return ns < 1 ? 1 : ns;
+}
+
+inline bool dw_shape_ok(int d, int ksz) { return d > 0 && d <= 4096 && ksz >= 1 && ksz <= 31 && (ksz & 1) == 1; }
+
+}  // namespace
+
+extern "C" int64_t ia_dwconv_scratch_elems(int B, int T, int d, int ksz) {
+    if (B <= 0 || T <= 0 || !dw_shape_ok(d, ksz)) return 0;
+    const int64_t fwd = (int64_t)B * ((T + DW_TB - 1) / DW_TB) * 2 * d;
+    const int64_t wg = (int64_t)B * wgrad_splits(B, T, d) * (kmax_for(ksz) + 1) * d;
+    return fwd > wg ? fwd : wg;
+}
+
+extern "C" int ia_glu_dwconv(const void* x2, const int64_t* lens, int B, int T, int d, int ksz, const float* w,
+                             const float* bias, float* z, float* bn_sum, float* bn_sumsq, float* scratch,
+                             ia_stream_t stream) {
+    if (!x2 || !lens || !w || !bias || !z || !bn_sum || !bn_sumsq || !scratch || B <= 0 || T <= 0) return IA_INVALID_VALUE;
+    if (!dw_shape_ok(d, ksz)) return IA_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(B * ((T + DW_TB - 1) / DW_TB), (d + 63) / 64), blk(256);
+#define IA_DWF(K) hipLaunchKernelGGL((dwconv_fwd_kernel<K, true>), grid, blk, 0, st, x2, lens, B, T, d, ksz, w, bias, 0, z, scratch)
+    switch (kmax_for(ksz)) {
+        case 9: IA_DWF(9); break;
+        case 15: IA_DWF(15); break;
+        default: IA_DWF(31); break;
+    }
+#undef IA_DWF
+    IA_RETURN_IF_LAUNCH_FAILED();
+    ia_partials_finish(scratch, (int)grid.x, 2 * d, d, bn_sum, bn_sumsq, st);
+    IA_RETURN_IF_LAUNCH_FAILED();
+    return IA_OK;
+}
+
+extern "C" int ia_dwconv_time(const float* x, int B, int T, int d, int ksz, const float* w, const float* bias, int flip,
+                              float* y, ia_stream_t stream) {
+    if (!x || !w || !y || B <= 0 || T <= 0) return IA_INVALID_VALUE;
+    if (!dw_shape_ok(d, ksz)) return IA_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(B * ((T + DW_TB - 1) / DW_TB), (d + 63) / 64), blk(256);
+#define IA_DWF(K) hipLaunchKernelGGL((dwconv_fwd_kernel<K, false>), grid, blk, 0, st, (const void*)x, (const int64_t*)nullptr, B, T, d, ksz, w, bias, flip, y, (float*)nullptr)
+    switch (kmax_for(ksz)) {
+        case 9: IA_DWF(9); break;
+        case 15: IA_DWF(15); break;
+        default: IA_DWF(31); break;
+    }
+#undef IA_DWF
+    IA_RETURN_IF_LAUNCH_FAILED();
+    return IA_OK;
+}
+
+extern "C" int ia_dwconv_time_wgrad(const float* x, const float* dy, int B, int T, int d, int ksz, float* dw, float* db,
+                                    float* scratch, ia_stream_t stream) {
+    if (!x || !dy || !dw || !scratch || B <= 0 || T <= 0) return IA_INVALID_VALUE;
+    if (!dw_shape_ok(d, ksz)) return IA_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int ns = wgrad_splits(B, T, d), kmax = kmax_for(ksz);
+    const dim3 grid(B * ns, (d + 63) / 64), blk(256);
+#define IA_DWG(K) hipLaunchKernelGGL((dwconv_wgrad_kernel<K>), grid, blk, 0, st, x, dy, B, T, d, ns, scratch)
+    switch (kmax) {
+        case 9: IA_DWG(9); break;
+        case 15: IA_DWG(15); break;
+        default: IA_DWG(31); break;
+    }
+#undef IA_DWG
+    IA_RETURN_IF_LAUNCH_FAILED();
+    hipLaunchKernelGGL(dwconv_wgrad_finish_kernel, dim3(((kmax + 1) * d + 255) / 256), dim3(256), 0, st, scratch, (int)grid.x, d,
+                       kmax, ksz, dw, db);
+    IA_RETURN_IF_LAUNCH_FAILED();
+    return IA_OK;
+}

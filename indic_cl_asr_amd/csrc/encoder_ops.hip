@@ -3,9 +3,7 @@
 //   ia_layernorm ........ LayerNorm over the feature axis (nn.LayerNorm of conformer_modules.py:86-139), one wave per
 //                         frame, optional SECOND LayerNorm chained in registers (norm_out of layer l followed by
 //                         norm_feed_forward1 of layer l+1), fp32 and/or bf16 outputs.
-//   ia_glu_dwconv ....... GLU over channels -> zero the padded frames -> depthwise conv (k taps, 'same' padding)
-//                         -> fp32 output + per-channel sum / sum-of-squares for BatchNorm
-//                         (ConformerConvolution.forward conformer_modules.py:340-353, CausalConv1D causal_convs.py:72-150).
+//   (GLU + depthwise conv + BatchNorm sums: dwconv.hip)
 //   ia_bn_silu .......... train-mode BatchNorm1d from those sums (+ running-stat update) -> SiLU -> bf16
 //                         (conformer_modules.py:353-362); eval mode uses the running statistics.
 #include <hip/hip_bf16.h>
@@ -90,124 +88,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             }
         }
     }
-}
-
-// ------------------------------------------------------------------------------------------------ GLU + depthwise conv
-constexpr int DW_TT = 32;  // output frames per workgroup
-
-__global__ void glu_dwconv_kernel(const __bf16* __restrict__ x2, const int64_t* __restrict__ lens, int B, int T, int d,
-                                  int ksz, const float* __restrict__ w, const float* __restrict__ bias,
-                                  float* __restrict__ z, float* __restrict__ bn_sum, float* __restrict__ bn_sumsq) {
-    extern __shared__ float sg[];  // [(DW_TT + ksz - 1)][d]
-    const int ntt = (T + DW_TT - 1) / DW_TT;
-    const int b = blockIdx.x / ntt, t0 = (blockIdx.x - b * ntt) * DW_TT;
-    const int ch = threadIdx.x;  // blockDim.x == d
-    const int half = (ksz - 1) / 2, len = (int)lens[b];
-    const int rows = DW_TT + ksz - 1;
-    for (int r = 0; r < rows; ++r) {
-        const int t = t0 - half + r;
-        float g = 0.f;
-        if (t >= 0 && t < T && t < len) {  // frames at/after len are zeroed AFTER the GLU (masked_fill, :351)
-            const __bf16* p = x2 + ((size_t)b * T + t) * (2 * d);
-            const float a = (float)p[ch], gate = (float)p[d + ch];
-            g = a / (1.f + __expf(-gate));
-        }
-        sg[r * d + ch] = g;
-    }
-    __syncthreads();
-    float wr[32];  // ksz <= 32
-#pragma unroll
-    for (int j = 0; j < 32; ++j) wr[j] = (j < ksz) ? w[ch * ksz + j] : 0.f;
-    const float bb = bias[ch];
-    float s = 0.f, s2 = 0.f;
-    // 4 outputs per pass over the taps: each LDS value feeds up to 4 accumulators (4x fewer LDS reads)
-    for (int i0 = 0; i0 < DW_TT; i0 += 4) {
-        if (t0 + i0 >= T) break;
-        float a0 = bb, a1 = bb, a2 = bb, a3 = bb;
-#pragma unroll
-        for (int r = 0; r < 32 + 3; ++r) {
-            if (r < ksz + 3) {
-                const float v = sg[(i0 + r) * d + ch];
-                if (r < ksz) a0 += wr[r < 32 ? r : 0] * v;
-                if (r >= 1 && r - 1 < ksz) a1 += wr[(r - 1) < 32 && r >= 1 ? r - 1 : 0] * v;
-                if (r >= 2 && r - 2 < ksz) a2 += wr[(r - 2) < 32 && r >= 2 ? r - 2 : 0] * v;
-                if (r >= 3 && r - 3 < ksz) a3 += wr[(r - 3) < 32 && r >= 3 ? r - 3 : 0] * v;
-            }
-        }
-        const float av[4] = {a0, a1, a2, a3};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int t = t0 + i0 + k;
-            if (t < T) {
-                z[((size_t)b * T + t) * d + ch] = av[k];
-                s += av[k]; s2 += av[k] * av[k];
-            }
-        }
-    }
-    atomicAdd(bn_sum + ch, s);
-    atomicAdd(bn_sumsq + ch, s2);
-}
-
-// Plain depthwise conv over time on fp32 [B,T,d] (autograd path of the trainable blocks):
-//   y[b,t,c] = bias[c] + sum_j w[c][flip ? k-1-j : j] * x[b, t + j - half, c]      (zero padding)
-// flip = 1 with bias = NULL is the data gradient of the same op.
-__global__ void dwconv_time_kernel(const float* __restrict__ x, int B, int T, int d, int ksz, const float* __restrict__ w,
-                                   const float* __restrict__ bias, int flip, float* __restrict__ y) {
-    extern __shared__ float sg[];
-    const int ntt = (T + DW_TT - 1) / DW_TT;
-    const int b = blockIdx.x / ntt, t0 = (blockIdx.x - b * ntt) * DW_TT;
-    const int ch = threadIdx.x;
-    const int half = (ksz - 1) / 2, rows = DW_TT + ksz - 1;
-    for (int r = 0; r < rows; ++r) {
-        const int t = t0 - half + r;
-        sg[r * d + ch] = (t >= 0 && t < T) ? x[((size_t)b * T + t) * d + ch] : 0.f;
-    }
-    __syncthreads();
-    float wr[32];
-#pragma unroll
-    for (int j = 0; j < 32; ++j) wr[j] = (j < ksz) ? w[ch * ksz + (flip ? ksz - 1 - j : j)] : 0.f;
-    const float bb = bias ? bias[ch] : 0.f;
-    for (int i = 0; i < DW_TT; ++i) {
-        const int t = t0 + i;
-        if (t >= T) break;
-        float acc = bb;
-#pragma unroll
-        for (int j = 0; j < 32; ++j)
-            if (j < ksz) acc += wr[j] * sg[(i + j) * d + ch];
-        y[((size_t)b * T + t) * d + ch] = acc;
-    }
-}
-
-// Weight / bias gradient of the depthwise conv: dw[c][j] += sum_{b,t} dy[b,t,c] x[b,t+j-half,c]; db[c] += sum dy.
-__global__ void dwconv_time_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, int B, int T, int d,
-                                         int ksz, float* __restrict__ dw, float* __restrict__ db) {
-    extern __shared__ float sg[];
-    const int ntt = (T + DW_TT - 1) / DW_TT;
-    const int b = blockIdx.x / ntt, t0 = (blockIdx.x - b * ntt) * DW_TT;
-    const int ch = threadIdx.x;
-    const int half = (ksz - 1) / 2, rows = DW_TT + ksz - 1;
-    for (int r = 0; r < rows; ++r) {
-        const int t = t0 - half + r;
-        sg[r * d + ch] = (t >= 0 && t < T) ? x[((size_t)b * T + t) * d + ch] : 0.f;
-    }
-    __syncthreads();
-    float acc[32];
-#pragma unroll
-    for (int j = 0; j < 32; ++j) acc[j] = 0.f;
-    float sb = 0.f;
-    for (int i = 0; i < DW_TT; ++i) {
-        const int t = t0 + i;
-        if (t >= T) break;
-        const float g = dy[((size_t)b * T + t) * d + ch];
-        sb += g;
-#pragma unroll
-        for (int j = 0; j < 32; ++j)
-            if (j < ksz) acc[j] += g * sg[(i + j) * d + ch];
-    }
-#pragma unroll
-    for (int j = 0; j < 32; ++j)
-        if (j < ksz) atomicAdd(dw + ch * ksz + j, acc[j]);
-    if (db) atomicAdd(db + ch, sb);
 }
 
 // ------------------------------------------------------------------------------------------------ BatchNorm + SiLU
@@ -317,22 +197,6 @@ extern "C" int ia_layernorm(const float* x, int ldx, int N, int d, const float* 
     return IA_OK;
 }
 
-extern "C" int ia_glu_dwconv(const void* x2, const int64_t* lens, int B, int T, int d, int ksz, const float* w,
-                             const float* bias, float* z, float* bn_sum, float* bn_sumsq, ia_stream_t stream) {
-    if (!x2 || !lens || !w || !bias || !z || !bn_sum || !bn_sumsq || B <= 0 || T <= 0) return IA_INVALID_VALUE;
-    if (d <= 0 || d > 1024 || ksz < 1 || ksz > 32 || (ksz & 1) == 0) return IA_UNSUPPORTED;
-    const size_t lds = (size_t)(DW_TT + ksz - 1) * d * sizeof(float);
-    if (lds > 160 * 1024) return IA_UNSUPPORTED;
-    const int ntt = (T + DW_TT - 1) / DW_TT;
-    if (lds > 64 * 1024 &&
-        hipFuncSetAttribute((const void*)glu_dwconv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return IA_LAUNCH_FAILED;
-    hipLaunchKernelGGL(glu_dwconv_kernel, dim3(B * ntt), dim3(d), lds, (hipStream_t)stream, (const __bf16*)x2, lens, B, T, d,
-                       ksz, w, bias, z, bn_sum, bn_sumsq);
-    IA_RETURN_IF_LAUNCH_FAILED();
-    return IA_OK;
-}
-
 extern "C" int ia_bn_silu(const float* z, int64_t n_rows, int d, const float* bn_sum, const float* bn_sumsq,
                           const float* gamma, const float* beta, float* running_mean, float* running_var,
                           int64_t* num_batches_tracked, float momentum, float eps, int training, void* out,
@@ -354,32 +218,3 @@ extern "C" int ia_bn_silu(const float* z, int64_t n_rows, int d, const float* bn
     return IA_OK;
 }
 
-extern "C" int ia_dwconv_time(const float* x, int B, int T, int d, int ksz, const float* w, const float* bias, int flip,
-                              float* y, ia_stream_t stream) {
-    if (!x || !w || !y || B <= 0 || T <= 0) return IA_INVALID_VALUE;
-    if (d <= 0 || d > 1024 || ksz < 1 || ksz > 32 || (ksz & 1) == 0) return IA_UNSUPPORTED;
-    const size_t lds = (size_t)(DW_TT + ksz - 1) * d * sizeof(float);
-    if (lds > 160 * 1024) return IA_UNSUPPORTED;
-    if (lds > 64 * 1024 &&
-        hipFuncSetAttribute((const void*)dwconv_time_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return IA_LAUNCH_FAILED;
-    const int ntt = (T + DW_TT - 1) / DW_TT;
-    hipLaunchKernelGGL(dwconv_time_kernel, dim3(B * ntt), dim3(d), lds, (hipStream_t)stream, x, B, T, d, ksz, w, bias, flip, y);
-    IA_RETURN_IF_LAUNCH_FAILED();
-    return IA_OK;
-}
-
-extern "C" int ia_dwconv_time_wgrad(const float* x, const float* dy, int B, int T, int d, int ksz, float* dw, float* db,
-                                    ia_stream_t stream) {
-    if (!x || !dy || !dw || B <= 0 || T <= 0) return IA_INVALID_VALUE;
-    if (d <= 0 || d > 1024 || ksz < 1 || ksz > 32 || (ksz & 1) == 0) return IA_UNSUPPORTED;
-    const size_t lds = (size_t)(DW_TT + ksz - 1) * d * sizeof(float);
-    if (lds > 160 * 1024) return IA_UNSUPPORTED;
-    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)dwconv_time_wgrad_kernel,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return IA_LAUNCH_FAILED;
-    const int ntt = (T + DW_TT - 1) / DW_TT;
-    hipLaunchKernelGGL(dwconv_time_wgrad_kernel, dim3(B * ntt), dim3(d), lds, (hipStream_t)stream, x, dy, B, T, d, ksz, dw, db);
-    IA_RETURN_IF_LAUNCH_FAILED();
-    return IA_OK;
-}

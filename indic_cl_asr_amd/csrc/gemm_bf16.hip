@@ -13,6 +13,7 @@
 #include <hip/hip_bf16.h>
 
 #include "ia_common.h"
+#include "dropout_mask.h"
 
 namespace {
 
@@ -173,13 +174,10 @@ __global__ __launch_bounds__(G_THREADS) void gemm_bf16_nt_kernel(GemmArgs a) {
         }
         float sc_all = a.alpha;
         if (a.thr > 0) {
-            const unsigned base = ((unsigned)gm * (unsigned)a.N + (unsigned)gn) * 0x9E3779B1u + a.seed;
-            const unsigned r0 = g_hash32(base), r1 = g_hash32(base ^ 0x68E31DA4u);
+            const unsigned m = ia_keep8(a.seed, (unsigned)gm, (unsigned)a.N, (unsigned)gn, a.thr);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (((r0 >> (8 * j)) & 0xFFu) < a.thr) v[j] = 0.f;
-                if (((r1 >> (8 * j)) & 0xFFu) < a.thr) v[4 + j] = 0.f;
-            }
+            for (int j = 0; j < 8; ++j)
+                if (!((m >> j) & 1u)) v[j] = 0.f;
             sc_all *= a.keep_scale;
         }
 #pragma unroll

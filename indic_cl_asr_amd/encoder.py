@@ -235,6 +235,7 @@ class ConformerEncoder(nn.Module):
                                                     cfg.dropout_att) for _ in range(cfg.n_layers)])
         self.encoder_frozen_till = -1  # the reference's custom attribute (conformer_encoder.py:447)
         self.use_fast_path = True
+        self.use_fused_blocks = True   # trainable blocks as single autograd nodes on the HIP kernels
         self.fast_seed = 0             # per-step dropout seed for the fused path (set by the model)
 
     def _amp(self, x):
@@ -274,9 +275,25 @@ class ConformerEncoder(nn.Module):
                     with torch.no_grad():
                         if self.layers[0].fast_supported(x):
                             x, lth = self._fast_prefix(x, length, pos_emb, n_fast)
-            for l in range(lth, n_layers):
-                with (torch.no_grad() if self.encoder_frozen_till > l else nullcontext()):
-                    x = self.layers[l](x, length, pos_emb, pad_mask)
+            # trainable suffix: one autograd node per block on the HIP kernels (ops/block.py), ATen composition otherwise
+            blk_ok = False
+            if (self.use_fast_path and self.use_fused_blocks and self.cfg.compute_dtype == "bf16" and x.is_cuda
+                    and torch.is_grad_enabled() and lth < n_layers and self.training):
+                from .ops import block
+                B_, T_, d_ = x.shape
+                blk_ok = all(block.block_supported(self.layers[l], x, T_) and self.encoder_frozen_till <= l
+                             for l in range(lth, n_layers))
+            if blk_ok:
+                xr = x.float().reshape(B_ * T_, d_).contiguous()
+                pe16 = block.pad_pos_emb(pos_emb, d_)
+                base = (self.fast_seed * 2654435761) & 0x7FFFFFFF
+                for l in range(lth, n_layers):
+                    xr = block.conformer_block(xr, self.layers[l], length, pe16, B_, T_, base + 16 * l)
+                x = xr.view(B_, T_, d_)
+            else:
+                for l in range(lth, n_layers):
+                    with (torch.no_grad() if self.encoder_frozen_till > l else nullcontext()):
+                        x = self.layers[l](x, length, pos_emb, pad_mask)
         return x.transpose(1, 2), length
 
     def _fast_prefix(self, x, length, pos_emb, n_fast):

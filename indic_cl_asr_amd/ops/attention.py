@@ -16,7 +16,7 @@ def _rel_shift_index(T, device):
     return (T - 1 - i + j)  # [T,T] indices into the 2T-1 axis
 
 
-def rel_pos_attention(q, k, v, p, bias_u, bias_v, lens, dropout_p=0.0, training=False):
+def rel_pos_attention(q, k, v, p, bias_u, bias_v, lens, dropout_p=0.0, training=False, keep_mask=None):
     """q,k,v: [B,h,T,dk]; p: [h,2T-1,dk]; bias_u/bias_v: [h,dk]; lens: [B] i64 -> context [B,h,T,dk]."""
     B, h, T, dk = q.shape
     scale = 1.0 / math.sqrt(dk)
@@ -31,6 +31,8 @@ def rel_pos_attention(q, k, v, p, bias_u, bias_v, lens, dropout_p=0.0, training=
     mask = ~(valid[:, :, None] & valid[:, None, :])                                # [B,T,T]
     scores = scores.masked_fill(mask.unsqueeze(1), -10000.0)
     attn = torch.softmax(scores, dim=-1).masked_fill(mask.unsqueeze(1), 0.0)
-    if training and dropout_p > 0.0:
+    if keep_mask is not None:      # explicit dropout mask (0 or 1/(1-p)) [B,h,T,T]: the HIP kernel's, for its backward
+        attn = attn * keep_mask.to(attn.dtype)
+    elif training and dropout_p > 0.0:
         attn = torch.nn.functional.dropout(attn, dropout_p, True)
     return torch.matmul(attn.to(v.dtype), v)

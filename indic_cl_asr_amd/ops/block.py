@@ -1,0 +1,266 @@
+"""One trainable Conformer block as a single autograd node on the HIP kernels.
+
+Forward = the fused no-autograd path of encoder.ConformerLayer.forward_fast (GEMMs with fused epilogues, LayerNorm,
+GLU+depthwise conv+BatchNorm+SiLU, rel-pos attention) keeping the intermediates the backward needs; backward = manual
+chain rule: bf16 library GEMMs for the data gradients, batched split-K GEMMs for the weight gradients, and the
+kernels of csrc/encoder_bwd.hip for everything in between.  The attention core's backward is obtained by recomputing
+it with ATen ops under autograd with the SAME dropout mask the HIP kernel used (ia_attn_keepmask).
+
+Semantics: ConformerLayer.forward, A/parts/submodules/conformer_modules.py:141-214 (bf16 projections, fp32 residual
+stream / norms / BatchNorm statistics), dropout masks are counter-based and regenerated in the backward.
+"""
+import torch
+
+from .. import _lib
+from . import attention as att_ops
+from . import fast
+
+
+def _ptr(t):
+    return _lib.ptr(t)
+
+
+def _ln_bwd(x, ln, dy_f32=None, dy_bf16=None, dx_in=None):
+    N, d = x.shape
+    dev = x.device
+    dx = torch.empty(N, d, dtype=torch.float32, device=dev)
+    dgb = torch.empty(2, d, dtype=torch.float32, device=dev)
+    dy = dy_f32 if dy_f32 is not None else dy_bf16
+    L = _lib.lib()
+    st = L.ia_layernorm_bwd(_ptr(x), x.stride(0), _ptr(dy_f32), _ptr(dy_bf16), dy.stride(0), N, d, _ptr(ln.weight),
+                            float(ln.eps), _ptr(dx_in), _ptr(dx), d, _ptr(dgb[0]), _ptr(dgb[1]),
+                            _ptr(fast.scratch(dev, L.ia_layernorm_bwd_scratch_elems(N, d))), _lib.stream_ptr())
+    _lib.check(st, "ia_layernorm_bwd")
+    return dx, dgb[0], dgb[1]
+
+
+def _branch_grad(dxr, alpha, p, seed):
+    N, d = dxr.shape
+    out = torch.empty(N, d, dtype=torch.bfloat16, device=dxr.device)
+    st = _lib.lib().ia_scale_dropout_bf16(_ptr(dxr), N, d, float(alpha), float(p), int(seed) & 0xFFFFFFFF, _ptr(out),
+                                          _lib.stream_ptr())
+    _lib.check(st, "ia_scale_dropout_bf16")
+    return out
+
+
+def _lin_bwd(dyb, xb, wb, need_dx=True):
+    """dyb [M,n] bf16, xb [M,k] bf16, wb [n,k] bf16 -> (dx bf16 [M,k] or None, dW f32 [n,k], db f32 [n])."""
+    M, n = dyb.shape
+    k = xb.shape[1]
+    dx = torch.mm(dyb, wb) if need_dx else None
+    S = next((s for s in (8, 4, 2) if M % s == 0 and M // s >= 256), 1)
+    if S > 1:
+        dW = torch.bmm(dyb.view(S, M // S, n).transpose(1, 2), xb.view(S, M // S, k), out_dtype=torch.float32).sum(0)
+    else:
+        dW = torch.mm(dyb.t(), xb, out_dtype=torch.float32)
+    return dx, dW, fast.colsum(dyb)
+
+
+def _silu_dropout(h_pre, p, seed):
+    M, N = h_pre.shape
+    out = torch.empty_like(h_pre)
+    _lib.check(_lib.lib().ia_silu_dropout(_ptr(h_pre), M, N, float(p), int(seed) & 0xFFFFFFFF, _ptr(out), _lib.stream_ptr()),
+               "ia_silu_dropout")
+    return out
+
+
+def _silu_dropout_bwd(h_pre, dh, p, seed):
+    M, N = h_pre.shape
+    out = torch.empty_like(h_pre)
+    _lib.check(_lib.lib().ia_silu_dropout_bwd(_ptr(h_pre), _ptr(dh), M, N, float(p), int(seed) & 0xFFFFFFFF, _ptr(out),
+                                              _lib.stream_ptr()), "ia_silu_dropout_bwd")
+    return out
+
+
+# True: the block's backward adds parameter gradients into existing fp32 .grad buffers itself (and reports None to
+# autograd).  Set False when differentiating with torch.autograd.grad(..., block parameters).
+DIRECT_ACCUMULATE = True
+
+
+def block_supported(layer, x2d, T):
+    d = x2d.shape[-1]
+    bn = layer.conv.batch_norm
+    return (x2d.is_cuda and d % 64 == 0 and d <= 1024 and type(bn) is torch.nn.BatchNorm1d and 256 % (d // 4) == 0
+            and layer.conv.depthwise_conv.weight.shape[-1] <= 31 and fast.attention_supported(T, layer.self_attn.d_k))
+
+
+class _ConformerBlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, layer, lens, pe, B, T, seed, *params):
+        L = _lib.lib()
+        N, d = x.shape
+        dev = x.device
+        tr = layer.training
+        p = float(layer.dropout.p) if tr else 0.0
+        ff1, ff2, att, cv = layer.feed_forward1, layer.feed_forward2, layer.self_attn, layer.conv
+        pff1 = float(ff1.dropout.p) if tr else 0.0
+        pff2 = float(ff2.dropout.p) if tr else 0.0
+        patt = float(att.dropout_rate) if tr else 0.0
+        W = dict(w1=fast.bf16_shadow(ff1.linear1.weight), w2=fast.bf16_shadow(ff1.linear2.weight),
+                 wqkv=fast.bf16_shadow(att.linear_q.weight, att.linear_k.weight, att.linear_v.weight),
+                 wpos=fast.bf16_shadow(att.linear_pos.weight), wo=fast.bf16_shadow(att.linear_out.weight),
+                 wp1=fast.bf16_shadow(cv.pointwise_conv1.weight), wp2=fast.bf16_shadow(cv.pointwise_conv2.weight),
+                 w1b=fast.bf16_shadow(ff2.linear1.weight), w2b=fast.bf16_shadow(ff2.linear2.weight))
+        new = lambda: torch.empty(N, d, dtype=torch.float32, device=dev)
+        x0 = x.contiguous()
+        # 1/2 FFN
+        y1 = fast.layernorm(x0, layer.norm_feed_forward1.weight, layer.norm_feed_forward1.bias, layer.norm_feed_forward1.eps)
+        _, h1p = fast.gemm(y1, W["w1"], ff1.linear1.bias)
+        h1 = _silu_dropout(h1p, pff1, seed + 1)
+        x1, _ = fast.gemm(h1, W["w2"], ff1.linear2.bias, dropout_p=p, seed=seed + 2, alpha=layer.fc_factor, residual=x0,
+                          out_f32=new(), want_bf16=False)
+        # self-attention
+        y2 = fast.layernorm(x1, layer.norm_self_att.weight, layer.norm_self_att.bias, layer.norm_self_att.eps)
+        _, qkv = fast.gemm(y2, W["wqkv"], fast.f32_cat(att.linear_q.bias, att.linear_k.bias, att.linear_v.bias))
+        _, pl = fast.gemm(pe, W["wpos"])
+        ctxv = fast.relpos_attention(qkv, pl, att.pos_bias_u, att.pos_bias_v, lens, B, T, att.h, att.d_k, patt, seed + 7)
+        x2, _ = fast.gemm(ctxv, W["wo"], att.linear_out.bias, dropout_p=p, seed=seed + 3, residual=x1, out_f32=new(),
+                          want_bf16=False)
+        # convolution module
+        y3 = fast.layernorm(x2, layer.norm_conv.weight, layer.norm_conv.bias, layer.norm_conv.eps)
+        _, c2 = fast.gemm(y3, W["wp1"], cv.pointwise_conv1.bias)
+        bn = cv.batch_norm
+        z = torch.empty(N, d, dtype=torch.float32, device=dev)
+        sums = torch.empty(2, d, dtype=torch.float32, device=dev)
+        ksz = cv.depthwise_conv.weight.shape[-1]
+        dw_scr = fast.scratch(dev, L.ia_dwconv_scratch_elems(B, T, d, ksz))
+        _lib.check(L.ia_glu_dwconv(_ptr(c2), _ptr(lens), B, T, d, ksz, _ptr(cv.depthwise_conv.weight), _ptr(cv.depthwise_conv.bias),
+                                   _ptr(z), _ptr(sums[0]), _ptr(sums[1]), _ptr(dw_scr), _lib.stream_ptr()), "ia_glu_dwconv")
+        c3 = torch.empty(N, d, dtype=torch.bfloat16, device=dev)
+        use_batch = bool(tr or not bn.track_running_stats)
+        _lib.check(L.ia_bn_silu(_ptr(z), N, d, _ptr(sums[0]), _ptr(sums[1]), _ptr(bn.weight), _ptr(bn.bias), _ptr(bn.running_mean),
+                                _ptr(bn.running_var), _ptr(bn.num_batches_tracked), float(bn.momentum or 0.1), float(bn.eps),
+                                int(use_batch), _ptr(c3), _lib.stream_ptr()), "ia_bn_silu")
+        x3, _ = fast.gemm(c3, W["wp2"], cv.pointwise_conv2.bias, dropout_p=p, seed=seed + 4, residual=x2, out_f32=new(),
+                          want_bf16=False)
+        # 1/2 FFN
+        y4 = fast.layernorm(x3, layer.norm_feed_forward2.weight, layer.norm_feed_forward2.bias, layer.norm_feed_forward2.eps)
+        _, h4p = fast.gemm(y4, W["w1b"], ff2.linear1.bias)
+        h4 = _silu_dropout(h4p, pff2, seed + 5)
+        x4, _ = fast.gemm(h4, W["w2b"], ff2.linear2.bias, dropout_p=p, seed=seed + 6, alpha=layer.fc_factor, residual=x3,
+                          out_f32=new(), want_bf16=False)
+        out = new()
+        fast.layernorm(x4, layer.norm_out.weight, layer.norm_out.bias, layer.norm_out.eps, out_f32=out, want_bf16=False)
+        if not use_batch:
+            raise RuntimeError("trainable fused block expects train-mode BatchNorm (batch statistics)")
+        ctx.S = dict(x0=x0, y1=y1, h1p=h1p, h1=h1, x1=x1, y2=y2, qkv=qkv, pl=pl, ctxv=ctxv, x2=x2, y3=y3, c2=c2, z=z, sums=sums,
+                     c3=c3, x3=x3, y4=y4, h4p=h4p, h4=h4, x4=x4, W=W, pe=pe, lens=lens)
+        ctx.meta = (layer, B, T, seed, p, pff1, pff2, patt, [n for n, _ in layer.named_parameters()],
+                    [q.requires_grad for q in params], params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = _lib.lib()
+        S = ctx.S
+        ctx.S = None
+        layer, B, T, seed, p, pff1, pff2, patt, names, req, params = ctx.meta
+        W = S["W"]
+        ff1, ff2, att, cv = layer.feed_forward1, layer.feed_forward2, layer.self_attn, layer.conv
+        d = S["x0"].shape[1]
+        N = B * T
+        dev = dout.device
+        G = {}
+        dout = dout.float().contiguous()
+        # norm_out
+        dx4, G["norm_out.weight"], G["norm_out.bias"] = _ln_bwd(S["x4"], layer.norm_out, dy_f32=dout)
+        # feed_forward2
+        dB = _branch_grad(dx4, layer.fc_factor, p, seed + 6)
+        dh, G["feed_forward2.linear2.weight"], G["feed_forward2.linear2.bias"] = _lin_bwd(dB, S["h4"], W["w2b"])
+        dhp = _silu_dropout_bwd(S["h4p"], dh, pff2, seed + 5)
+        dy, G["feed_forward2.linear1.weight"], G["feed_forward2.linear1.bias"] = _lin_bwd(dhp, S["y4"], W["w1b"])
+        dx3, G["norm_feed_forward2.weight"], G["norm_feed_forward2.bias"] = _ln_bwd(S["x3"], layer.norm_feed_forward2,
+                                                                                  dy_bf16=dy, dx_in=dx4)
+        del dx4, dh, dhp
+        # convolution module
+        dB = _branch_grad(dx3, 1.0, p, seed + 4)
+        dc3, dWp2, G["conv.pointwise_conv2.bias"] = _lin_bwd(dB, S["c3"], W["wp2"])
+        G["conv.pointwise_conv2.weight"] = dWp2.unsqueeze(-1)
+        bn = cv.batch_norm
+        S12 = torch.zeros(2, d, dtype=torch.float32, device=dev)
+        dz = torch.empty(N, d, dtype=torch.float32, device=dev)
+        _lib.check(L.ia_bn_silu_bwd(_ptr(S["z"]), _ptr(dc3), N, d, _ptr(S["sums"][0]), _ptr(S["sums"][1]), _ptr(bn.weight),
+                                    _ptr(bn.bias), float(bn.eps), _ptr(S12[0]), _ptr(S12[1]), _ptr(dz), _lib.stream_ptr()),
+                   "ia_bn_silu_bwd")
+        G["conv.batch_norm.bias"], G["conv.batch_norm.weight"] = S12[0], S12[1]
+        ksz = cv.depthwise_conv.weight.shape[-1]
+        w2 = cv.depthwise_conv.weight.detach().float().reshape(d, ksz).contiguous()
+        dG = torch.empty(N, d, dtype=torch.float32, device=dev)
+        _lib.check(L.ia_dwconv_time(_ptr(dz), B, T, d, ksz, _ptr(w2), None, 1, _ptr(dG), _lib.stream_ptr()), "ia_dwconv_time")
+        Gm = torch.empty(N, d, dtype=torch.float32, device=dev)
+        _lib.check(L.ia_glu_mask(_ptr(S["c2"]), _ptr(S["lens"]), B, T, d, _ptr(Gm), _lib.stream_ptr()), "ia_glu_mask")
+        dwd = torch.empty(d, ksz, dtype=torch.float32, device=dev)
+        dbd = torch.empty(d, dtype=torch.float32, device=dev)
+        _lib.check(L.ia_dwconv_time_wgrad(_ptr(Gm), _ptr(dz), B, T, d, ksz, _ptr(dwd), _ptr(dbd),
+                                          _ptr(fast.scratch(dev, L.ia_dwconv_scratch_elems(B, T, d, ksz))), _lib.stream_ptr()),
+                   "ia_dwconv_time_wgrad")
+        G["conv.depthwise_conv.weight"], G["conv.depthwise_conv.bias"] = dwd.view(d, 1, ksz), dbd
+        dc2 = torch.empty(N, 2 * d, dtype=torch.bfloat16, device=dev)
+        _lib.check(L.ia_glu_bwd(_ptr(S["c2"]), _ptr(dG), _ptr(S["lens"]), B, T, d, _ptr(dc2), _lib.stream_ptr()), "ia_glu_bwd")
+        dy, dWp1, G["conv.pointwise_conv1.bias"] = _lin_bwd(dc2, S["y3"], W["wp1"])
+        G["conv.pointwise_conv1.weight"] = dWp1.unsqueeze(-1)
+        dx2, G["norm_conv.weight"], G["norm_conv.bias"] = _ln_bwd(S["x2"], layer.norm_conv, dy_bf16=dy, dx_in=dx3)
+        del dx3, dz, dG, Gm, dc2, dc3
+        # self-attention
+        dB = _branch_grad(dx2, 1.0, p, seed + 3)
+        dctx, G["self_attn.linear_out.weight"], G["self_attn.linear_out.bias"] = _lin_bwd(dB, S["ctxv"], W["wo"])
+        h, dk = att.h, att.d_k
+        keep = None
+        if patt > 0.0:
+            keep = torch.empty(B, h, T, T, dtype=torch.bfloat16, device=dev)
+            _lib.check(L.ia_attn_keepmask(B, h, T, patt, (seed + 7) & 0xFFFFFFFF, _ptr(keep), _lib.stream_ptr()), "ia_attn_keepmask")
+        qkv_l = S["qkv"].detach().requires_grad_(True)
+        pl_l = S["pl"].detach().requires_grad_(True)
+        u_l = att.pos_bias_u.detach().clone().requires_grad_(True)
+        v_l = att.pos_bias_v.detach().clone().requires_grad_(True)
+        with torch.enable_grad():
+            q5 = qkv_l.view(B, T, 3, h, dk)
+            q, k, v = (q5[:, :, i].transpose(1, 2) for i in range(3))
+            cre = att_ops.rel_pos_attention(q, k, v, pl_l[:2 * T - 1].view(-1, h, dk).transpose(0, 1), u_l, v_l, S["lens"], 0.0, False,
+                                            keep_mask=keep)
+            cre = cre.transpose(1, 2).reshape(N, d)
+        dqkv, dpl, du, dv = torch.autograd.grad(cre, [qkv_l, pl_l, u_l, v_l], dctx.to(cre.dtype))
+        G["self_attn.pos_bias_u"], G["self_attn.pos_bias_v"] = du, dv
+        dy, dWqkv, dbqkv = _lin_bwd(dqkv.contiguous(), S["y2"], W["wqkv"])
+        for i, nm in enumerate(("q", "k", "v")):
+            G[f"self_attn.linear_{nm}.weight"] = dWqkv[i * d:(i + 1) * d]
+            G[f"self_attn.linear_{nm}.bias"] = dbqkv[i * d:(i + 1) * d]
+        G["self_attn.linear_pos.weight"] = torch.mm(dpl.t(), S["pe"], out_dtype=torch.float32)
+        dx1, G["norm_self_att.weight"], G["norm_self_att.bias"] = _ln_bwd(S["x1"], layer.norm_self_att, dy_bf16=dy, dx_in=dx2)
+        del dx2, dqkv, dctx
+        # feed_forward1
+        dB = _branch_grad(dx1, layer.fc_factor, p, seed + 2)
+        dh, G["feed_forward1.linear2.weight"], G["feed_forward1.linear2.bias"] = _lin_bwd(dB, S["h1"], W["w2"])
+        dhp = _silu_dropout_bwd(S["h1p"], dh, pff1, seed + 1)
+        dy, G["feed_forward1.linear1.weight"], G["feed_forward1.linear1.bias"] = _lin_bwd(dhp, S["y1"], W["w1"])
+        dx0, G["norm_feed_forward1.weight"], G["norm_feed_forward1.bias"] = _ln_bwd(S["x0"], layer.norm_feed_forward1,
+                                                                                  dy_bf16=dy, dx_in=dx1)
+        # parameter gradients: added to existing .grad buffers in ONE multi-tensor launch (autograd's AccumulateGrad
+        # would issue one small add per parameter: 40 launches per block); parameters without a .grad get theirs returned
+        outs, dst, src = [], [], []
+        for n, r, q in zip(names, req, params):
+            if not r:
+                outs.append(None)
+            elif DIRECT_ACCUMULATE and q.grad is not None and q.grad.dtype == torch.float32:
+                dst.append(q.grad); src.append(G[n].reshape(q.grad.shape)); outs.append(None)
+            else:
+                outs.append(G[n].reshape(q.shape))
+        if dst:
+            torch._foreach_add_(dst, src)
+        return (dx0, None, None, None, None, None, None) + tuple(outs)
+
+
+def pad_pos_emb(pos_emb, d):
+    """[1, 2T-1, d] -> bf16 [ceil8(2T-1), d] with zero rows appended (row count a multiple of 8 keeps the bf16 GEMMs that
+    touch it -- linear_pos forward and its weight gradient -- on aligned fast paths)."""
+    pe = pos_emb.detach().reshape(-1, d)
+    rows = (pe.shape[0] + 7) // 8 * 8
+    out = torch.zeros(rows, d, dtype=torch.bfloat16, device=pe.device)
+    out[:pe.shape[0]] = pe
+    return out
+
+
+def conformer_block(x2d, layer, lens, pe_bf16, B, T, seed):
+    """x2d [B*T, d] f32 residual stream -> [B*T, d] f32 (autograd-connected to x2d and the block's parameters).
+    pe_bf16: pad_pos_emb(pos_emb) (>= 2T-1 rows)."""
+    return _ConformerBlockFn.apply(x2d, layer, lens, pe_bf16, B, T, seed, *list(layer.parameters()))

@@ -2,7 +2,7 @@
 zeroed padded frames, as the reference) -> SiLU  (conformer_modules.py:340-366), autograd path of the trainable blocks.
 
 Time-major throughout ([B,T,d], channel = lane): the depthwise conv and its two gradients are HIP kernels
-(csrc/encoder_ops.hip: ia_dwconv_time / ia_dwconv_time_wgrad) -- MIOpen has no tuned depthwise-1D kernels on gfx950
+(csrc/dwconv.hip: ia_dwconv_time / ia_dwconv_time_wgrad) -- MIOpen has no tuned depthwise-1D kernels on gfx950
 and falls back to naive ones (1.6 ms per weight gradient at bs32 x 15 s); no [B,d,T] transposes are made.
 """
 import torch
@@ -39,9 +39,11 @@ class _DepthwiseConvTime(torch.autograd.Function):
             _lib.check(L.ia_dwconv_time(_lib.ptr(dy), B, T, d, k, _lib.ptr(w2), None, 1, _lib.ptr(dx), _lib.stream_ptr()),
                        "ia_dwconv_time")
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            dw = torch.zeros(d, k, dtype=torch.float32, device=x.device)
-            db = torch.zeros(d, dtype=torch.float32, device=x.device)
+            from . import fast
+            dw = torch.empty(d, k, dtype=torch.float32, device=x.device)
+            db = torch.empty(d, dtype=torch.float32, device=x.device)
             _lib.check(L.ia_dwconv_time_wgrad(_lib.ptr(x), _lib.ptr(dy), B, T, d, k, _lib.ptr(dw), _lib.ptr(db),
+                                              _lib.ptr(fast.scratch(x.device, L.ia_dwconv_scratch_elems(B, T, d, k))),
                                               _lib.stream_ptr()), "ia_dwconv_time_wgrad")
             dw = dw.view(ctx.wshape).to(ctx.wdtype)
             db = db.to(ctx.bdtype)

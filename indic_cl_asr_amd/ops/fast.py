@@ -46,6 +46,19 @@ def f32_cat(*params):
     return w
 
 
+_SCRATCH = {}
+
+
+def scratch(dev, n):
+    """Stream-ordered fp32 scratch for the two-stage reductions (workgroup partial rows): one buffer per (device,
+    stream), reused by consecutive launches on that stream."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    buf = _SCRATCH.get(key)
+    if buf is None or buf.numel() < n:
+        buf = _SCRATCH[key] = torch.empty(max(int(n), 1 << 20), dtype=torch.float32, device=dev)
+    return buf
+
+
 def gemm_supported(K, N):
     return K % 64 == 0 and N % 8 == 0
 
@@ -81,10 +94,11 @@ def glu_dwconv_bn_silu_fast(x2_bf16, lens, B, T, d, dw_weight, dw_bias, bn, trai
     L = _lib.lib()
     dev = x2_bf16.device
     z = torch.empty(B * T, d, dtype=torch.float32, device=dev)
-    sums = torch.zeros(2, d, dtype=torch.float32, device=dev)
+    sums = torch.empty(2, d, dtype=torch.float32, device=dev)
     ksz = dw_weight.shape[-1]
     st = L.ia_glu_dwconv(_lib.ptr(x2_bf16), _lib.ptr(lens), B, T, d, ksz, _lib.ptr(dw_weight), _lib.ptr(dw_bias),
-                         _lib.ptr(z), _lib.ptr(sums[0]), _lib.ptr(sums[1]), _lib.stream_ptr())
+                         _lib.ptr(z), _lib.ptr(sums[0]), _lib.ptr(sums[1]),
+                         _lib.ptr(scratch(dev, L.ia_dwconv_scratch_elems(B, T, d, ksz))), _lib.stream_ptr())
     _lib.check(st, "ia_glu_dwconv")
     out = torch.empty(B * T, d, dtype=torch.bfloat16, device=dev)
     use_batch = bool(training or not bn.track_running_stats)

@@ -1,0 +1,58 @@
+"""Depthwise-conv kernels (csrc/dwconv.hip) through the C ABI against ATen conv1d in fp32
+(CausalConv1D as configured by the Conformer convolution module, causal_convs.py:72-150)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _scratch(L, B, T, d, k):
+    return torch.empty(max(1, L.ia_dwconv_scratch_elems(B, T, d, k)), dtype=torch.float32, device="cuda")
+
+
+@pytest.mark.parametrize("B,T,d,k", [(3, 50, 32, 9), (2, 77, 256, 31), (4, 33, 80, 5), (2, 40, 192, 17), (1, 7, 64, 31),
+                                     (32, 376, 256, 31)])
+def test_dwconv_time_forward_dgrad_wgrad(B, T, d, k):
+    from indic_cl_asr_amd import _lib
+    L = _lib.lib()
+    torch.manual_seed(B * 1000 + T + d + k)
+    x = torch.randn(B, T, d, device="cuda")
+    w = torch.randn(d, k, device="cuda") * 0.3
+    b = torch.randn(d, device="cuda")
+    dy = torch.randn(B, T, d, device="cuda")
+    xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
+    yr = F.conv1d(xr.transpose(1, 2), wr.unsqueeze(1), br, padding=(k - 1) // 2, groups=d).transpose(1, 2)
+    yr.backward(dy)
+    y = torch.empty_like(x)
+    _lib.check(L.ia_dwconv_time(_lib.ptr(x), B, T, d, k, _lib.ptr(w), _lib.ptr(b), 0, _lib.ptr(y), _lib.stream_ptr()), "fwd")
+    assert torch.allclose(y, yr, rtol=1e-4, atol=1e-4)
+    dx = torch.empty_like(x)
+    _lib.check(L.ia_dwconv_time(_lib.ptr(dy), B, T, d, k, _lib.ptr(w), None, 1, _lib.ptr(dx), _lib.stream_ptr()), "dgrad")
+    assert torch.allclose(dx, xr.grad, rtol=1e-4, atol=1e-4)
+    dw = torch.full((d, k), float("nan"), device="cuda"); db = torch.full((d,), float("nan"), device="cuda")
+    _lib.check(L.ia_dwconv_time_wgrad(_lib.ptr(x), _lib.ptr(dy), B, T, d, k, _lib.ptr(dw), _lib.ptr(db),
+                                      _lib.ptr(_scratch(L, B, T, d, k)), _lib.stream_ptr()), "wgrad")
+    scale = wr.grad.abs().max().item()
+    assert torch.allclose(dw, wr.grad.view(d, k), rtol=1e-4, atol=1e-5 * scale + 1e-4)
+    assert torch.allclose(db, br.grad, rtol=1e-4, atol=1e-5 * br.grad.abs().max().item() + 1e-4)
+
+
+@pytest.mark.parametrize("B,T,d,k", [(3, 50, 64, 9), (4, 101, 256, 31), (2, 20, 96, 15)])
+def test_glu_dwconv_masks_padding_and_returns_batchnorm_sums(B, T, d, k):
+    from indic_cl_asr_amd import _lib
+    L = _lib.lib()
+    torch.manual_seed(T)
+    x2 = torch.randn(B, T, 2 * d, device="cuda").bfloat16()
+    lens = torch.randint(1, T + 1, (B,), device="cuda"); lens[0] = T
+    w = torch.randn(d, k, device="cuda") * 0.3
+    b = torch.randn(d, device="cuda")
+    g = F.glu(x2.float(), dim=-1) * (torch.arange(T, device="cuda")[None, :] < lens[:, None]).unsqueeze(-1)
+    zr = F.conv1d(g.transpose(1, 2), w.unsqueeze(1), b, padding=(k - 1) // 2, groups=d).transpose(1, 2)
+    z = torch.empty(B, T, d, device="cuda")
+    sums = torch.full((2, d), float("nan"), device="cuda")
+    _lib.check(L.ia_glu_dwconv(_lib.ptr(x2), _lib.ptr(lens), B, T, d, k, _lib.ptr(w), _lib.ptr(b), _lib.ptr(z),
+                               _lib.ptr(sums[0]), _lib.ptr(sums[1]), _lib.ptr(_scratch(L, B, T, d, k)), _lib.stream_ptr()), "glu")
+    assert torch.allclose(z, zr, rtol=1e-3, atol=1e-3)
+    assert torch.allclose(sums[0], zr.sum((0, 1)), rtol=1e-3, atol=1e-2)
+    assert torch.allclose(sums[1], (zr * zr).sum((0, 1)), rtol=1e-3, atol=1e-2)

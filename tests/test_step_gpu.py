@@ -344,3 +344,109 @@ def test_bf16_weight_shadows_follow_the_fused_optimizer():
     with flat.weights(teacher):
         assert fast.bf16_shadow(w).abs().max().item() == 0.0
     assert torch.equal(fast.bf16_shadow(w), w.detach().bfloat16())
+
+
+def test_fused_trainable_blocks_match_aten_path_and_oracle():
+    """Trainable Conformer blocks as single autograd nodes on the HIP kernels (ops/block.py): encoder output and every
+    parameter gradient against the ATen composition on the same bf16 model and against the fp32 oracle."""
+    from indic_cl_asr_amd.config import model_config
+    from indic_cl_asr_amd.model import EncDecHybridRNNTCTCModel, freeze_layer
+    torch.manual_seed(0)
+    kw = dict(d_model=128, n_layers=3, n_heads=2, pred_hidden=64, joint_hidden=64, languages=['hi', 'ta'],
+              vocab_per_lang=16, fused_batch_size=2)
+    o = S.OracleHybridModel(**kw)
+    with torch.no_grad():
+        for l in o.encoder.layers:
+            l.self_attn.pos_bias_u.normal_(0, 0.2); l.self_attn.pos_bias_v.normal_(0, 0.2)
+            l.conv.batch_norm.weight.uniform_(0.5, 1.5); l.conv.batch_norm.bias.normal_(0, 0.2)
+    cfg = model_config('tiny', compute_dtype='bf16', dither=0.0, **kw)
+    batch = _batch()
+    o.train(); S.freeze_layer(o, 0)
+    lo, mo = o.training_step(batch, ['hi'] * 5)
+    lo.backward()
+    og = {n: p.grad for n, p in o.named_parameters()}
+    res = []
+    for fused in (True, False):
+        m = EncDecHybridRNNTCTCModel(cfg); m.load_state_dict(o.state_dict()); m.disable_dropout().cuda().train()
+        m.spec_augment_enabled = False; m.encoder.use_fused_blocks = fused
+        freeze_layer(m, 0); m.encoder.encoder_frozen_till = 0
+        lp, mp = m.training_step(tuple(t.cuda() for t in batch), ['hi'] * 5)
+        lp.backward()
+        res.append((mp, {n: p.grad for n, p in m.named_parameters()}, m))
+    assert math.isclose(res[0][0]['train_loss'], res[1][0]['train_loss'], rel_tol=5e-3)
+    assert math.isclose(res[0][0]['train_loss'], mo['train_loss'], rel_tol=2e-2)
+    n_checked = 0
+    for n, g in res[0][1].items():
+        if not n.startswith("encoder.layers."):
+            continue
+        if og[n] is None:
+            assert g is None or g.abs().max().item() == 0.0, n
+            continue
+        a, b, c = g.float().cpu().flatten(), res[1][1][n].float().cpu().flatten(), og[n].float().flatten()
+        if _structural_zero(n):
+            assert a.abs().max().item() < 5e-3 * max(1.0, c.abs().max().item()) + 1e-3, n
+            continue
+        # bf16 paths: compare direction and size of each gradient tensor (element-wise noise is ~1e-2 relative)
+        for ref, tol, tag in ((b, 0.03, "aten"), (c, 0.06, "oracle")):
+            err = (a - ref).norm().item() / (ref.norm().item() + 1e-12)
+            assert err < tol, f"{n} vs {tag}: relative L2 error {err:.3e}"
+        n_checked += 1
+    assert n_checked >= 2 * 30
+    bn0, bn1 = res[0][2].encoder.layers[2].conv.batch_norm, res[1][2].encoder.layers[2].conv.batch_norm
+    assert torch.allclose(bn0.running_var, bn1.running_var, rtol=2e-2, atol=1e-4)
+    assert int(bn0.num_batches_tracked) == int(bn1.num_batches_tracked) == 2   # the oracle's own step + this one
+    # second backward: the block adds into the existing .grad buffers itself (one multi-tensor launch)
+    m = res[0][2]
+    first = {n: g.clone() for n, g in res[0][1].items() if g is not None and n.startswith("encoder.layers.2.")}
+    lp, _ = m.training_step(tuple(t.cuda() for t in batch), ['hi'] * 5)
+    lp.backward()
+    for n, g in first.items():
+        if _structural_zero(n):
+            continue
+        now = dict(m.named_parameters())[n].grad
+        assert (now - 2 * g).norm().item() <= 0.02 * (2 * g).norm().item() + 1e-6, n
+
+
+def test_fused_block_dropout_masks_replayed_in_backward():
+    """With dropout active the block's backward must regenerate exactly the masks its forward used: check the
+    analytic directional derivatives (input and a weight) against central differences of the same seeded forward."""
+    from indic_cl_asr_amd.encoder import ConformerLayer
+    from indic_cl_asr_amd.ops import block
+    torch.manual_seed(3)
+    B, T, d = 4, 96, 128
+    layer = ConformerLayer(d, 4 * d, 2, 9, 0.5, 0.5).cuda().train()
+    with torch.no_grad():
+        layer.self_attn.pos_bias_u.normal_(0, 0.2); layer.self_attn.pos_bias_v.normal_(0, 0.2)
+    lens = torch.tensor([96, 80, 57, 33], device="cuda")
+    x = torch.randn(B * T, d, device="cuda")
+    pe = (torch.randn(2 * T - 1, d, device="cuda") * 0.5).bfloat16()
+    R = torch.randn(B * T, d, device="cuda") * (torch.arange(T, device="cuda")[None, :] < lens[:, None]).reshape(-1, 1)
+    seed = 1234
+
+    def run(xin):
+        rm, rv = layer.conv.batch_norm.running_mean.clone(), layer.conv.batch_norm.running_var.clone()
+        out = block.conformer_block(xin, layer, lens, pe, B, T, seed)
+        layer.conv.batch_norm.running_mean.copy_(rm); layer.conv.batch_norm.running_var.copy_(rv)
+        return (out * R).sum()
+
+    xg = x.clone().requires_grad_(True)
+    run(xg).backward()
+    r1, r2 = run(x.clone().requires_grad_(True)).item(), run(x.clone().requires_grad_(True)).item()
+    assert abs(r1 - r2) <= 1e-3 * abs(r1)       # same masks every time (BatchNorm sums are atomics: not bit-equal)
+    # input direction
+    v = torch.randn_like(x)
+    eps = 0.05
+    with torch.no_grad():
+        fd = (run(x + eps * v) - run(x - eps * v)).item() / (2 * eps)
+    an = (xg.grad * v).sum().item()
+    assert abs(fd - an) <= 0.1 * abs(an) + 1e-3, (fd, an)
+    # weight direction (second FFN's first projection)
+    w = layer.feed_forward2.linear1.weight
+    vw = torch.randn_like(w) * w.abs().mean()
+    an = (w.grad * vw).sum().item()
+    with torch.no_grad():
+        w.add_(eps * vw); fp = run(x).item()
+        w.sub_(2 * eps * vw); fm = run(x).item()
+        w.add_(eps * vw)
+    fd = (fp - fm) / (2 * eps)
+    assert abs(fd - an) <= 0.1 * abs(an) + 1e-3, (fd, an)
