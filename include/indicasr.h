@@ -195,6 +195,17 @@ size_t ia_attn_vt_elems(int B, int T, int H);
 int ia_relpos_attention(const void* qkv, const void* pos_proj, const float* bias_u, const float* bias_v,
                         const int64_t* lens, int B, int T, int H, int dk, float dropout_p, unsigned seed,
                         void* vt_scratch, void* ctx, ia_stream_t stream);
+/* Backward of ia_relpos_attention, row pass (one wave = 16 queries): recomputes the probabilities and writes three bf16
+ * matrices on which every remaining contraction is a plain (batched) GEMM with 16-byte aligned rows:
+ *   Pd    [B,H,T,Ts]  dropout(P)                          dV     = Pd^T dctx
+ *   dS    [B,H,T,Ts]  P o (keep*dctx V^T - dctx.ctx)/sqrt(dk)   dK = dS^T (q+u),  d(q+u) = dS K
+ *   dBand [H,B,T,Rs]  dS skewed to column pad0 + (T-1-i+j)       d(q+v) = dBand p, dp = dBand^T (q+v) summed over B
+ * with Ts, Rs, pad0 from ia_relpos_attention_bwd_dims (Ts = ceil8(T), pad0 = (8 - T%8)%8, Rs = ceil8(pad0 + 2T-1)).
+ * ctx = the forward's output, dctx its gradient (bf16 [B*T, H*dk]); same seed / dropout_p / limits as the forward. */
+int ia_relpos_attention_bwd_dims(int T, int* Ts, int* Rs, int* pad0);
+int ia_relpos_attention_bwd(const void* qkv, const void* pos_proj, const float* bias_u, const float* bias_v,
+                            const int64_t* lens, const void* ctx, const void* dctx, int B, int T, int H, int dk,
+                            float dropout_p, unsigned seed, void* Pd, void* dS, void* dBand, ia_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Persistent single-layer LSTM: the recurrence of the RNNT prediction network (RNNTDecoder.predict

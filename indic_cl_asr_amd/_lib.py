@@ -45,6 +45,8 @@ SIGNATURES = {
     "ia_bn_silu": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp]),
     "ia_attn_vt_elems": (_sz, [_i, _i, _i]),
     "ia_relpos_attention": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _c.c_uint, _vp, _vp, _vp]),
+    "ia_relpos_attention_bwd_dims": (_i, [_i, _vp, _vp, _vp]),
+    "ia_relpos_attention_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _c.c_uint, _vp, _vp, _vp, _vp]),
     "ia_lstm_scratch_bytes": (_sz, [_i, _i]),
     "ia_lstm_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "ia_lstm_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),

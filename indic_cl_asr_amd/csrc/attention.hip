@@ -221,6 +221,233 @@ __global__ __launch_bounds__(AT_THREADS, 1) void relpos_attn_kernel(
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------- backward (rows)
+// Same ownership as the forward (one wave = 16 queries of one head, all keys): recomputes the probabilities, then
+//   Pd = dropout(P)                              -> Pd_out [B,H,T,Ts] bf16   (dV = Pd^T dO is a GEMM on it)
+//   dP = keep * (dO V^T),  D_i = dO_i . O_i,  dS = P o (dP - D) / sqrt(dk)
+//                                                -> dS_out [B,H,T,Ts] bf16   (dK = dS^T (q+u), d(q+u) = dS K)
+//   the same dS skewed onto the absolute relative-position axis r = T-1-i+j (column r + pad0)
+//                                                -> dBand_out [H,B,T,Rs] bf16 (d(q+v) = dBand p, dp = dBand^T (q+v))
+// so that every contraction over queries / batch is a plain GEMM on 16-byte aligned rows (pad0 = (8 - T%8)%8 makes each
+// wave's band start a multiple of 8 columns).  Rows go registers -> wave-private LDS -> coalesced 16-byte stores.
+__global__ __launch_bounds__(AT_THREADS, 1) void relpos_attn_bwd_kernel(
+    const __bf16* __restrict__ qkv, const __bf16* __restrict__ pl, const float* __restrict__ bias_u,
+    const float* __restrict__ bias_v, const int64_t* __restrict__ lens, const __bf16* __restrict__ ctx,
+    const __bf16* __restrict__ dctx, __bf16* __restrict__ Pd_out, __bf16* __restrict__ dS_out, __bf16* __restrict__ dBand_out,
+    int B, int T, int H, int Ts, int Rs, int pad0, float scale, unsigned seed, unsigned thr, float keep_scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, q4 = lane >> 4;
+    const int d = H * AT_DK;
+    const int nqt = (T + 63) / 64;
+    int bid = blockIdx.x;
+    const int qt = bid % nqt; bid /= nqt;
+    const int h = bid % H;
+    const int b = bid / H;
+    const int len = (int)lens[b];
+    const int iw = qt * 64 + wave * 16;
+    float* sR = reinterpret_cast<float*>(smem) + (size_t)wave * (16 * AT_LDR + 80);
+    float* sD = sR + 16 * AT_LDR;  // [4][16] partial dO.O, then 16 row sums
+    if (iw >= T) return;           // wave-uniform; no block-level barrier below
+    const int nt = (T + 15) / 16, nr = nt + 1;
+
+    const int iq = (iw + c < T) ? (iw + c) : (T - 1);
+    const __bf16* qrow = qkv + ((size_t)b * T + iq) * (3 * d) + h * AT_DK;
+    bf8 Qu[2], Qv[2], dOa[2];
+    float dpart = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const bf8 qv = *reinterpret_cast<const bf8*>(qrow + ks * 32 + q4 * 8);
+        Qu[ks] = add_bias_bf8(qv, bias_u + h * AT_DK + ks * 32 + q4 * 8);
+        Qv[ks] = add_bias_bf8(qv, bias_v + h * AT_DK + ks * 32 + q4 * 8);
+        const size_t off = ((size_t)b * T + iq) * d + h * AT_DK + ks * 32 + q4 * 8;
+        dOa[ks] = *reinterpret_cast<const bf8*>(dctx + off);
+        const bf8 oa = *reinterpret_cast<const bf8*>(ctx + off);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dpart += (float)dOa[ks][j] * (float)oa[j];
+    }
+    sD[q4 * 16 + c] = dpart;
+    const int r_lo = T - 1 - (iw + 15);
+    {
+        f4 R[AT_NR];
+#pragma unroll
+        for (int rt = 0; rt < AT_NR; ++rt) {
+            R[rt] = (f4){0.f, 0.f, 0.f, 0.f};
+            if (rt < nr) {
+                int r = r_lo + rt * 16 + c;
+                r = r < 0 ? 0 : (r > 2 * T - 2 ? 2 * T - 2 : r);
+                const __bf16* prow = pl + (size_t)r * d + h * AT_DK;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const bf8 pf = *reinterpret_cast<const bf8*>(prow + ks * 32 + q4 * 8);
+                    R[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Qv[ks], pf, R[rt], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int rt = 0; rt < AT_NR; ++rt)
+            if (rt < nr)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sR[(q4 * 4 + r) * AT_LDR + rt * 16 + c] = R[rt][r];
+    }
+    f4 S[AT_NT];
+    const __bf16* kbase = qkv + (size_t)b * T * (3 * d) + d + h * AT_DK;
+#pragma unroll
+    for (int jt = 0; jt < AT_NT; ++jt) {
+        S[jt] = (f4){0.f, 0.f, 0.f, 0.f};
+        if (jt < nt) {
+            int j = jt * 16 + c;
+            j = j < T ? j : T - 1;
+            const __bf16* krow = kbase + (size_t)j * (3 * d);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf8 kf = *reinterpret_cast<const bf8*>(krow + ks * 32 + q4 * 8);
+                S[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Qu[ks], kf, S[jt], 0, 0, 0);
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    float m[4] = {IA_NEG_INF, IA_NEG_INF, IA_NEG_INF, IA_NEG_INF};
+#pragma unroll
+    for (int jt = 0; jt < AT_NT; ++jt)
+        if (jt < nt) {
+            const int j = jt * 16 + c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int il = q4 * 4 + r;
+                const float bd = sR[il * AT_LDR + j + 15 - il];
+                const float s = (j < len) ? (S[jt][r] + bd) * scale : IA_NEG_INF;
+                S[jt][r] = s;
+                m[r] = fmaxf(m[r], s);
+            }
+        }
+    float Drow[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        m[r] = fmaxf(m[r], IA_DPP_F(m[r], m[r], 0xB1, 0xF));
+        m[r] = fmaxf(m[r], IA_DPP_F(m[r], m[r], 0x4E, 0xF));
+        m[r] = fmaxf(m[r], IA_DPP_F(m[r], m[r], 0x141, 0xF));
+        m[r] = fmaxf(m[r], IA_DPP_F(m[r], m[r], 0x140, 0xF));
+        const int il = q4 * 4 + r;
+        Drow[r] = (sD[il] + sD[16 + il]) + (sD[32 + il] + sD[48 + il]);
+    }
+    float sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jt = 0; jt < AT_NT; ++jt)
+        if (jt < nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = (len > 0) ? __expf(S[jt][r] - m[r]) : 0.f;
+                S[jt][r] = p;
+                sum[r] += p;
+            }
+    float inv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        sum[r] += IA_DPP_F(0.f, sum[r], 0xB1, 0xF);
+        sum[r] += IA_DPP_F(0.f, sum[r], 0x4E, 0xF);
+        sum[r] += IA_DPP_F(0.f, sum[r], 0x141, 0xF);
+        sum[r] += IA_DPP_F(0.f, sum[r], 0x140, 0xF);
+        const int i = iw + q4 * 4 + r;
+        inv[r] = (i < len && sum[r] > 0.f) ? 1.f / sum[r] : 0.f;  // padded queries: zero context in the forward
+    }
+    __bf16* sP = reinterpret_cast<__bf16*>(sR);
+    constexpr int LDP = 2 * AT_LDR;
+    const int chs = Ts / 8, chb = Rs / 8;
+    const size_t row0 = ((size_t)(b * H + h) * T + iw);
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // band reads done before the scratch is reused
+    // ---- stage 1: Pd = dropout(P) -> LDS -> Pd_out
+#pragma unroll
+    for (int jt = 0; jt < AT_NT; ++jt)
+        if (jt < nt) {
+            const int j = jt * 16 + c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float p = S[jt][r] * inv[r];
+                S[jt][r] = p;
+                if (thr > 0) {
+                    const int i = iw + q4 * 4 + r;
+                    const unsigned idx = (((unsigned)(b * H + h) * (unsigned)T + (unsigned)i) * (unsigned)T + (unsigned)j);
+                    const unsigned rnd = at_hash32(idx * 0x9E3779B1u + seed) & 0xFFu;
+                    p = (rnd >= thr) ? p * keep_scale : 0.f;
+                }
+                sP[(q4 * 4 + r) * LDP + j] = (__bf16)p;
+            }
+        }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    for (int il = 0; il < 16; ++il) {
+        if (iw + il >= T) break;
+        for (int ch = lane; ch < chs; ch += 64)
+            *reinterpret_cast<uint4*>(Pd_out + (row0 + il) * Ts + ch * 8) = *reinterpret_cast<const uint4*>(sP + il * LDP + ch * 8);
+    }
+    // ---- stage 2: dS = P o (keep*dO V^T - D) * scale
+    const __bf16* vbase = qkv + (size_t)b * T * (3 * d) + 2 * d + h * AT_DK;
+#pragma unroll
+    for (int jt = 0; jt < AT_NT; ++jt)
+        if (jt < nt) {
+            int j = jt * 16 + c;
+            const int jc = j < T ? j : T - 1;
+            const __bf16* vrow = vbase + (size_t)jc * (3 * d);
+            f4 dP = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf8 vf = *reinterpret_cast<const bf8*>(vrow + ks * 32 + q4 * 8);
+                dP = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dOa[ks], vf, dP, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float g = dP[r];
+                if (thr > 0) {
+                    const int i = iw + q4 * 4 + r;
+                    const unsigned idx = (((unsigned)(b * H + h) * (unsigned)T + (unsigned)i) * (unsigned)T + (unsigned)j);
+                    const unsigned rnd = at_hash32(idx * 0x9E3779B1u + seed) & 0xFFu;
+                    g = (rnd >= thr) ? g * keep_scale : 0.f;
+                }
+                S[jt][r] = S[jt][r] * (g - Drow[r]) * scale;
+            }
+        }
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // stage-1 LDS reads returned
+#pragma unroll
+    for (int jt = 0; jt < AT_NT; ++jt)
+        if (jt < nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sP[(q4 * 4 + r) * LDP + jt * 16 + c] = (__bf16)S[jt][r];
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    for (int il = 0; il < 16; ++il) {
+        if (iw + il >= T) break;
+        for (int ch = lane; ch < chs; ch += 64)
+            *reinterpret_cast<uint4*>(dS_out + (row0 + il) * Ts + ch * 8) = *reinterpret_cast<const uint4*>(sP + il * LDP + ch * 8);
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    // ---- stage 3: the same dS on the band axis rr = j + 15 - il (zero elsewhere) -> dBand_out[..., r_lo + pad0 + rr]
+    const int nb8 = nr * 2;  // 16-byte chunks per band row
+    for (int x = lane; x < 16 * nb8; x += 64) {
+        const int il = x / nb8, ch = x - il * nb8;
+        *reinterpret_cast<uint4*>(sP + il * LDP + ch * 8) = make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int jt = 0; jt < AT_NT; ++jt)
+        if (jt < nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int il = q4 * 4 + r;
+                sP[il * LDP + jt * 16 + c + 15 - il] = (__bf16)S[jt][r];
+            }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    const int c0 = r_lo + pad0;  // multiple of 8 (may be negative only for rows >= T)
+    const size_t brow0 = ((size_t)(h * B + b) * T + iw);
+    for (int il = 0; il < 16; ++il) {
+        if (iw + il >= T) break;
+        for (int ch = lane; ch < chb; ch += 64) {
+            const int rel = ch * 8 - c0;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (rel >= 0 && rel < nr * 16) v = *reinterpret_cast<const uint4*>(sP + il * LDP + rel);
+            *reinterpret_cast<uint4*>(dBand_out + (brow0 + il) * Rs + ch * 8) = v;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" size_t ia_attn_vt_elems(int B, int T, int H) {
@@ -252,6 +479,39 @@ extern "C" int ia_relpos_attention(const void* qkv, const void* pos_proj, const 
     hipLaunchKernelGGL(relpos_attn_kernel, dim3(B * H * nqt), dim3(AT_THREADS), lds, st, (const __bf16*)qkv,
                        (const __bf16*)pos_proj, (const __bf16*)vt_scratch, bias_u, bias_v, lens, (__bf16*)ctx, B, T, H, Tp,
                        1.0f / sqrtf((float)dk), seed, thr, keep_scale);
+    IA_RETURN_IF_LAUNCH_FAILED();
+    return IA_OK;
+}
+
+extern "C" int ia_relpos_attention_bwd_dims(int T, int* Ts, int* Rs, int* pad0) {
+    if (T <= 0 || !Ts || !Rs || !pad0) return IA_INVALID_VALUE;
+    *Ts = (T + 7) / 8 * 8;
+    *pad0 = (8 - T % 8) % 8;
+    *Rs = (*pad0 + 2 * T - 1 + 7) / 8 * 8;
+    return IA_OK;
+}
+
+extern "C" int ia_relpos_attention_bwd(const void* qkv, const void* pos_proj, const float* bias_u, const float* bias_v,
+                                       const int64_t* lens, const void* ctx, const void* dctx, int B, int T, int H, int dk,
+                                       float dropout_p, unsigned seed, void* Pd, void* dS, void* dBand, ia_stream_t stream) {
+    if (!qkv || !pos_proj || !bias_u || !bias_v || !lens || !ctx || !dctx || !Pd || !dS || !dBand || B <= 0 || T <= 0 || H <= 0)
+        return IA_INVALID_VALUE;
+    if (dk != AT_DK || T > AT_NT * 16) return IA_UNSUPPORTED;
+    if (dropout_p < 0.f || dropout_p >= 1.f) return IA_INVALID_VALUE;
+    if (!ia_is_aligned(qkv, 16) || !ia_is_aligned(pos_proj, 16) || !ia_is_aligned(ctx, 16) || !ia_is_aligned(dctx, 16) ||
+        !ia_is_aligned(Pd, 16) || !ia_is_aligned(dS, 16) || !ia_is_aligned(dBand, 16))
+        return IA_INVALID_VALUE;
+    int Ts, Rs, pad0;
+    ia_relpos_attention_bwd_dims(T, &Ts, &Rs, &pad0);
+    const unsigned thr = (unsigned)(dropout_p * 256.f + 0.5f);
+    const float keep_scale = thr > 0 ? 256.f / (256.f - (float)thr) : 1.f;
+    const size_t lds = 4 * (size_t)(16 * AT_LDR + 80) * sizeof(float);
+    if (hipFuncSetAttribute((const void*)relpos_attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return IA_LAUNCH_FAILED;
+    const int nqt = (T + 63) / 64;
+    hipLaunchKernelGGL(relpos_attn_bwd_kernel, dim3(B * H * nqt), dim3(AT_THREADS), lds, (hipStream_t)stream, (const __bf16*)qkv,
+                       (const __bf16*)pos_proj, bias_u, bias_v, lens, (const __bf16*)ctx, (const __bf16*)dctx, (__bf16*)Pd,
+                       (__bf16*)dS, (__bf16*)dBand, B, T, H, Ts, Rs, pad0, 1.0f / sqrtf((float)dk), seed, thr, keep_scale);
     IA_RETURN_IF_LAUNCH_FAILED();
     return IA_OK;
 }

@@ -3,8 +3,8 @@
 Forward = the fused no-autograd path of encoder.ConformerLayer.forward_fast (GEMMs with fused epilogues, LayerNorm,
 GLU+depthwise conv+BatchNorm+SiLU, rel-pos attention) keeping the intermediates the backward needs; backward = manual
 chain rule: bf16 library GEMMs for the data gradients, batched split-K GEMMs for the weight gradients, and the
-kernels of csrc/encoder_bwd.hip for everything in between.  The attention core's backward is obtained by recomputing
-it with ATen ops under autograd with the SAME dropout mask the HIP kernel used (ia_attn_keepmask).
+kernels of csrc/encoder_bwd.hip for everything in between; the attention core's backward is csrc/attention.hip's row
+pass + batched GEMMs (ops/fast.relpos_attention_bwd).
 
 Semantics: ConformerLayer.forward, A/parts/submodules/conformer_modules.py:141-214 (bf16 projections, fp32 residual
 stream / norms / BatchNorm statistics), dropout masks are counter-based and regenerated in the backward.
@@ -12,7 +12,6 @@ stream / norms / BatchNorm statistics), dropout masks are counter-based and rege
 import torch
 
 from .. import _lib
-from . import attention as att_ops
 from . import fast
 
 
@@ -204,24 +203,10 @@ class _ConformerBlockFn(torch.autograd.Function):
         # self-attention
         dB = _branch_grad(dx2, 1.0, p, seed + 3)
         dctx, G["self_attn.linear_out.weight"], G["self_attn.linear_out.bias"] = _lin_bwd(dB, S["ctxv"], W["wo"])
-        h, dk = att.h, att.d_k
-        keep = None
-        if patt > 0.0:
-            keep = torch.empty(B, h, T, T, dtype=torch.bfloat16, device=dev)
-            _lib.check(L.ia_attn_keepmask(B, h, T, patt, (seed + 7) & 0xFFFFFFFF, _ptr(keep), _lib.stream_ptr()), "ia_attn_keepmask")
-        qkv_l = S["qkv"].detach().requires_grad_(True)
-        pl_l = S["pl"].detach().requires_grad_(True)
-        u_l = att.pos_bias_u.detach().clone().requires_grad_(True)
-        v_l = att.pos_bias_v.detach().clone().requires_grad_(True)
-        with torch.enable_grad():
-            q5 = qkv_l.view(B, T, 3, h, dk)
-            q, k, v = (q5[:, :, i].transpose(1, 2) for i in range(3))
-            cre = att_ops.rel_pos_attention(q, k, v, pl_l[:2 * T - 1].view(-1, h, dk).transpose(0, 1), u_l, v_l, S["lens"], 0.0, False,
-                                            keep_mask=keep)
-            cre = cre.transpose(1, 2).reshape(N, d)
-        dqkv, dpl, du, dv = torch.autograd.grad(cre, [qkv_l, pl_l, u_l, v_l], dctx.to(cre.dtype))
+        dqkv, dpl, du, dv = fast.relpos_attention_bwd(S["qkv"], S["pl"], att.pos_bias_u, att.pos_bias_v, S["lens"], S["ctxv"],
+                                                      dctx, B, T, att.h, att.d_k, patt, seed + 7)
         G["self_attn.pos_bias_u"], G["self_attn.pos_bias_v"] = du, dv
-        dy, dWqkv, dbqkv = _lin_bwd(dqkv.contiguous(), S["y2"], W["wqkv"])
+        dy, dWqkv, dbqkv = _lin_bwd(dqkv, S["y2"], W["wqkv"])
         for i, nm in enumerate(("q", "k", "v")):
             G[f"self_attn.linear_{nm}.weight"] = dWqkv[i * d:(i + 1) * d]
             G[f"self_attn.linear_{nm}.bias"] = dbqkv[i * d:(i + 1) * d]

@@ -134,6 +134,57 @@ def relpos_attention(qkv_bf16, pos_proj_bf16, bias_u, bias_v, lens, B, T, H, dk,
     return ctx
 
 
+def attention_bwd_dims(T):
+    import ctypes
+    ts, rs, p0 = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    _lib.check(_lib.lib().ia_relpos_attention_bwd_dims(int(T), ctypes.byref(ts), ctypes.byref(rs), ctypes.byref(p0)), "dims")
+    return ts.value, rs.value, p0.value
+
+
+def relpos_attention_bwd(qkv, pl, bias_u, bias_v, lens, ctx, dctx, B, T, H, dk, dropout_p=0.0, seed=0):
+    """Backward of relpos_attention.  qkv [B*T,3d], pl [>=2T-1, d], ctx/dctx [B*T, d] (bf16) ->
+    (dqkv [B*T,3d] bf16, dpl [pl rows, d] bf16, dbias_u [H,dk] f32, dbias_v [H,dk] f32).
+    csrc/attention.hip writes dropout(P), dS and the band-skewed dS; the five contractions are batched GEMMs on them."""
+    L = _lib.lib()
+    dev = qkv.device
+    d = H * dk
+    Ts, Rs, pad0 = attention_bwd_dims(T)
+    bf = torch.bfloat16
+    Pd = torch.empty(B, H, T, Ts, dtype=bf, device=dev)
+    dS = torch.empty(B, H, T, Ts, dtype=bf, device=dev)
+    dBand = torch.empty(H, B * T, Rs, dtype=bf, device=dev)
+    dctx = dctx.contiguous()
+    st = L.ia_relpos_attention_bwd(_lib.ptr(qkv), _lib.ptr(pl), _lib.ptr(bias_u), _lib.ptr(bias_v), _lib.ptr(lens), _lib.ptr(ctx),
+                                   _lib.ptr(dctx), B, T, H, dk, float(dropout_p), int(seed) & 0xFFFFFFFF, _lib.ptr(Pd),
+                                   _lib.ptr(dS), _lib.ptr(dBand), _lib.stream_ptr())
+    _lib.check(st, "ia_relpos_attention_bwd")
+    q5 = qkv.view(B, T, 3, H, dk)
+    qf = q5[:, :, 0].float()
+    Qu = (qf + bias_u.detach().view(1, 1, H, dk)).to(bf).permute(0, 2, 1, 3).contiguous()      # [B,H,T,dk]
+    Qv = (qf + bias_v.detach().view(1, 1, H, dk)).to(bf).permute(2, 0, 1, 3).reshape(H, B * T, dk)  # [H,B*T,dk]
+    K = q5[:, :, 1].permute(0, 2, 1, 3).contiguous()
+    dO = dctx.view(B, T, H, dk).permute(0, 2, 1, 3).contiguous()
+    Pv, dSv = (Pd, dS) if Ts == T else (Pd[..., :T], dS[..., :T])
+    dV = torch.matmul(Pv.transpose(-1, -2), dO)                                                # [B,H,T,dk]
+    dK = torch.matmul(dSv.transpose(-1, -2), Qu)
+    dQu = torch.matmul(dSv, K)
+    R = 2 * T - 1
+    posB = torch.zeros(H, Rs, dk, dtype=bf, device=dev)
+    posB[:, pad0:pad0 + R] = pl[:R].view(R, H, dk).permute(1, 0, 2)
+    dQv = torch.bmm(dBand, posB)                                                               # [H,B*T,dk]
+    dposB = torch.bmm(dBand.transpose(1, 2), Qv)                                               # [H,Rs,dk]
+    du = dQu.float().sum((0, 2))
+    dvb = dQv.float().sum(1)
+    dqkv = torch.empty(B * T, 3 * d, dtype=bf, device=dev)
+    d5 = dqkv.view(B, T, 3, H, dk)
+    d5[:, :, 0] = dQu.permute(0, 2, 1, 3) + dQv.view(H, B, T, dk).permute(1, 2, 0, 3)
+    d5[:, :, 1] = dK.permute(0, 2, 1, 3)
+    d5[:, :, 2] = dV.permute(0, 2, 1, 3)
+    dpl = torch.zeros_like(pl)
+    dpl[:R] = dposB[:, pad0:pad0 + R].permute(1, 0, 2).reshape(R, d)
+    return dqkv, dpl, du, dvb
+
+
 def colsum(x_bf16):
     M, N = x_bf16.shape
     out = torch.zeros(N, dtype=torch.float32, device=x_bf16.device)
