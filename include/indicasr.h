@@ -105,8 +105,9 @@ int ia_rnnt_export_alphas_betas(const void* workspace, size_t workspace_bytes, c
  *               kappa > 0: power-of-two range scale chosen by the caller so that kappa*|cost_grad| ~ 1.
  *               ev_start/ev_stop: optional caller-owned hipEvent_t recorded around the streaming gradient kernel.
  * ia_joint_hidden: hidden[cell, 0:H] = keep * relu(f+g) (un-scaled), hidden[cell, H] = 1, rest of the LDH-wide row 0.
- * ia_joint_dh_reduce: d f[b,t,:] = (1/kappa) sum_u mask * dH[b,t,u,:] (written), d g[b,u,:] += (1/kappa) sum_t ...
- *               (f32 atomics; caller zeroes df and dg).  dH = G @ W[0:LD,:] is a library GEMM by the caller.
+ * ia_joint_dh_reduce: d f[b,t,:] = (1/kappa) sum_u mask * dH[b,t,u,:], d g[b,u,:] = (1/kappa) sum_t ... (both written;
+ *               16-frame partial rows of d g in `scratch` = ia_joint_dh_reduce_scratch_bytes, then a finishing sum: no
+ *               atomics, deterministic).  dH = G @ W[0:LD,:] is a library GEMM by the caller.
  */
 int ia_joint_ld(int V);
 int ia_joint_fwd(const void* f, const void* g, const void* W, const float* bias, const int64_t* labels,
@@ -129,7 +130,18 @@ int ia_joint_hidden(const void* f, const void* g, void* hidden, int B, int T, in
                     unsigned seed, ia_stream_t stream);
 int ia_joint_dh_reduce(const void* dh, const void* f, const void* g, const int64_t* act_lens,
                        const int64_t* label_lens, float* df, float* dg, int B, int T, int U1, int H, float inv_kappa,
-                       float dropout_p, unsigned seed, ia_stream_t stream);
+                       float dropout_p, unsigned seed, void* scratch, ia_stream_t stream);
+size_t ia_joint_dh_reduce_scratch_bytes(int B, int T, int U1, int H);
+/* ia_joint_dh_fused: the dH GEMM, the relu/dropout mask and both reductions of ia_joint_dh_reduce in ONE kernel (dH only
+ * exists as MFMA accumulators):  df[b,t,:] (written for t < act_len rounded up to 16; caller zeroes df) and dg[b,u,:] +=
+ * (f32 atomics, one per element and frame slice; caller zeroes dg).  G = ia_joint_backward_g's in-place output
+ * [B*T*U1, LD] f16; Wt = W transposed and zero padded to [H, ia_joint_dh_k()] f16 (Wt[h][v] = W[v][h], dropout scale
+ * folded as in the forward).  Supported when ia_joint_dh_fused_supported(U1, H, LD): H % 128 == 0, LD <= 288. */
+int ia_joint_dh_fused_supported(int U1, int H, int LD);
+int ia_joint_dh_k(void);
+int ia_joint_dh_fused(const void* G, const void* Wt, const void* f, const void* g, const int64_t* act_lens,
+                      const int64_t* label_lens, float* df, float* dg, int B, int T, int U1, int H, int LD,
+                      float inv_kappa, float dropout_p, unsigned seed, ia_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Conformer block forward building blocks (bf16 projections, fp32 residual stream).

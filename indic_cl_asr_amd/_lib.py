@@ -32,7 +32,11 @@ SIGNATURES = {
     "ia_joint_backward_g": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _f, _vp, _i, _i, _vp, _sz, _vp, _vp, _vp]),
     "ia_joint_hidden_t": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _c.c_uint, _vp]),
     "ia_joint_hidden": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _c.c_uint, _vp]),
-    "ia_joint_dh_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _c.c_uint, _vp]),
+    "ia_joint_dh_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _c.c_uint, _vp, _vp]),
+    "ia_joint_dh_reduce_scratch_bytes": (_sz, [_i, _i, _i, _i]),
+    "ia_joint_dh_fused_supported": (_i, [_i, _i, _i]),
+    "ia_joint_dh_k": (_i, []),
+    "ia_joint_dh_fused": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _c.c_uint, _vp]),
     "ia_gemm_bf16": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _f, _c.c_uint, _f, _vp, _i, _vp, _i, _vp, _i, _vp]),
     "ia_subsample_conv1": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ia_subsample_conv2": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),

@@ -7,7 +7,7 @@
 //   joint_hidden ........ hidden[cell, 0:H] = keep * relu(f[b,t,:] + g[b,u,:]), column H = 1 (so the dW GEMM also
 //                         yields dbias), regenerated with the same counter-based dropout mask as the forward.
 //   joint_dh_reduce ..... one pass over dHidden: apply the relu/dropout mask (recomputed from f,g), unscale, and reduce
-//                         over u -> d f[b,t,:] (registers) and over t -> d g[b,u,:] (one f32 atomic per 16 frames).
+//                         over u -> d f[b,t,:] (registers) and over t -> d g[b,u,:] (16-frame partial rows + a finishing sum).
 #include "joint_common.h"
 #include "rnnt_ws.h"
 
@@ -70,56 +70,100 @@ __global__ __launch_bounds__(256) void joint_hidden_kernel(const _Float16* __res
     }
 }
 
-// grid = B * ceil(T/16); block = H/2 threads, thread owns 2 adjacent hidden units.
+// One pass over dHidden without atomics: thread = (utterance, 16-frame chunk, 8 hidden units); label loop outside, the
+// chunk's 16 frames unrolled inside (16 independent 16-byte loads in flight per lane).  d f accumulates in registers
+// over the labels; the chunk's frame sum for each label goes to a partial row part[b][chunk][u][H] that
+// joint_dg_finish_kernel adds up (f32 atomics here cost 50M same-line operations: 0.9 ms vs 0.4 ms for this pass).
 constexpr int DHR_T = 16;
 template <bool DROPOUT>
-__global__ void joint_dh_reduce_kernel(const _Float16* __restrict__ dh, const _Float16* __restrict__ f,
-                                       const _Float16* __restrict__ g, const int64_t* __restrict__ act_lens,
-                                       const int64_t* __restrict__ label_lens, float* __restrict__ df,
-                                       float* __restrict__ dg, int T, int U1, int H, float inv_kappa, unsigned seed,
-                                       unsigned thr) {
-    const int ntc = (T + DHR_T - 1) / DHR_T;
-    const int b = blockIdx.x / ntc, t0 = (blockIdx.x - b * ntc) * DHR_T;
-    const int Tb = (int)act_lens[b], Ub = (int)label_lens[b] + 1;
-    if (t0 >= Tb) return;
-    const int nt = (Tb - t0 < DHR_T) ? (Tb - t0) : DHR_T;
-    const int h = threadIdx.x * 2;
-    float accf[DHR_T][2];
-    h2 fv[DHR_T];
-#pragma unroll
-    for (int i = 0; i < DHR_T; ++i) {
-        accf[i][0] = accf[i][1] = 0.f;
-        fv[i] = (i < nt) ? *reinterpret_cast<const h2*>(f + ((size_t)b * T + t0 + i) * H + h) : (h2){(_Float16)0, (_Float16)0};
-    }
-    for (int u = 0; u < Ub; ++u) {
-        const h2 gv = *reinterpret_cast<const h2*>(g + ((size_t)b * U1 + u) * H + h);
-        float s0 = 0.f, s1 = 0.f;
+__global__ __launch_bounds__(256) void joint_dh_reduce_kernel(const _Float16* __restrict__ dh, const _Float16* __restrict__ f,
+                                                              const _Float16* __restrict__ g,
+                                                              const int64_t* __restrict__ act_lens,
+                                                              const int64_t* __restrict__ label_lens, float* __restrict__ df,
+                                                              float* __restrict__ part, int B, int T, int U1, int H,
+                                                              float inv_kappa, unsigned seed, unsigned thr) {
+    const int hg = H / 8, ntc = (T + DHR_T - 1) / DHR_T;
+    const int64_t items = (int64_t)B * ntc * hg;
+    for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < items; it += (int64_t)gridDim.x * 256) {
+        const int kg = (int)(it % hg);
+        const int64_t bc = it / hg;
+        const int tc = (int)(bc % ntc), b = (int)(bc / ntc);
+        const int t0 = tc * DHR_T, h0 = kg * 8;
+        const int Tb = (int)act_lens[b], Ub = (int)label_lens[b] + 1;
+        float* prow = part + (((size_t)b * ntc + tc) * U1) * H + h0;
+        const int nt = (Tb - t0 < DHR_T) ? (Tb - t0) : DHR_T;  // frames of this chunk inside the utterance (may be <= 0)
+        union H8 { h8 v; h2 p[4]; _Float16 h[8]; };
+        H8 fv[DHR_T];
+        float accf[DHR_T][8];
 #pragma unroll
         for (int i = 0; i < DHR_T; ++i) {
-            if (i < nt) {  // wave-uniform
-                const size_t cell = ((size_t)b * T + t0 + i) * U1 + u;
-                const h2 d = *reinterpret_cast<const h2*>(dh + cell * H + h);
-                const h2 pre = fv[i] + gv;
-                float d0 = ((float)pre[0] > 0.f) ? (float)d[0] : 0.f;
-                float d1 = ((float)pre[1] > 0.f) ? (float)d[1] : 0.f;
-                if (DROPOUT) {
-                    const unsigned m = dropout_keep8(seed, (unsigned)cell, (unsigned)(h >> 3), thr);
-                    d0 = ((m >> (h & 7)) & 1u) ? d0 : 0.f;
-                    d1 = ((m >> ((h & 7) + 1)) & 1u) ? d1 : 0.f;
-                }
-                accf[i][0] += d0; accf[i][1] += d1;
-                s0 += d0; s1 += d1;
-            }
-        }
-        atomicAdd(dg + ((size_t)b * U1 + u) * H + h, s0 * inv_kappa);
-        atomicAdd(dg + ((size_t)b * U1 + u) * H + h + 1, s1 * inv_kappa);
-    }
+            const int t = (t0 + i < T) ? t0 + i : T - 1;
+            fv[i].v = *reinterpret_cast<const h8*>(f + ((size_t)b * T + t) * H + h0);
 #pragma unroll
-    for (int i = 0; i < DHR_T; ++i)
-        if (i < nt) {
-            float2 o = make_float2(accf[i][0] * inv_kappa, accf[i][1] * inv_kappa);
-            *reinterpret_cast<float2*>(df + ((size_t)b * T + t0 + i) * H + h) = o;
+            for (int j = 0; j < 8; ++j) accf[i][j] = 0.f;
         }
+        for (int u = 0; u < U1; ++u) {
+            float s[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] = 0.f;
+            if (u < Ub && nt > 0) {
+                H8 gv;
+                gv.v = *reinterpret_cast<const h8*>(g + ((size_t)b * U1 + u) * H + h0);
+                H8 d[DHR_T];
+#pragma unroll
+                for (int i = 0; i < DHR_T; ++i) {
+                    const int t = (i < nt) ? t0 + i : t0;
+                    d[i].v = *reinterpret_cast<const h8*>(dh + (((size_t)b * T + t) * U1 + u) * H + h0);
+                }
+#pragma unroll
+                for (int i = 0; i < DHR_T; ++i) {
+                    if (i < nt) {
+                        const size_t cell = ((size_t)b * T + t0 + i) * U1 + u;
+                        unsigned m = 0xFFu;
+                        if (DROPOUT) m = dropout_keep8(seed, (unsigned)cell, (unsigned)kg, thr);
+                        H8 pre;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pre.p[e] = fv[i].p[e] + gv.p[e];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const float x = (((float)pre.h[j] > 0.f) && ((m >> j) & 1u)) ? (float)d[i].h[j] : 0.f;
+                            accf[i][j] += x;
+                            s[j] += x;
+                        }
+                    }
+                }
+            }
+            *reinterpret_cast<float4*>(prow + (size_t)u * H) = make_float4(s[0], s[1], s[2], s[3]);
+            *reinterpret_cast<float4*>(prow + (size_t)u * H + 4) = make_float4(s[4], s[5], s[6], s[7]);
+        }
+#pragma unroll
+        for (int i = 0; i < DHR_T; ++i)
+            if (t0 + i < T) {
+                float* o = df + ((size_t)b * T + t0 + i) * H + h0;
+                *reinterpret_cast<float4*>(o) = make_float4(accf[i][0] * inv_kappa, accf[i][1] * inv_kappa, accf[i][2] * inv_kappa, accf[i][3] * inv_kappa);
+                *reinterpret_cast<float4*>(o + 4) = make_float4(accf[i][4] * inv_kappa, accf[i][5] * inv_kappa, accf[i][6] * inv_kappa, accf[i][7] * inv_kappa);
+            }
+    }
+}
+
+// dg[b][u][:] = inv_kappa * sum_chunks part[b][chunk][u][:]   (4 floats per thread)
+__global__ __launch_bounds__(256) void joint_dg_finish_kernel(const float* __restrict__ part, float* __restrict__ dg, int B,
+                                                              int ntc, int U1, int H, float inv_kappa) {
+    const int64_t n4 = (int64_t)B * U1 * H / 4, row4 = (int64_t)U1 * H / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / row4, r = i - b * row4;
+        const float4* p = reinterpret_cast<const float4*>(part) + b * ntc * row4 + r;
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+        int c = 0;
+        for (; c + 1 < ntc; c += 2) {
+            const float4 x = p[(int64_t)c * row4], y = p[(int64_t)(c + 1) * row4];
+            a0.x += x.x; a0.y += x.y; a0.z += x.z; a0.w += x.w;
+            a1.x += y.x; a1.y += y.y; a1.z += y.z; a1.w += y.w;
+        }
+        if (c < ntc) { const float4 x = p[(int64_t)c * row4]; a0.x += x.x; a0.y += x.y; a0.z += x.z; a0.w += x.w; }
+        reinterpret_cast<float4*>(dg)[i] = make_float4((a0.x + a1.x) * inv_kappa, (a0.y + a1.y) * inv_kappa,
+                                                       (a0.z + a1.z) * inv_kappa, (a0.w + a1.w) * inv_kappa);
+    }
 }
 
 // Same gradient, one 64-cell tile per iteration, additionally emitting G^T in the chunked K-contiguous layout
@@ -282,20 +326,31 @@ extern "C" int ia_joint_hidden(const void* f, const void* g, void* hidden, int B
     return IA_OK;
 }
 
+extern "C" size_t ia_joint_dh_reduce_scratch_bytes(int B, int T, int U1, int H) {
+    if (B <= 0 || T <= 0 || U1 <= 0 || H <= 0) return 0;
+    return (size_t)B * ((T + DHR_T - 1) / DHR_T) * U1 * H * sizeof(float);
+}
+
 extern "C" int ia_joint_dh_reduce(const void* dh, const void* f, const void* g, const int64_t* act_lens,
                                   const int64_t* label_lens, float* df, float* dg, int B, int T, int U1, int H,
-                                  float inv_kappa, float dropout_p, unsigned seed, ia_stream_t stream) {
-    if (!dh || !f || !g || !act_lens || !label_lens || !df || !dg || B <= 0 || T <= 0 || U1 <= 0) return IA_INVALID_VALUE;
-    if (H % 8 != 0 || H / 2 > 1024 || !ia_is_aligned(df, 8)) return IA_UNSUPPORTED;
+                                  float inv_kappa, float dropout_p, unsigned seed, void* scratch, ia_stream_t stream) {
+    if (!dh || !f || !g || !act_lens || !label_lens || !df || !dg || !scratch || B <= 0 || T <= 0 || U1 <= 0)
+        return IA_INVALID_VALUE;
+    if (H % 8 != 0 || !ia_is_aligned(df, 16) || !ia_is_aligned(dg, 16) || !ia_is_aligned(scratch, 16) || !ia_is_aligned(dh, 16))
+        return IA_UNSUPPORTED;
     const unsigned thr = (unsigned)(dropout_p * 256.f + 0.5f);
     const int ntc = (T + DHR_T - 1) / DHR_T;
-    const dim3 grid((unsigned)(B * ntc)), blk(H / 2);
+    const dim3 grid(grid_for((int64_t)B * ntc * (H / 8))), blk(256);
+    hipStream_t st = (hipStream_t)stream;
     if (thr > 0)
-        hipLaunchKernelGGL((joint_dh_reduce_kernel<true>), grid, blk, 0, (hipStream_t)stream, (const _Float16*)dh,
-                           (const _Float16*)f, (const _Float16*)g, act_lens, label_lens, df, dg, T, U1, H, inv_kappa, seed, thr);
+        hipLaunchKernelGGL((joint_dh_reduce_kernel<true>), grid, blk, 0, st, (const _Float16*)dh, (const _Float16*)f,
+                           (const _Float16*)g, act_lens, label_lens, df, (float*)scratch, B, T, U1, H, inv_kappa, seed, thr);
     else
-        hipLaunchKernelGGL((joint_dh_reduce_kernel<false>), grid, blk, 0, (hipStream_t)stream, (const _Float16*)dh,
-                           (const _Float16*)f, (const _Float16*)g, act_lens, label_lens, df, dg, T, U1, H, inv_kappa, seed, thr);
+        hipLaunchKernelGGL((joint_dh_reduce_kernel<false>), grid, blk, 0, st, (const _Float16*)dh, (const _Float16*)f,
+                           (const _Float16*)g, act_lens, label_lens, df, (float*)scratch, B, T, U1, H, inv_kappa, seed, thr);
+    IA_RETURN_IF_LAUNCH_FAILED();
+    hipLaunchKernelGGL(joint_dg_finish_kernel, dim3(grid_for((int64_t)B * U1 * H / 4)), blk, 0, st, (const float*)scratch, dg, B,
+                       ntc, U1, H, inv_kappa);
     IA_RETURN_IF_LAUNCH_FAILED();
     return IA_OK;
 }

@@ -12,6 +12,9 @@ import torch
 from .. import _lib
 
 JOINT_MAX_V = 272
+# csrc/joint_dh.hip fuses the dH GEMM with its mask and reductions; measured 2.7 ms against 1.4 + 0.4 ms for the
+# library GEMM + ia_joint_dh_reduce at bs32 x 15 s (joint backward), so the unfused path is the default.
+USE_FUSED_DH = False
 
 
 def fused_joint_supported(H, V, device):
@@ -81,13 +84,24 @@ class _FusedJointRNNT(torch.autograd.Function):
                                    _lib.stream_ptr(), ev0, ev1)
         _lib.check(st, "ia_joint_backward_g")
         G = logits  # [cells, LD] f16, = kappa * dL/dlogits
-        dH = torch.mm(G, Wp[:LD])  # [cells, H] f16 (plain library GEMM)
         df = torch.zeros(B, T, H, dtype=torch.float32, device=dev)
         dg = torch.zeros(B, U1, H, dtype=torch.float32, device=dev)
-        st = L.ia_joint_dh_reduce(_lib.ptr(dH), _lib.ptr(f16), _lib.ptr(g16), _lib.ptr(act_lens), _lib.ptr(label_lens),
-                                  _lib.ptr(df), _lib.ptr(dg), B, T, U1, H, 1.0 / kappa, p, seed, _lib.stream_ptr())
-        _lib.check(st, "ia_joint_dh_reduce")
-        del dH
+        if USE_FUSED_DH and L.ia_joint_dh_fused_supported(U1, H, LD):
+            # dH = G @ W, relu/dropout mask and both reductions in one MFMA kernel (dH never reaches memory)
+            Wt = torch.zeros(H, L.ia_joint_dh_k(), dtype=torch.float16, device=dev)
+            Wt[:, :JOINT_MAX_V] = Wp.t()
+            st = L.ia_joint_dh_fused(_lib.ptr(G), _lib.ptr(Wt), _lib.ptr(f16), _lib.ptr(g16), _lib.ptr(act_lens),
+                                     _lib.ptr(label_lens), _lib.ptr(df), _lib.ptr(dg), B, T, U1, H, LD, 1.0 / kappa, p, seed,
+                                     _lib.stream_ptr())
+            _lib.check(st, "ia_joint_dh_fused")
+        else:
+            dH = torch.mm(G, Wp[:LD])  # [cells, H] f16 (plain library GEMM)
+            scr = torch.empty(L.ia_joint_dh_reduce_scratch_bytes(B, T, U1, H), dtype=torch.uint8, device=dev)
+            st = L.ia_joint_dh_reduce(_lib.ptr(dH), _lib.ptr(f16), _lib.ptr(g16), _lib.ptr(act_lens), _lib.ptr(label_lens),
+                                      _lib.ptr(df), _lib.ptr(dg), B, T, U1, H, 1.0 / kappa, p, seed, _lib.ptr(scr),
+                                      _lib.stream_ptr())
+            _lib.check(st, "ia_joint_dh_reduce")
+            del dH
         HT = torch.empty(S, LDH, Kc, dtype=torch.float16, device=dev)
         st = L.ia_joint_hidden_t(_lib.ptr(f16), _lib.ptr(g16), _lib.ptr(HT), B, T, U1, H, LDH, S, Kc, p, seed, _lib.stream_ptr())
         _lib.check(st, "ia_joint_hidden_t")

@@ -25,7 +25,8 @@ def _reference(f, g, W, b, labels, fl, gl, blank, weights):
     return r["costs"], df, dg, dW, db, logits
 
 
-@pytest.mark.parametrize("B,T,U1,H,V", [(2, 21, 9, 64, 30), (3, 37, 19, 128, 257), (1, 16, 16, 64, 272)])
+@pytest.mark.parametrize("B,T,U1,H,V", [(2, 21, 9, 64, 30), (3, 37, 19, 128, 257), (1, 16, 16, 64, 272), (2, 50, 33, 256, 257),
+                                       (3, 19, 40, 640, 130)])
 def test_fused_joint_matches_quantised_reference(B, T, U1, H, V):
     from indic_cl_asr_amd.ops.joint import fused_joint_rnnt
     g0 = torch.Generator().manual_seed(B * 100 + T)
@@ -72,3 +73,32 @@ def test_fused_joint_dropout_mask_consistent_between_forward_and_backward():
         e = torch.zeros(V, device="cuda"); e[v] = 0.05
         fd = (fn(f, b + e).item() - fn(f, b - e).item()) / 0.1
         assert math.isclose(bb.grad[v].item(), fd, rel_tol=0.05, abs_tol=0.02), (v, bb.grad[v].item(), fd)
+
+
+@pytest.mark.parametrize("B,T,U1,H,V,p", [(3, 45, 21, 256, 257, 0.25), (2, 33, 17, 128, 100, 0.0), (4, 70, 100, 640, 257, 0.2)])
+def test_fused_hidden_gradient_kernel_matches_gemm_plus_reduce_path(B, T, U1, H, V, p):
+    """csrc/joint_dh.hip (dH GEMM + relu/dropout mask + both reductions in one kernel) against the unfused
+    library-GEMM + ia_joint_dh_reduce path on identical inputs, ragged lengths, dropout on and off."""
+    from indic_cl_asr_amd.ops import joint as J
+    g0 = torch.Generator().manual_seed(T * 7 + U1)
+    f = (torch.randn(B, T, H, generator=g0) * 0.7).cuda(); g = (torch.randn(B, U1, H, generator=g0) * 0.7).cuda()
+    W = (torch.randn(V, H, generator=g0) * 0.15).cuda(); b = (torch.randn(V, generator=g0) * 0.1).cuda()
+    labels = torch.randint(0, V - 1, (B, U1 - 1), generator=g0).cuda()
+    fl = torch.randint(max(1, T // 2), T + 1, (B,), generator=g0); fl[0] = T
+    gl = torch.randint(0, U1, (B,), generator=g0); gl[-1] = U1 - 1
+    outs = []
+    for fused in (True, False):
+        J.USE_FUSED_DH = fused
+        try:
+            fc, gc = f.clone().requires_grad_(True), g.clone().requires_grad_(True)
+            J.fused_joint_rnnt(fc, gc, W, b, labels, fl.cuda(), gl.cuda(), V - 1, dropout_p=p, seed=77).sum().backward()
+        finally:
+            J.USE_FUSED_DH = False
+        outs.append((fc.grad.clone(), gc.grad.clone()))
+    for a, r, what in ((outs[0][0], outs[1][0], "df"), (outs[0][1], outs[1][1], "dg")):
+        tol = 4e-3 * r.abs().max().item() + 1e-6      # the unfused path rounds dHidden to f16
+        assert (a - r).abs().max().item() <= tol, (what, (a - r).abs().max().item(), r.abs().max().item())
+    # frames / labels outside an utterance's lattice receive exactly zero
+    for i in range(B):
+        assert outs[0][0][i, int(fl[i]):].abs().max().item() == 0.0 if int(fl[i]) < T else True
+        assert outs[0][1][i, int(gl[i]) + 1:].abs().max().item() == 0.0 if int(gl[i]) + 1 < U1 else True
