@@ -43,6 +43,60 @@ class TranscribeConfig:  # :114-127
     _internal: Optional[InternalTranscribeConfig] = None
 
 
+_SIDE_STREAMS = {}  # one side HIP stream per device (process-wide: models stay deep-copyable)
+
+
+class StepMonitor(dict):
+    """The step's monitor dict (hybrid_rnnt_ctc_models.py:899-913 fills it with `.item()` floats).  The loss values stay
+    on the device until somebody reads them: the D2H copy is started asynchronously inside training_step and resolved on
+    first access, so the step itself contains no device->host synchronisation (the CL loops read the monitor only after
+    backward + optimizer step, R/cl_baseline_ewc.py:258-260)."""
+
+    def __init__(self, static, keys=(), device_values=None):
+        super().__init__(static)
+        self._pending = None
+        if device_values is not None and device_values.is_cuda:
+            host = torch.empty(device_values.shape, dtype=device_values.dtype, pin_memory=True)
+            host.copy_(device_values, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._pending = (tuple(keys), host, ev)
+            for k in keys:
+                super().__setitem__(k, None)
+        elif device_values is not None:
+            for k, v in zip(keys, device_values.tolist()):
+                super().__setitem__(k, v)
+
+    def _resolve(self):
+        if self._pending is not None:
+            keys, host, ev = self._pending
+            self._pending = None
+            ev.synchronize()
+            for k, v in zip(keys, host.tolist()):
+                if super().__getitem__(k) is None:
+                    super().__setitem__(k, v)
+
+    def __getitem__(self, k):
+        self._resolve()
+        return super().__getitem__(k)
+
+    def get(self, k, default=None):
+        self._resolve()
+        return super().get(k, default)
+
+    def items(self):
+        self._resolve()
+        return super().items()
+
+    def values(self):
+        self._resolve()
+        return super().values()
+
+    def __repr__(self):
+        self._resolve()
+        return super().__repr__()
+
+
 class _WerStub(nn.Module):
     """Holds `log_prediction` (the scripts set it, R/cl_baseline.py:127-128).  Batch-WER inside the step is a
     SURVEY §8(f) NEXT row (greedy decode + editdistance); until then the monitor carries NaN for it."""
@@ -74,6 +128,15 @@ class EncDecHybridRNNTCTCModel(nn.Module):
         self.seed = 1234
         self.spec_augment_enabled = True
         self.dither_enabled = True
+        self.overlap_decoder = True      # prediction network on a side HIP stream (training_step)
+
+    @staticmethod
+    def _side_stream(device):
+        key = device.index if device.index is not None else torch.cuda.current_device()
+        st = _SIDE_STREAMS.get(key)
+        if st is None:
+            st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+        return st
 
     def disable_dropout(self):
         """Deterministic numerics runs (parity tests): p=0 everywhere, module tree / parameter names unchanged."""
@@ -121,8 +184,23 @@ class EncDecHybridRNNTCTCModel(nn.Module):
         h_sig, h_tgt = host_lengths
         h_enc = [subsampled_length(mel_frame_count(int(n), self.cfg.n_fft, self.cfg.n_window_stride)) for n in h_sig]
 
+        # The prediction network only meets the encoder in the joint: its persistent LSTM kernel occupies 40 of the 256
+        # CUs, so it runs on a side stream under the encoder (autograd replays its backward on that stream as well, under
+        # the encoder blocks' backward).
+        side = self._side_stream(signal.device) if self.overlap_decoder and signal.is_cuda else None
+        if side is not None:
+            main = torch.cuda.current_stream(signal.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                decoder, target_length, states = self.decoder(targets=transcript, target_length=transcript_len)
+            for t in (transcript, transcript_len):
+                t.record_stream(side)
         encoded, encoded_len = self.forward(input_signal=signal, input_signal_length=signal_len)
-        decoder, target_length, states = self.decoder(targets=transcript, target_length=transcript_len)
+        if side is not None:
+            main.wait_stream(side)
+            decoder.record_stream(main)
+        else:
+            decoder, target_length, states = self.decoder(targets=transcript, target_length=transcript_len)
         self.joint.loss_scale_hint = (1.0 - self.ctc_loss_weight) / max(1, signal.shape[0])
         self.joint.dropout_seed = (self.seed * 2654435761 + self._step * 40503) & 0x7FFFFFFF
         loss_value, wer, _, _ = self.joint(encoder_outputs=encoded, decoder_outputs=decoder, encoder_lengths=encoded_len,
@@ -133,9 +211,9 @@ class EncDecHybridRNNTCTCModel(nn.Module):
                                  target_lengths=transcript_len)
         rnnt_only = loss_value
         loss_value = (1 - self.ctc_loss_weight) * loss_value + self.ctc_loss_weight * ctc_loss
-        vals = torch.stack([rnnt_only.detach().float(), ctc_loss.detach().float(), loss_value.detach().float()]).tolist()
-        monitor = {'training_batch_wer': torch.tensor(float('nan')), 'train_rnnt_loss': vals[0],
-                   'train_ctc_loss': vals[1], 'training_batch_wer_ctc': float('nan'), 'train_loss': vals[2]}
+        vals = torch.stack([rnnt_only.detach().float(), ctc_loss.detach().float(), loss_value.detach().float()])
+        monitor = StepMonitor({'training_batch_wer': torch.tensor(float('nan')), 'training_batch_wer_ctc': float('nan')},
+                              ('train_rnnt_loss', 'train_ctc_loss', 'train_loss'), vals)
         self._step += 1
         if return_probs:
             return loss_value, monitor, log_probs
