@@ -217,7 +217,15 @@ int ia_relpos_attention(const void* qkv, const void* pos_proj, const float* bias
 int ia_relpos_attention_bwd_dims(int T, int* Ts, int* Rs, int* pad0);
 int ia_relpos_attention_bwd(const void* qkv, const void* pos_proj, const float* bias_u, const float* bias_v,
                             const int64_t* lens, const void* ctx, const void* dctx, int B, int T, int H, int dk,
-                            float dropout_p, unsigned seed, void* Pd, void* dS, void* dBand, ia_stream_t stream);
+                            float dropout_p, unsigned seed, void* Pd, void* dS, void* dBand, void* Qu, void* Qv, void* K,
+                            void* dO, ia_stream_t stream);
+/* The row pass also writes the head-major bf16 operands of those GEMMs: Qu = q+u, K, dO as [B,H,T,dk], Qv = q+v as
+ * [H,B,T,dk].  ia_attn_bwd_unpack folds their outputs back: dqkv [B*T, 3*H*dk] bf16 = (dQu + dQv | dK | dV) and
+ * dbias_u / dbias_v [H*dk] f32 = column sums of dQu / dQv (block partial rows in `scratch`, f32 x
+ * ia_attn_bwd_unpack_scratch_elems).  dQu, dK, dV are [B,H,T,dk], dQv is [H,B,T,dk] (bf16).  H*dk <= 2048. */
+int ia_attn_bwd_unpack(const void* dQu, const void* dQv, const void* dK, const void* dV, void* dqkv, float* dbias_u,
+                       float* dbias_v, int B, int T, int H, int dk, float* scratch, ia_stream_t stream);
+int64_t ia_attn_bwd_unpack_scratch_elems(int B, int T, int H);
 
 /* ------------------------------------------------------------------------------------------------
  * Persistent single-layer LSTM: the recurrence of the RNNT prediction network (RNNTDecoder.predict
@@ -292,7 +300,8 @@ int ia_ctc_backward(const float* log_probs, const int64_t* targets, const int64_
  *   ia_silu_dropout_bwd   out = dh * keep*scale * SiLU'(h_pre)
  *   ia_scale_dropout_bf16 out = bf16(alpha * keep*scale * dy)   -- gradient entering a residual branch
  *   ia_bn_silu_bwd        SiLU' and train-mode BatchNorm backward from the forward's per-channel sums: S1 = dbeta,
- *                         S2 = dgamma (caller zeroes both), dz [n_rows,d] f32
+ *                         S2 = dgamma (both written: block partial rows in `scratch`, f32 x ia_bn_silu_bwd_scratch_elems),
+ *                         dz [n_rows,d] f32
  *   ia_glu_mask / ia_glu_bwd   G = mask(GLU(c2)) f32;  dc2 bf16 [rows,2d] from dG
  *   ia_attn_keepmask      attention-dropout keep mask of ia_relpos_attention as a bf16 [B,H,T,T] tensor (0 or 1/(1-p))
  */
@@ -306,7 +315,9 @@ int ia_silu_dropout_bwd(const void* h_pre, const void* dh, int64_t M, int N, flo
 int ia_scale_dropout_bf16(const float* dy, int64_t M, int N, float alpha, float dropout_p, unsigned seed, void* out,
                           ia_stream_t stream);
 int ia_bn_silu_bwd(const float* z, const void* dc3, int64_t n_rows, int d, const float* bn_sum, const float* bn_sumsq,
-                   const float* gamma, const float* beta, float eps, float* S1, float* S2, float* dz, ia_stream_t stream);
+                   const float* gamma, const float* beta, float eps, float* S1, float* S2, float* dz, float* scratch,
+                   ia_stream_t stream);
+int64_t ia_bn_silu_bwd_scratch_elems(int64_t n_rows, int d);
 int ia_glu_mask(const void* c2, const int64_t* lens, int B, int T, int d, float* G, ia_stream_t stream);
 int ia_glu_bwd(const void* c2, const float* dG, const int64_t* lens, int B, int T, int d, void* dc2, ia_stream_t stream);
 int ia_attn_keepmask(int B, int H, int T, float dropout_p, unsigned seed, void* mask_bf16, ia_stream_t stream);

@@ -50,7 +50,10 @@ SIGNATURES = {
     "ia_attn_vt_elems": (_sz, [_i, _i, _i]),
     "ia_relpos_attention": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _c.c_uint, _vp, _vp, _vp]),
     "ia_relpos_attention_bwd_dims": (_i, [_i, _vp, _vp, _vp]),
-    "ia_relpos_attention_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _c.c_uint, _vp, _vp, _vp, _vp]),
+    "ia_relpos_attention_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _c.c_uint, _vp, _vp, _vp, _vp, _vp,
+                                     _vp, _vp, _vp]),
+    "ia_attn_bwd_unpack": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "ia_attn_bwd_unpack_scratch_elems": (_i64, [_i, _i, _i]),
     "ia_lstm_scratch_bytes": (_sz, [_i, _i]),
     "ia_lstm_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "ia_lstm_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
@@ -67,7 +70,8 @@ SIGNATURES = {
     "ia_silu_dropout": (_i, [_vp, _i64, _i, _f, _c.c_uint, _vp, _vp]),
     "ia_silu_dropout_bwd": (_i, [_vp, _vp, _i64, _i, _f, _c.c_uint, _vp, _vp]),
     "ia_scale_dropout_bf16": (_i, [_vp, _i64, _i, _f, _f, _c.c_uint, _vp, _vp]),
-    "ia_bn_silu_bwd": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
+    "ia_bn_silu_bwd": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
+    "ia_bn_silu_bwd_scratch_elems": (_i64, [_i64, _i]),
     "ia_glu_mask": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "ia_glu_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "ia_attn_keepmask": (_i, [_i, _i, _i, _f, _c.c_uint, _vp, _vp]),

@@ -13,6 +13,7 @@
 #include <hip/hip_bf16.h>
 
 #include "ia_common.h"
+#include "partials.h"
 
 namespace {
 
@@ -235,6 +236,7 @@ __global__ __launch_bounds__(AT_THREADS, 1) void relpos_attn_bwd_kernel(
     const __bf16* __restrict__ qkv, const __bf16* __restrict__ pl, const float* __restrict__ bias_u,
     const float* __restrict__ bias_v, const int64_t* __restrict__ lens, const __bf16* __restrict__ ctx,
     const __bf16* __restrict__ dctx, __bf16* __restrict__ Pd_out, __bf16* __restrict__ dS_out, __bf16* __restrict__ dBand_out,
+    __bf16* __restrict__ Qu_out, __bf16* __restrict__ Qv_out, __bf16* __restrict__ K_out, __bf16* __restrict__ dO_out,
     int B, int T, int H, int Ts, int Rs, int pad0, float scale, unsigned seed, unsigned thr, float keep_scale) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -266,6 +268,13 @@ __global__ __launch_bounds__(AT_THREADS, 1) void relpos_attn_bwd_kernel(
         const bf8 oa = *reinterpret_cast<const bf8*>(ctx + off);
 #pragma unroll
         for (int j = 0; j < 8; ++j) dpart += (float)dOa[ks][j] * (float)oa[j];
+        if (iw + c < T) {  // head-major copies of this wave's rows: the GEMM operands of the remaining contractions
+            const size_t ro = ((size_t)(b * H + h) * T + iw + c) * AT_DK + ks * 32 + q4 * 8;
+            *reinterpret_cast<bf8*>(Qu_out + ro) = Qu[ks];
+            *reinterpret_cast<bf8*>(dO_out + ro) = dOa[ks];
+            *reinterpret_cast<bf8*>(K_out + ro) = *reinterpret_cast<const bf8*>(qrow + d + ks * 32 + q4 * 8);
+            *reinterpret_cast<bf8*>(Qv_out + ((size_t)(h * B + b) * T + iw + c) * AT_DK + ks * 32 + q4 * 8) = Qv[ks];
+        }
     }
     sD[q4 * 16 + c] = dpart;
     const int r_lo = T - 1 - (iw + 15);
@@ -448,6 +457,53 @@ __global__ __launch_bounds__(AT_THREADS, 1) void relpos_attn_bwd_kernel(
     }
 }
 
+
+// dqkv[b*T+t][0:d | d:2d | 2d:3d] = (dQu + dQv | dK | dV) from the head-major GEMM outputs; block partial column sums of dQu
+// and dQv (= gradients of pos_bias_u / pos_bias_v) into part[block][2d] for partials.h.  Thread = 8 head-dim elements.
+__global__ __launch_bounds__(256) void attn_bwd_unpack_kernel(const __bf16* __restrict__ dQu, const __bf16* __restrict__ dQv,
+                                                              const __bf16* __restrict__ dK, const __bf16* __restrict__ dV,
+                                                              __bf16* __restrict__ dqkv, float* __restrict__ part, int B, int T,
+                                                              int H, int rows_per_block) {
+    const int d = H * AT_DK, cg = d / 8;        // column groups of 8 (cg divides 256)
+    const int col8 = threadIdx.x % cg, rl = threadIdx.x / cg, nrl = 256 / cg;  // nrl row lanes of cg threads
+    const int h = (col8 * 8) / AT_DK, k0 = (col8 * 8) % AT_DK;
+    const int64_t N = (int64_t)B * T;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < N ? r0 + rows_per_block : N;
+    float su[8], sv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) su[j] = sv[j] = 0.f;
+    for (int64_t r = r0 + rl; r < r1 && rl < nrl; r += nrl) {  // (256 % cg) trailing threads idle
+        const int b = (int)(r / T), t = (int)(r - (int64_t)b * T);
+        const size_t bh = ((size_t)(b * H + h) * T + t) * AT_DK + k0;
+        const size_t hb = ((size_t)(h * B + b) * T + t) * AT_DK + k0;
+        const bf8 qu = *reinterpret_cast<const bf8*>(dQu + bh), qv = *reinterpret_cast<const bf8*>(dQv + hb);
+        bf8 q;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float a = (float)qu[j], c = (float)qv[j];
+            su[j] += a; sv[j] += c;
+            q[j] = (__bf16)(a + c);
+        }
+        __bf16* o = dqkv + (size_t)r * (3 * d) + col8 * 8;
+        *reinterpret_cast<bf8*>(o) = q;
+        *reinterpret_cast<bf8*>(o + d) = *reinterpret_cast<const bf8*>(dK + bh);
+        *reinterpret_cast<bf8*>(o + 2 * d) = *reinterpret_cast<const bf8*>(dV + bh);
+    }
+    __shared__ float red[2][256][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[0][threadIdx.x][j] = su[j]; red[1][threadIdx.x][j] = sv[j]; }
+    __syncthreads();
+    if (rl == 0) {
+        for (int k = 1; k < nrl; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { su[j] += red[0][threadIdx.x + k * cg][j]; sv[j] += red[1][threadIdx.x + k * cg][j]; }
+        float* row = part + (size_t)blockIdx.x * 2 * d + col8 * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { row[j] = su[j]; row[d + j] = sv[j]; }
+    }
+}
+
 }  // namespace
 
 extern "C" size_t ia_attn_vt_elems(int B, int T, int H) {
@@ -493,13 +549,16 @@ extern "C" int ia_relpos_attention_bwd_dims(int T, int* Ts, int* Rs, int* pad0) 
 
 extern "C" int ia_relpos_attention_bwd(const void* qkv, const void* pos_proj, const float* bias_u, const float* bias_v,
                                        const int64_t* lens, const void* ctx, const void* dctx, int B, int T, int H, int dk,
-                                       float dropout_p, unsigned seed, void* Pd, void* dS, void* dBand, ia_stream_t stream) {
-    if (!qkv || !pos_proj || !bias_u || !bias_v || !lens || !ctx || !dctx || !Pd || !dS || !dBand || B <= 0 || T <= 0 || H <= 0)
+                                       float dropout_p, unsigned seed, void* Pd, void* dS, void* dBand, void* Qu, void* Qv,
+                                       void* K, void* dO, ia_stream_t stream) {
+    if (!qkv || !pos_proj || !bias_u || !bias_v || !lens || !ctx || !dctx || !Pd || !dS || !dBand || !Qu || !Qv || !K || !dO ||
+        B <= 0 || T <= 0 || H <= 0)
         return IA_INVALID_VALUE;
     if (dk != AT_DK || T > AT_NT * 16) return IA_UNSUPPORTED;
     if (dropout_p < 0.f || dropout_p >= 1.f) return IA_INVALID_VALUE;
     if (!ia_is_aligned(qkv, 16) || !ia_is_aligned(pos_proj, 16) || !ia_is_aligned(ctx, 16) || !ia_is_aligned(dctx, 16) ||
-        !ia_is_aligned(Pd, 16) || !ia_is_aligned(dS, 16) || !ia_is_aligned(dBand, 16))
+        !ia_is_aligned(Pd, 16) || !ia_is_aligned(dS, 16) || !ia_is_aligned(dBand, 16) || !ia_is_aligned(Qu, 16) ||
+        !ia_is_aligned(Qv, 16) || !ia_is_aligned(K, 16) || !ia_is_aligned(dO, 16))
         return IA_INVALID_VALUE;
     int Ts, Rs, pad0;
     ia_relpos_attention_bwd_dims(T, &Ts, &Rs, &pad0);
@@ -511,7 +570,38 @@ extern "C" int ia_relpos_attention_bwd(const void* qkv, const void* pos_proj, co
     const int nqt = (T + 63) / 64;
     hipLaunchKernelGGL(relpos_attn_bwd_kernel, dim3(B * H * nqt), dim3(AT_THREADS), lds, (hipStream_t)stream, (const __bf16*)qkv,
                        (const __bf16*)pos_proj, bias_u, bias_v, lens, (const __bf16*)ctx, (const __bf16*)dctx, (__bf16*)Pd,
-                       (__bf16*)dS, (__bf16*)dBand, B, T, H, Ts, Rs, pad0, 1.0f / sqrtf((float)dk), seed, thr, keep_scale);
+                       (__bf16*)dS, (__bf16*)dBand, (__bf16*)Qu, (__bf16*)Qv, (__bf16*)K, (__bf16*)dO, B, T, H, Ts, Rs, pad0,
+                       1.0f / sqrtf((float)dk), seed, thr, keep_scale);
+    IA_RETURN_IF_LAUNCH_FAILED();
+    return IA_OK;
+}
+
+namespace {
+inline int unpack_rows_per_block(int64_t N) {
+    int64_t rpb = (N + 1023) / 1024;
+    return (int)(rpb < 32 ? 32 : rpb);
+}
+}  // namespace
+
+extern "C" int64_t ia_attn_bwd_unpack_scratch_elems(int B, int T, int H) {
+    if (B <= 0 || T <= 0 || H <= 0) return 0;
+    const int64_t N = (int64_t)B * T;
+    const int rpb = unpack_rows_per_block(N);
+    return ((N + rpb - 1) / rpb) * 2 * (int64_t)H * AT_DK;
+}
+
+extern "C" int ia_attn_bwd_unpack(const void* dQu, const void* dQv, const void* dK, const void* dV, void* dqkv, float* dbias_u,
+                                  float* dbias_v, int B, int T, int H, int dk, float* scratch, ia_stream_t stream) {
+    if (!dQu || !dQv || !dK || !dV || !dqkv || !dbias_u || !dbias_v || !scratch || B <= 0 || T <= 0 || H <= 0) return IA_INVALID_VALUE;
+    if (dk != AT_DK || H * AT_DK / 8 > 256) return IA_UNSUPPORTED;
+    const int64_t N = (int64_t)B * T;
+    const int rpb = unpack_rows_per_block(N);
+    const int G = (int)((N + rpb - 1) / rpb);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(attn_bwd_unpack_kernel, dim3(G), dim3(256), 0, st, (const __bf16*)dQu, (const __bf16*)dQv, (const __bf16*)dK,
+                       (const __bf16*)dV, (__bf16*)dqkv, scratch, B, T, H, rpb);
+    IA_RETURN_IF_LAUNCH_FAILED();
+    ia_partials_finish(scratch, G, 2 * H * AT_DK, H * AT_DK, dbias_u, dbias_v, st);
     IA_RETURN_IF_LAUNCH_FAILED();
     return IA_OK;
 }

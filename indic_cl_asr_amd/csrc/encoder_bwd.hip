@@ -163,12 +163,13 @@ __global__ __launch_bounds__(256) void scale_dropout_bf16_kernel(const float* __
 }
 
 // ------------------------------------------------------------------------------------------------ SiLU + BatchNorm backward
-// pass 1: S1[c] += sum dyb, S2[c] += sum dyb * xhat,   dyb = dc3 * silu'(xhat*gamma+beta)
+// pass 1: partial rows part[block][0:d] = sum dyb, part[block][d:2d] = sum dyb * xhat over the block's rows,
+//         dyb = dc3 * silu'(xhat*gamma+beta); summed into S1|S2 by partials.h
 __global__ __launch_bounds__(256) void bn_silu_bwd_reduce_kernel(const float* __restrict__ z, const __bf16* __restrict__ dc3,
                                                                  int64_t n_rows, int d, const float* __restrict__ bn_sum,
                                                                  const float* __restrict__ bn_sumsq, const float* __restrict__ gamma,
-                                                                 const float* __restrict__ beta, float eps, float* __restrict__ S1,
-                                                                 float* __restrict__ S2, int rows_per_block) {
+                                                                 const float* __restrict__ beta, float eps,
+                                                                 float* __restrict__ part, int rows_per_block) {
     // thread = 4 channels x one of (256/(d/4)) row lanes; d % 4 == 0, (d/4) divides 256
     const int cg = d / 4, c0 = (threadIdx.x % cg) * 4, rl = threadIdx.x / cg, nrl = 256 / cg;
     const float inv_n = 1.f / (float)n_rows;
@@ -193,8 +194,18 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_reduce_kernel(const float* __
             a1[j] += dyb; a2[j] += dyb * xh;
         }
     }
+    __shared__ float red[2][256][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { atomicAdd(S1 + c0 + j, a1[j]); atomicAdd(S2 + c0 + j, a2[j]); }
+    for (int j = 0; j < 4; ++j) { red[0][threadIdx.x][j] = a1[j]; red[1][threadIdx.x][j] = a2[j]; }
+    __syncthreads();
+    if (rl == 0) {
+        for (int k = 1; k < nrl; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a1[j] += red[0][threadIdx.x + k * cg][j]; a2[j] += red[1][threadIdx.x + k * cg][j]; }
+        float* row = part + (size_t)blockIdx.x * 2 * d;
+        *reinterpret_cast<float4*>(row + c0) = make_float4(a1[0], a1[1], a1[2], a1[3]);
+        *reinterpret_cast<float4*>(row + d + c0) = make_float4(a2[0], a2[1], a2[2], a2[3]);
+    }
 }
 // pass 2: dz = gamma*rstd*(dyb - S1/n - xhat*S2/n)
 __global__ __launch_bounds__(256) void bn_silu_bwd_apply_kernel(const float* __restrict__ z, const __bf16* __restrict__ dc3,
@@ -328,15 +339,32 @@ extern "C" int ia_scale_dropout_bf16(const float* dy, int64_t M, int N, float al
     return IA_OK;
 }
 
+namespace {
+inline int bnb_rows_per_block(int64_t n_rows) {
+    int64_t rpb = (n_rows + 1023) / 1024;
+    return (int)(rpb < 32 ? 32 : rpb);
+}
+}  // namespace
+
+extern "C" int64_t ia_bn_silu_bwd_scratch_elems(int64_t n_rows, int d) {
+    if (n_rows <= 0 || d <= 0) return 0;
+    const int rpb = bnb_rows_per_block(n_rows);
+    return ((n_rows + rpb - 1) / rpb) * 2 * (int64_t)d;
+}
+
 extern "C" int ia_bn_silu_bwd(const float* z, const void* dc3, int64_t n_rows, int d, const float* bn_sum, const float* bn_sumsq,
                               const float* gamma, const float* beta, float eps, float* S1, float* S2, float* dz,
-                              ia_stream_t stream) {
-    if (!z || !dc3 || !bn_sum || !bn_sumsq || !gamma || !beta || !S1 || !S2 || !dz || n_rows <= 1 || d <= 0) return IA_INVALID_VALUE;
+                              float* scratch, ia_stream_t stream) {
+    if (!z || !dc3 || !bn_sum || !bn_sumsq || !gamma || !beta || !S1 || !S2 || !dz || !scratch || n_rows <= 1 || d <= 0)
+        return IA_INVALID_VALUE;
     if (d % 4 != 0 || 256 % (d / 4) != 0) return IA_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    const int rpb = 128;
-    hipLaunchKernelGGL(bn_silu_bwd_reduce_kernel, dim3((unsigned)((n_rows + rpb - 1) / rpb)), dim3(256), 0, st, z,
-                       (const __bf16*)dc3, n_rows, d, bn_sum, bn_sumsq, gamma, beta, eps, S1, S2, rpb);
+    const int rpb = bnb_rows_per_block(n_rows);
+    const int G = (int)((n_rows + rpb - 1) / rpb);
+    hipLaunchKernelGGL(bn_silu_bwd_reduce_kernel, dim3((unsigned)G), dim3(256), 0, st, z, (const __bf16*)dc3, n_rows, d, bn_sum,
+                       bn_sumsq, gamma, beta, eps, scratch, rpb);
+    IA_RETURN_IF_LAUNCH_FAILED();
+    ia_partials_finish(scratch, G, 2 * d, d, S1, S2, st);
     IA_RETURN_IF_LAUNCH_FAILED();
     hipLaunchKernelGGL(bn_silu_bwd_apply_kernel, dim3(ew_grid(n_rows * d / 4)), dim3(256), 0, st, z, (const __bf16*)dc3, n_rows, d,
                        bn_sum, bn_sumsq, gamma, beta, eps, S1, S2, dz);

@@ -176,10 +176,11 @@ class _ConformerBlockFn(torch.autograd.Function):
         dc3, dWp2, G["conv.pointwise_conv2.bias"] = _lin_bwd(dB, S["c3"], W["wp2"])
         G["conv.pointwise_conv2.weight"] = dWp2.unsqueeze(-1)
         bn = cv.batch_norm
-        S12 = torch.zeros(2, d, dtype=torch.float32, device=dev)
+        S12 = torch.empty(2, d, dtype=torch.float32, device=dev)
         dz = torch.empty(N, d, dtype=torch.float32, device=dev)
         _lib.check(L.ia_bn_silu_bwd(_ptr(S["z"]), _ptr(dc3), N, d, _ptr(S["sums"][0]), _ptr(S["sums"][1]), _ptr(bn.weight),
-                                    _ptr(bn.bias), float(bn.eps), _ptr(S12[0]), _ptr(S12[1]), _ptr(dz), _lib.stream_ptr()),
+                                    _ptr(bn.bias), float(bn.eps), _ptr(S12[0]), _ptr(S12[1]), _ptr(dz),
+                                    _ptr(fast.scratch(dev, L.ia_bn_silu_bwd_scratch_elems(N, d))), _lib.stream_ptr()),
                    "ia_bn_silu_bwd")
         G["conv.batch_norm.bias"], G["conv.batch_norm.weight"] = S12[0], S12[1]
         ksz = cv.depthwise_conv.weight.shape[-1]

@@ -153,17 +153,14 @@ def relpos_attention_bwd(qkv, pl, bias_u, bias_v, lens, ctx, dctx, B, T, H, dk, 
     Pd = torch.empty(B, H, T, Ts, dtype=bf, device=dev)
     dS = torch.empty(B, H, T, Ts, dtype=bf, device=dev)
     dBand = torch.empty(H, B * T, Rs, dtype=bf, device=dev)
+    Qu, K, dO = (torch.empty(B, H, T, dk, dtype=bf, device=dev) for _ in range(3))
+    Qv = torch.empty(H, B * T, dk, dtype=bf, device=dev)
     dctx = dctx.contiguous()
     st = L.ia_relpos_attention_bwd(_lib.ptr(qkv), _lib.ptr(pl), _lib.ptr(bias_u), _lib.ptr(bias_v), _lib.ptr(lens), _lib.ptr(ctx),
                                    _lib.ptr(dctx), B, T, H, dk, float(dropout_p), int(seed) & 0xFFFFFFFF, _lib.ptr(Pd),
-                                   _lib.ptr(dS), _lib.ptr(dBand), _lib.stream_ptr())
+                                   _lib.ptr(dS), _lib.ptr(dBand), _lib.ptr(Qu), _lib.ptr(Qv), _lib.ptr(K), _lib.ptr(dO),
+                                   _lib.stream_ptr())
     _lib.check(st, "ia_relpos_attention_bwd")
-    q5 = qkv.view(B, T, 3, H, dk)
-    qf = q5[:, :, 0].float()
-    Qu = (qf + bias_u.detach().view(1, 1, H, dk)).to(bf).permute(0, 2, 1, 3).contiguous()      # [B,H,T,dk]
-    Qv = (qf + bias_v.detach().view(1, 1, H, dk)).to(bf).permute(2, 0, 1, 3).reshape(H, B * T, dk)  # [H,B*T,dk]
-    K = q5[:, :, 1].permute(0, 2, 1, 3).contiguous()
-    dO = dctx.view(B, T, H, dk).permute(0, 2, 1, 3).contiguous()
     Pv, dSv = (Pd, dS) if Ts == T else (Pd[..., :T], dS[..., :T])
     dV = torch.matmul(Pv.transpose(-1, -2), dO)                                                # [B,H,T,dk]
     dK = torch.matmul(dSv.transpose(-1, -2), Qu)
@@ -173,16 +170,15 @@ def relpos_attention_bwd(qkv, pl, bias_u, bias_v, lens, ctx, dctx, B, T, H, dk, 
     posB[:, pad0:pad0 + R] = pl[:R].view(R, H, dk).permute(1, 0, 2)
     dQv = torch.bmm(dBand, posB)                                                               # [H,B*T,dk]
     dposB = torch.bmm(dBand.transpose(1, 2), Qv)                                               # [H,Rs,dk]
-    du = dQu.float().sum((0, 2))
-    dvb = dQv.float().sum(1)
     dqkv = torch.empty(B * T, 3 * d, dtype=bf, device=dev)
-    d5 = dqkv.view(B, T, 3, H, dk)
-    d5[:, :, 0] = dQu.permute(0, 2, 1, 3) + dQv.view(H, B, T, dk).permute(1, 2, 0, 3)
-    d5[:, :, 1] = dK.permute(0, 2, 1, 3)
-    d5[:, :, 2] = dV.permute(0, 2, 1, 3)
+    dub = torch.empty(2, H, dk, dtype=torch.float32, device=dev)
+    st = L.ia_attn_bwd_unpack(_lib.ptr(dQu), _lib.ptr(dQv), _lib.ptr(dK), _lib.ptr(dV), _lib.ptr(dqkv), _lib.ptr(dub[0]),
+                              _lib.ptr(dub[1]), B, T, H, dk, _lib.ptr(scratch(dev, L.ia_attn_bwd_unpack_scratch_elems(B, T, H))),
+                              _lib.stream_ptr())
+    _lib.check(st, "ia_attn_bwd_unpack")
     dpl = torch.zeros_like(pl)
     dpl[:R] = dposB[:, pad0:pad0 + R].permute(1, 0, 2).reshape(R, d)
-    return dqkv, dpl, du, dvb
+    return dqkv, dpl, dub[0], dub[1]
 
 
 def colsum(x_bf16):
