@@ -278,13 +278,15 @@ class FusedAdamW:
     exists -- the reference wraps the model in DDP but never arms its reducer."""
 
     def __init__(self, model_or_flat, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, group=None,
-                 bf16_shadow=False):
+                 bf16_shadow=None):
         self.flat = model_or_flat if isinstance(model_or_flat, FlatParams) else flat_of(model_or_flat)
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.exp_avg = torch.zeros_like(self.flat.theta)
         self.exp_avg_sq = torch.zeros_like(self.flat.theta)
         self.step_count = 0
         self.group = group
+        if bf16_shadow is None:  # the HIP GEMM paths consume bf16 weights: let the optimizer kernel emit them (one launch)
+            bf16_shadow = self.flat.theta.is_cuda
         self.shadow = torch.zeros(self.flat.numel, dtype=torch.bfloat16, device=self.flat.theta.device) if bf16_shadow else None
         self.param_groups = [dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, params=self.flat.params)]
 
@@ -310,3 +312,7 @@ class FusedAdamW:
         _lib.check(st, "ia_adamw_step")
         from .ops import fast
         fast.bump_weight_epoch()  # the kernel rewrote theta by raw pointer: bf16 weight shadows are stale now
+        if self.shadow is not None:  # ... and were re-made by the same kernel: hand the views to the shadow cache
+            for (n, o, k, shape), q in zip(self.flat.entries, self.flat.params):
+                if q.dim() >= 2:
+                    fast.register_flat_shadow(q, self.shadow[o:o + k].view(shape[0], -1))

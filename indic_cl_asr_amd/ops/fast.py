@@ -16,6 +16,20 @@ def bump_weight_epoch():
 
 
 
+_FLAT16 = {}  # id(param) -> (weight epoch, param version, data_ptr, bf16 view written by the fused optimizer kernel)
+
+
+def register_flat_shadow(p, view16):
+    _FLAT16[id(p)] = (WEIGHT_EPOCH, p._version, p.data_ptr(), view16)
+
+
+def _flat_shadow(p):
+    hit = _FLAT16.get(id(p))
+    if hit is not None and hit[0] == WEIGHT_EPOCH and hit[1] == p._version and hit[2] == p.data_ptr():
+        return hit[3]
+    return None
+
+
 def bf16_shadow(*params):
     """bf16 copy of a parameter (or of several concatenated along dim 0), re-made only when a source version changes.
     Frozen layers therefore pay the fp32->bf16 cast once, not once per step as autocast does."""
@@ -26,9 +40,13 @@ def bf16_shadow(*params):
     if hit is not None and hit[0] == ver:
         return hit[1]
     with torch.no_grad():
-        w = torch.cat([p.detach().reshape(p.shape[0], -1) for p in params], 0) if len(params) > 1 \
-            else params[0].detach().reshape(params[0].shape[0], -1)
-        w = w.to(torch.bfloat16).contiguous()
+        flat16 = [_flat_shadow(p) for p in params]
+        if all(v is not None for v in flat16):  # emitted by ia_adamw_step: no cast kernels at all (one cat for q|k|v)
+            w = flat16[0] if len(params) == 1 else torch.cat(flat16, 0)
+        else:
+            w = torch.cat([p.detach().reshape(p.shape[0], -1) for p in params], 0) if len(params) > 1 \
+                else params[0].detach().reshape(params[0].shape[0], -1)
+            w = w.to(torch.bfloat16).contiguous()
     _SHADOW[key] = (ver, w)
     return w
 
