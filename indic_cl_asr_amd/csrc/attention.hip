@@ -25,10 +25,20 @@ constexpr int AT_NT = 24;            // key tiles of 16: T <= 384
 constexpr int AT_NR = AT_NT + 1;     // band tiles
 constexpr int AT_LDR = AT_NR * 16 + 4;  // fp32 row stride of the band scratch
 constexpr int AT_THREADS = 256;
+constexpr int AT_LDB = AT_NR * 16 + 8;   // bf16 row stride of the forward's band scratch (816 B: conflict-free rows)
+constexpr int AT_LDPN = AT_NT * 16 + 8;  // bf16 row stride of the forward's probability scratch (784 B)
+constexpr int AT_WAVE_LDS = 16 * AT_LDB * 2 + 64;  // bytes per wave: band | probabilities, then 16 row sums
 
 __device__ __forceinline__ unsigned at_hash32(unsigned x) {
     x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
     return x;
+}
+
+// Attention-dropout randomness: ONE hash per (head, group of 4 query rows, key) yields the 4 rows' keep bytes (row i uses
+// byte i & 3; keep iff byte >= round(256 p)).  i0 is a multiple of 4.  Shared by forward, backward and ia_attn_keepmask.
+__device__ __forceinline__ unsigned at_keep_rand4(unsigned seed, int bh, int T, int i0, int j) {
+    const unsigned idx = ((unsigned)bh * (unsigned)((T + 3) >> 2) + (unsigned)(i0 >> 2)) * (unsigned)T + (unsigned)j;
+    return at_hash32(idx * 0x9E3779B1u + seed);
 }
 
 __device__ __forceinline__ bf8 add_bias_bf8(const bf8 q, const float* __restrict__ bias) {
@@ -62,7 +72,7 @@ __global__ __launch_bounds__(256) void attn_vt_kernel(const __bf16* __restrict__
     }
 }
 
-__global__ __launch_bounds__(AT_THREADS, 1) void relpos_attn_kernel(
+__global__ __launch_bounds__(AT_THREADS, 2) void relpos_attn_kernel(
     const __bf16* __restrict__ qkv, const __bf16* __restrict__ pl, const __bf16* __restrict__ vt,
     const float* __restrict__ bias_u, const float* __restrict__ bias_v, const int64_t* __restrict__ lens,
     __bf16* __restrict__ ctx, int B, int T, int H, int Tp, float scale, unsigned seed, unsigned thr, float keep_scale) {
@@ -77,8 +87,10 @@ __global__ __launch_bounds__(AT_THREADS, 1) void relpos_attn_kernel(
     const int b = bid / H;
     const int len = (int)lens[b];
     const int iw = qt * 64 + wave * 16;  // first query of this wave
-    float* sR = reinterpret_cast<float*>(smem) + (size_t)wave * (16 * AT_LDR + 16);
-    float* sSum = sR + 16 * AT_LDR;
+    // wave-private scratch: the bf16 band [16][AT_LDB] (the reference's autocast holds matrix_bd in 16 bits as well), later
+    // reused for the bf16 probabilities [16][AT_LDPN]; 13 KB per wave = two workgroups per CU
+    __bf16* sRb = reinterpret_cast<__bf16*>(smem + (size_t)wave * AT_WAVE_LDS);
+    float* sSum = reinterpret_cast<float*>(smem + (size_t)wave * AT_WAVE_LDS + 16 * AT_LDB * 2);
     if (iw >= T) return;  // wave-uniform; no block-level barrier is used below
     const int nt = (T + 15) / 16;       // key tiles actually needed
     const int nr = nt + 1;
@@ -115,7 +127,7 @@ __global__ __launch_bounds__(AT_THREADS, 1) void relpos_attn_kernel(
         for (int rt = 0; rt < AT_NR; ++rt)
             if (rt < nr)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) sR[(q4 * 4 + r) * AT_LDR + rt * 16 + c] = R[rt][r];
+                for (int r = 0; r < 4; ++r) sRb[(q4 * 4 + r) * AT_LDB + rt * 16 + c] = (__bf16)R[rt][r];
     }
     // ---- S = (q+u) k^T
     f4 S[AT_NT];
@@ -144,7 +156,7 @@ __global__ __launch_bounds__(AT_THREADS, 1) void relpos_attn_kernel(
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int il = q4 * 4 + r;
-                const float bd = sR[il * AT_LDR + j + 15 - il];
+                const float bd = (float)sRb[il * AT_LDB + j + 15 - il];
                 const float s = (j < len) ? (S[jt][r] + bd) * scale : IA_NEG_INF;
                 S[jt][r] = s;
                 m[r] = fmaxf(m[r], s);
@@ -158,23 +170,20 @@ __global__ __launch_bounds__(AT_THREADS, 1) void relpos_attn_kernel(
         m[r] = fmaxf(m[r], IA_DPP_F(m[r], m[r], 0x140, 0xF));
     }
     float sum[4] = {0.f, 0.f, 0.f, 0.f};
-    __bf16* sP = reinterpret_cast<__bf16*>(sR);  // reuse: [16][2*AT_LDR] bf16 (row stride 2*AT_LDR elements)
-    constexpr int LDP = 2 * AT_LDR;
+    __bf16* sP = sRb;  // reuse as [16][AT_LDPN]
+    constexpr int LDP = AT_LDPN;
     __builtin_amdgcn_s_waitcnt(0xC07F);  // all band reads returned before the scratch is overwritten
 #pragma unroll
     for (int jt = 0; jt < AT_NT; ++jt) {
         const int j = jt * 16 + c;
         if (jt < nt) {
+            unsigned rnd4 = 0;
+            if (thr > 0) rnd4 = at_keep_rand4(seed, b * H + h, T, iw + q4 * 4, j);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float p = (len > 0) ? __expf(S[jt][r] - m[r]) : 0.f;  // exp(-inf) = 0 for excluded keys
                 sum[r] += p;
-                if (thr > 0) {
-                    const int i = iw + q4 * 4 + r;
-                    const unsigned idx = (((unsigned)(b * H + h) * (unsigned)T + (unsigned)i) * (unsigned)T + (unsigned)j);
-                    const unsigned rnd = at_hash32(idx * 0x9E3779B1u + seed) & 0xFFu;
-                    p = (rnd >= thr) ? p * keep_scale : 0.f;
-                }
+                if (thr > 0) p = (((rnd4 >> (8 * r)) & 0xFFu) >= thr) ? p * keep_scale : 0.f;
                 sP[(q4 * 4 + r) * LDP + j] = (__bf16)p;
             }
         }
@@ -376,9 +385,7 @@ __global__ __launch_bounds__(AT_THREADS, 1) void relpos_attn_bwd_kernel(
                 float p = S[jt][r] * inv[r];
                 S[jt][r] = p;
                 if (thr > 0) {
-                    const int i = iw + q4 * 4 + r;
-                    const unsigned idx = (((unsigned)(b * H + h) * (unsigned)T + (unsigned)i) * (unsigned)T + (unsigned)j);
-                    const unsigned rnd = at_hash32(idx * 0x9E3779B1u + seed) & 0xFFu;
+                    const unsigned rnd = (at_keep_rand4(seed, b * H + h, T, iw + q4 * 4, j) >> (8 * r)) & 0xFFu;
                     p = (rnd >= thr) ? p * keep_scale : 0.f;
                 }
                 sP[(q4 * 4 + r) * LDP + j] = (__bf16)p;
@@ -408,9 +415,7 @@ __global__ __launch_bounds__(AT_THREADS, 1) void relpos_attn_bwd_kernel(
             for (int r = 0; r < 4; ++r) {
                 float g = dP[r];
                 if (thr > 0) {
-                    const int i = iw + q4 * 4 + r;
-                    const unsigned idx = (((unsigned)(b * H + h) * (unsigned)T + (unsigned)i) * (unsigned)T + (unsigned)j);
-                    const unsigned rnd = at_hash32(idx * 0x9E3779B1u + seed) & 0xFFu;
+                    const unsigned rnd = (at_keep_rand4(seed, b * H + h, T, iw + q4 * 4, j) >> (8 * r)) & 0xFFu;
                     g = (rnd >= thr) ? g * keep_scale : 0.f;
                 }
                 S[jt][r] = S[jt][r] * (g - Drow[r]) * scale;
@@ -528,7 +533,7 @@ extern "C" int ia_relpos_attention(const void* qkv, const void* pos_proj, const 
     IA_RETURN_IF_LAUNCH_FAILED();
     const unsigned thr = (unsigned)(dropout_p * 256.f + 0.5f);
     const float keep_scale = thr > 0 ? 256.f / (256.f - (float)thr) : 1.f;
-    const size_t lds = 4 * (size_t)(16 * AT_LDR + 16) * sizeof(float);
+    const size_t lds = 4 * (size_t)AT_WAVE_LDS;
     if (hipFuncSetAttribute((const void*)relpos_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return IA_LAUNCH_FAILED;
     const int nqt = (T + 63) / 64;

@@ -261,10 +261,15 @@ __global__ __launch_bounds__(256) void glu_kernel(const __bf16* __restrict__ c2,
 
 __global__ __launch_bounds__(256) void attn_keepmask_kernel(int B, int H, int T, unsigned seed, unsigned thr, float keep_scale,
                                                             __bf16* __restrict__ mask) {
+    // attention.hip's at_keep_rand4: one hash per (head, 4 query rows, key), row i takes byte i & 3
     const int64_t total = (int64_t)B * H * T * T;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const unsigned rnd = ia_dm_hash32((unsigned)i * 0x9E3779B1u + seed) & 0xFFu;  // = attention.hip's key
-        mask[i] = (__bf16)((rnd >= thr) ? keep_scale : 0.f);
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int j = (int)(e % T);
+        const int64_t r = e / T;
+        const int i = (int)(r % T), bh = (int)(r / T);
+        const unsigned idx = ((unsigned)bh * (unsigned)((T + 3) >> 2) + (unsigned)(i >> 2)) * (unsigned)T + (unsigned)j;
+        const unsigned rnd = (ia_dm_hash32(idx * 0x9E3779B1u + seed) >> (8 * (i & 3))) & 0xFFu;
+        mask[e] = (__bf16)((rnd >= thr) ? keep_scale : 0.f);
     }
 }
 
