@@ -168,54 +168,84 @@ __global__ __launch_bounds__(256) void joint_dg_finish_kernel(const float* __res
 
 // Same gradient, one 64-cell tile per iteration, additionally emitting G^T in the chunked K-contiguous layout
 // GT[s][v][kc] (cell = s*Kc + kc) that the split-K weight-gradient GEMM consumes (both operands K-contiguous).
+// The tile goes through LDS as 16-byte chunks whose chunk index is XOR-swizzled with (row >> 3): the transposed read
+// (8 rows x one column per thread, rows 8 apart across neighbouring lanes) then touches 8 different chunks instead of
+// one bank 8 times (16-byte aligned rows make every 8-row stride a multiple of 32 banks).  The next tile's rows and
+// cell scalars are loaded into registers before the barrier, so their latency hides under the transposed write-out.
 constexpr int GT_CELLS = 64;
-__global__ __launch_bounds__(256) void joint_grad_h_t_kernel(_Float16* __restrict__ x, const float4* __restrict__ cs,
+constexpr int GT_NV = 9;  // 16-byte chunks per thread per tile: 4 threads per row, LD/8 <= 36 chunks per row
+__global__ __launch_bounds__(256, 3) void joint_grad_h_t_kernel(_Float16* __restrict__ x, const float4* __restrict__ cs,
                                                              int64_t cells, int LD, int V, int blank, float kappa,
-                                                             _Float16* __restrict__ gt, int S, int Kc) {
+                                                             _Float16* __restrict__ gt, int S, int Kc, int nch) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int ldt = LD + 8;  // halves per LDS row (16-byte multiple)
-    _Float16* tile = reinterpret_cast<_Float16*>(smem);
+    uint4* tile = reinterpret_cast<uint4*>(smem);                      // [GT_CELLS][nch] chunks, swizzled
+    const _Float16* tileh = reinterpret_cast<const _Float16*>(smem);
     const int vpr = LD / 8;
     const int64_t ntiles = (int64_t)S * (Kc / GT_CELLS);
-    for (int64_t tile_id = blockIdx.x; tile_id < ntiles; tile_id += gridDim.x) {
+    // thread = one tile row (cell) x every 4th chunk of it: a single cell-scalar record per thread
+    const int rr = threadIdx.x >> 2, c4 = threadIdx.x & 3;
+    uint4 px[GT_NV];
+    float4 pc;
+#define GT_LOAD(tile_id_)                                                                                    \
+    do {                                                                                                     \
+        const int64_t cell_ = (tile_id_) * GT_CELLS + rr;                                                    \
+        const bool ok_ = cell_ < cells;                                                                      \
+        pc = ok_ ? cs[cell_] : make_float4(IA_NEG_INF, 0.f, 0.f, 0.f);                                       \
+        _Pragma("unroll") for (int k = 0; k < GT_NV; ++k) {                                                  \
+            const int cv_ = c4 + 4 * k;                                                                      \
+            px[k] = (ok_ && cv_ < vpr && pc.x != IA_NEG_INF)                                                 \
+                        ? reinterpret_cast<const uint4*>(x + cell_ * LD)[cv_] : make_uint4(0, 0, 0, 0);      \
+        }                                                                                                    \
+    } while (0)
+    int64_t tile_id = blockIdx.x;
+    if (tile_id < ntiles) GT_LOAD(tile_id);
+    for (; tile_id < ntiles; tile_id += gridDim.x) {
         const int64_t cell0 = tile_id * GT_CELLS;
-        __syncthreads();
-        for (int i = threadIdx.x; i < GT_CELLS * vpr; i += 256) {
-            const int r = i / vpr, v0 = (i - r * vpr) * 8;
-            const int64_t cell = cell0 + r;
-            union { uint4 u; _Float16 h[8]; } io;
-            io.u = make_uint4(0, 0, 0, 0);
-            if (cell < cells) {
-                const float4 s = cs[cell];
-                if (s.x != IA_NEG_INF) {
-                    io.u = reinterpret_cast<const uint4*>(x + cell * LD)[v0 >> 3];
-                    const int w = __float_as_int(s.w);
-                    const int lab = (w & 0x7fffffff) - 1;
-                    const float sign = (w < 0) ? -kappa : kappa;
+        {
+            const float4 sc = pc;
+            const int64_t cell = cell0 + rr;
+            const bool live = sc.x != IA_NEG_INF;
+            const int w = __float_as_int(sc.w);
+            const int lab = (w & 0x7fffffff) - 1;
+            const float sign = (w < 0) ? -kappa : kappa;
+#pragma unroll
+            for (int k = 0; k < GT_NV; ++k) {
+                const int cvk = c4 + 4 * k;
+                if (cvk >= vpr) continue;
+                union { uint4 u; _Float16 h[8]; } io;
+                io.u = make_uint4(0, 0, 0, 0);
+                if (live) {
+                    io.u = px[k];
+                    const int v0 = cvk * 8;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const int v = v0 + j;
-                        float g = __expf((float)io.h[j] + s.x);
-                        if (v == blank) g -= s.y;
-                        if (v == lab) g -= s.z;
+                        float g = __expf((float)io.h[j] + sc.x);
+                        if (v == blank) g -= sc.y;
+                        if (v == lab) g -= sc.z;
                         io.h[j] = (v < V) ? (_Float16)(g * sign) : (_Float16)0.f;
                     }
                 }
-                reinterpret_cast<uint4*>(x + cell * LD)[v0 >> 3] = io.u;
+                if (cell < cells) reinterpret_cast<uint4*>(x + cell * LD)[cvk] = io.u;
+                tile[rr * nch + (cvk ^ ((rr >> 3) & 7))] = io.u;
             }
-            *reinterpret_cast<uint4*>(tile + r * ldt + v0) = io.u;
         }
+        const int64_t next = tile_id + gridDim.x;
+        if (next < ntiles) GT_LOAD(next);
         __syncthreads();
         const int s_idx = (int)(cell0 / Kc);
         const int kc0 = (int)(cell0 - (int64_t)s_idx * Kc);
         for (int i = threadIdx.x; i < LD * (GT_CELLS / 8); i += 256) {
-            const int v = i / (GT_CELLS / 8), r0 = (i - v * (GT_CELLS / 8)) * 8;
+            const int v = i >> 3, g8 = i & 7, r0 = g8 * 8;
+            const int off = ((v >> 3) ^ g8) * 8 + (v & 7);  // halves within a row ((r0+j)>>3 == g8 for j < 8)
             union { uint4 u; _Float16 h[8]; } o;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o.h[j] = tile[(r0 + j) * ldt + v];
+            for (int j = 0; j < 8; ++j) o.h[j] = tileh[(size_t)(r0 + j) * nch * 8 + off];
             *reinterpret_cast<uint4*>(gt + ((size_t)s_idx * LD + v) * Kc + kc0 + r0) = o.u;
         }
+        __syncthreads();
     }
+#undef GT_LOAD
 }
 
 // hidden^T in the same chunked layout: HT[s][hh][kc], hh < H: keep*relu(f+g); hh == H: 1; else 0.
@@ -295,10 +325,12 @@ extern "C" int ia_joint_backward_g(void* logits_inout, const int64_t* labels, co
     if (ev_start && hipEventRecord((hipEvent_t)ev_start, st) != hipSuccess) return IA_LAUNCH_FAILED;
     if (gt_out) {
         const int64_t ntiles = (int64_t)S * (Kc / GT_CELLS);
-        const size_t lds = (size_t)GT_CELLS * (LD + 8) * sizeof(_Float16);
+        const int nch = ((LD / 8) + 7) / 8 * 8;  // chunks per LDS row: room for the XOR-swizzled index
+        if (LD / 8 > 4 * GT_NV) return IA_UNSUPPORTED;
+        const size_t lds = (size_t)GT_CELLS * nch * 16;
         hipLaunchKernelGGL(joint_grad_h_t_kernel, dim3((unsigned)(ntiles < 16384 ? ntiles : 16384)), dim3(256), lds, st,
                            (_Float16*)logits_inout, (const float4*)(ws + w.off_cs), cells, LD, V, blank, kappa,
-                           (_Float16*)gt_out, S, Kc);
+                           (_Float16*)gt_out, S, Kc, nch);
     } else {
         hipLaunchKernelGGL(joint_grad_h_kernel, dim3(grid_for(cells * (LD / 8))), dim3(256), 0, st, (_Float16*)logits_inout,
                            (const float4*)(ws + w.off_cs), cells, LD, V, blank, kappa);

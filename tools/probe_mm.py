@@ -1,26 +1,25 @@
+"""Developer probe: library GEMM orientations for the joint's hidden gradient (not part of the product)."""
 import torch, time
-def bench(name, fn, fl):
-    try:
-        for _ in range(3): fn()
-        torch.cuda.synchronize(); t=time.time()
-        for _ in range(20): fn()
-        torch.cuda.synchronize(); dt=(time.time()-t)/20; print(f"{name}: {dt*1e6:.1f} us  {fl/dt/1e12:.1f} TF/s")
-    except Exception as e: print(name, "fail", repr(e)[:200])
-M=12032
-for N,K in [(1024,256),(256,1024),(256,256),(768,256)]:
-    dY=torch.randn(M,N,device='cuda',dtype=torch.bfloat16); X=torch.randn(M,K,device='cuda',dtype=torch.bfloat16)
-    fl=2*M*N*K
-    print(f"--- dW[{N},{K}] = dY^T X, M={M}")
-    bench("TN mm              ", lambda: torch.mm(dY.t(), X), fl)
-    bench("TN mm f32 out      ", lambda: torch.mm(dY.t(), X, out_dtype=torch.float32), fl)
-    def tr_bmm(S):
-        dYt=dY.t().contiguous().view(N,S,M//S).transpose(0,1); Xt=X.t().contiguous().view(K,S,M//S).transpose(0,1)
-        return torch.bmm(dYt, Xt.transpose(1,2), out_dtype=torch.float32).sum(0)
-    for S in (4,8,16):
-        bench(f"transposes+bmm S={S:2d} ", lambda: tr_bmm(S), fl)
-    def view_bmm(S):
-        a=dY.view(S,M//S,N).transpose(1,2); b=X.view(S,M//S,K)
-        return torch.bmm(a,b,out_dtype=torch.float32).sum(0)
-    for S in (4,8,16,47):
-        bench(f"view bmm (TN) S={S:2d}   ", lambda: view_bmm(S), fl)
-    bench("transpose only      ", lambda: (dY.t().contiguous(), X.t().contiguous()), 0)
+def t(fn, n=5):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+cells, LD, H, S = 1275392, 264, 640, 64
+Kc = ((cells + S - 1) // S + 63) // 64 * 64
+dev = "cuda"
+G = torch.randn(cells, LD, device=dev, dtype=torch.float16)
+Wp = torch.randn(LD, H, device=dev, dtype=torch.float16)
+Wt = Wp.t().contiguous()
+GT = torch.randn(S, LD, Kc, device=dev, dtype=torch.float16)
+print("mm(G, Wp)            [cells,264]x[264,640]      ", t(lambda: torch.mm(G, Wp)))
+print("matmul(Wt, GT)       [640,264]x[S,264,Kc]       ", t(lambda: torch.matmul(Wt, GT)))
+print("mm(G, Wt.t())        B given K-contiguous        ", t(lambda: torch.mm(G, Wt.t())))
+Gp = torch.randn(cells, 320, device=dev, dtype=torch.float16); Wp3 = torch.randn(320, H, device=dev, dtype=torch.float16)
+print("mm(G320, W320)       K padded to 320             ", t(lambda: torch.mm(Gp, Wp3)))
+Gb = G.bfloat16(); Wb = Wp.bfloat16()
+print("mm bf16                                          ", t(lambda: torch.mm(Gb, Wb)))
+GTl = GT.view(S * LD, Kc)
+print("bmm(GT^T view) per chunk: [S,Kc,264]x[264,640]   ", t(lambda: torch.matmul(GT.transpose(1, 2), Wp)))
