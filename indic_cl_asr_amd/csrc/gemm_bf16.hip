@@ -4,7 +4,7 @@
 //
 // A and W are both K-contiguous (activations row-major, nn.Linear weight layout), so A and B MFMA fragments are
 // 16-byte ds_read_b128 from 144-byte padded LDS rows (conflict-free).  Workgroup = 4 waves (2x2), tile BM x BN x 64,
-// register-staged double buffering.  The epilogue goes through LDS so that bias / SiLU / dropout / scaling / fp32
+// one LDS stage with the next k-tile prefetched in registers (37 KB per workgroup).  The epilogue goes through LDS so that bias / SiLU / dropout / scaling / fp32
 // residual add / dual fp32+bf16 output are done row-major with 16-byte coalesced accesses -- this is what removes the
 // ~40 separate elementwise launches per Conformer layer of the ATen composition.
 // Replaces nn.Linear + the elementwise ops around it in ConformerFeedForward (A/parts/submodules/conformer_modules.py
@@ -53,12 +53,13 @@ __device__ __forceinline__ uint4 conv_a_load(const GemmArgs& a, const ConvRow& r
 }
 
 template <int BM, int BN, bool CONV = false>
-__global__ __launch_bounds__(G_THREADS) void gemm_bf16_nt_kernel(GemmArgs a) {
+__global__ __launch_bounds__(G_THREADS, (BM == 128 ? 3 : 4)) void gemm_bf16_nt_kernel(GemmArgs a) {
     constexpr int WM = BM / 2, WN = BN / 2, TI = WM / 16, TJ = WN / 16;
-    constexpr int A_BYTES = BM * G_ROWB, B_BYTES = BN * G_ROWB, STAGE = A_BYTES + B_BYTES;
+    constexpr int A_BYTES = BM * G_ROWB;
     constexpr int AV = BM * 8 / G_THREADS, BV = BN * 8 / G_THREADS;  // 16-byte vectors per thread per stage
     constexpr int LDC = BN + 4;                                        // fp32 epilogue row stride (floats)
-    static_assert(2 * STAGE >= BM * LDC * 4, "epilogue tile must fit in the staging buffers");
+    constexpr int EP_ROWS = 64;                                        // tile rows per epilogue pass through LDS
+    static_assert(BM % EP_ROWS == 0 && (EP_ROWS % WM == 0 || WM % EP_ROWS == 0), "epilogue passes cover whole wave rows");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, q = lane >> 4;
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_bf16_nt_kernel(GemmArgs a) {
     } while (0)
 #define G_STORE(buf_) \
     do { \
-        unsigned char* sa_ = smem + (buf_) * STAGE; \
+        unsigned char* sa_ = smem; (void)(buf_); \
         unsigned char* sb_ = sa_ + A_BYTES; \
         { const int idx_ = tid + 0 * G_THREADS; *reinterpret_cast<uint4*>(sa_ + (idx_ >> 3) * G_ROWB + (idx_ & 7) * 16) = ra0; } \
         { const int idx_ = tid + 1 * G_THREADS; *reinterpret_cast<uint4*>(sa_ + (idx_ >> 3) * G_ROWB + (idx_ & 7) * 16) = ra1; } \
@@ -120,8 +121,8 @@ __global__ __launch_bounds__(G_THREADS) void gemm_bf16_nt_kernel(GemmArgs a) {
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) G_LOAD((kt + 1) * G_BK);
-        const unsigned char* sa = smem + (kt & 1) * STAGE + (wm * WM + c) * G_ROWB + q * 16;
-        const unsigned char* sb = smem + (kt & 1) * STAGE + A_BYTES + (wn * WN + c) * G_ROWB + q * 16;
+        const unsigned char* sa = smem + (wm * WM + c) * G_ROWB + q * 16;
+        const unsigned char* sb = smem + A_BYTES + (wn * WN + c) * G_ROWB + q * 16;
 #pragma unroll
         for (int ks = 0; ks < G_BK / 32; ++ks) {
             bf8 af[TI], bfr[TJ];
@@ -142,20 +143,25 @@ __global__ __launch_bounds__(G_THREADS) void gemm_bf16_nt_kernel(GemmArgs a) {
         }
     }
 
-    // ---- epilogue: accumulators -> LDS (fp32, row-major) -> row-major elementwise pass with 16-byte accesses
+    // ---- epilogue: accumulators -> LDS (fp32, row-major, EP_ROWS tile rows per pass) -> row-major elementwise pass with
+    // 16-byte accesses.  One LDS stage + a 64-row epilogue tile keep the workgroup at 37 KB: four workgroups per CU.
     float* sc = reinterpret_cast<float*>(smem);
-#pragma unroll
-    for (int i = 0; i < TI; ++i)
-#pragma unroll
-        for (int j = 0; j < TJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                sc[(wm * WM + i * 16 + q * 4 + r) * LDC + wn * WN + j * 16 + c] = acc[i][j][r];
-    __syncthreads();
     constexpr int VEC_PER_ROW = BN / 8;
-    for (int it = tid; it < BM * VEC_PER_ROW; it += G_THREADS) {
+    for (int pass = 0; pass < BM / EP_ROWS; ++pass) {
+    if (pass > 0) __syncthreads();
+    if ((wm * WM) / EP_ROWS == pass) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    sc[(wm * WM - pass * EP_ROWS + i * 16 + q * 4 + r) * LDC + wn * WN + j * 16 + c] = acc[i][j][r];
+    }
+    __syncthreads();
+    for (int it = tid; it < EP_ROWS * VEC_PER_ROW; it += G_THREADS) {
         const int row = it / VEC_PER_ROW, cv = it - row * VEC_PER_ROW;
-        const int gm = m0 + row, gn = n0 + cv * 8;
+        const int gm = m0 + pass * EP_ROWS + row, gn = n0 + cv * 8;
         if (gm >= a.M || gn >= a.N) continue;
         float v[8];
         const float4 x0 = *reinterpret_cast<const float4*>(sc + row * LDC + cv * 8);
@@ -198,12 +204,13 @@ __global__ __launch_bounds__(G_THREADS) void gemm_bf16_nt_kernel(GemmArgs a) {
             *reinterpret_cast<uint4*>(a.outH + (size_t)gm * a.ldoh + gn) = o.u;
         }
     }
+    }
 }
 
 template <int BM, int BN, bool CONV = false>
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
-    constexpr int STAGE = (BM + BN) * G_ROWB;
-    const size_t lds = 2 * (size_t)STAGE;
+    constexpr int STAGE = (BM + BN) * G_ROWB, EPI = 64 * (BN + 4) * 4;
+    const size_t lds = STAGE > EPI ? STAGE : EPI;
     const int grid = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<BM, BN, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
