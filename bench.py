@@ -188,6 +188,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    host_dt = time.perf_counter() - t0   # host enqueue time of the timed steps (no sync inside a step)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -211,7 +212,8 @@ def main():
                                    f"{args.dtype} projections, freeze_encoder_till={args.freeze}, 22x257 heads, "
                                    f"fused_batch_size={cfg.fused_batch_size}",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}",
-                       "final_loss": round(float(loss.item()), 4)},
+                       "final_loss": round(float(loss.item()), 4),
+                       "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 3)},
         }
         s = events.summary()
         if s is not None:

@@ -292,6 +292,29 @@ int ia_ctc_backward(const float* log_probs, const int64_t* targets, const int64_
                     size_t workspace_bytes, ia_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Native executor of the no-autograd Conformer prefix (frozen blocks / teacher / eval): one call enqueues the 14
+ * kernels of each of `n_layers` blocks (ConformerLayer.forward, conformer_modules.py:141-214) on `stream`.
+ * x [B*T, d] f32 residual stream, updated in place to the last block's norm_out; pos_emb [pos_rows >= 2T-1, d] bf16;
+ * block l uses dropout seeds seed_base + l*seed_stride + {1..7} (the sites of the Python path); training = 0 disables
+ * dropout and uses the BatchNorm running statistics.  All pointers in ia_block_params are device pointers: bf16 weights
+ * [out, in] (w_qkv = q|k|v rows concatenated, b_qkv likewise), f32 everything else.  Workspace from
+ * ia_conformer_prefix_ws_bytes.  Same limits as the kernels it sequences (head dim 64, T <= 384, taps <= 31). */
+typedef struct ia_block_params {
+    const void *w_ff1a, *w_ff1b, *w_qkv, *w_pos, *w_out, *w_pw1, *w_pw2, *w_ff2a, *w_ff2b;
+    const float *b_ff1a, *b_ff1b, *b_qkv, *b_out, *b_pw1, *b_pw2, *b_ff2a, *b_ff2b;
+    const float *ln_ff1_g, *ln_ff1_b, *ln_att_g, *ln_att_b, *ln_conv_g, *ln_conv_b, *ln_ff2_g, *ln_ff2_b, *ln_out_g, *ln_out_b;
+    const float *pos_u, *pos_v, *dw_w, *dw_b, *bn_g, *bn_b;
+    float *bn_rm, *bn_rv;
+    int64_t* bn_nbt;
+    float ln_eps, bn_eps, bn_momentum, p_drop, p_ff, p_att, fc_factor;
+    int d, d_ff, n_heads, ksz;
+} ia_block_params;
+size_t ia_conformer_prefix_ws_bytes(int B, int T, int d, int d_ff, int H, int ksz, int pos_rows);
+int ia_conformer_prefix_fwd(const ia_block_params* layers, int n_layers, float* x, const void* pos_emb, int pos_rows,
+                            const int64_t* lens, int B, int T, unsigned seed_base, unsigned seed_stride, int training,
+                            void* workspace, size_t workspace_bytes, ia_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Backward-side kernels of the trainable Conformer blocks (autograd of ConformerLayer.forward,
  * A/parts/submodules/conformer_modules.py:141-214); the dense contractions in between are bf16 GEMMs.
  *   ia_layernorm_bwd      dx_out = (dx_in or 0) + dLN/dx; dgamma/dbeta written (block partials in `scratch`, f32 x

@@ -19,6 +19,17 @@ _vp, _i, _f, _sz = _c.c_void_p, _c.c_int, _c.c_float, _c.c_size_t
 _i64 = _c.c_int64
 
 # name -> (restype, argtypes); must list every symbol include/indicasr.h declares (tests/test_abi.py checks)
+class BlockParams(_c.Structure):
+    """ia_block_params of include/indicasr.h (device pointers of one Conformer block for the native prefix executor)."""
+    _fields_ = ([(n, _c.c_void_p) for n in (
+        "w_ff1a", "w_ff1b", "w_qkv", "w_pos", "w_out", "w_pw1", "w_pw2", "w_ff2a", "w_ff2b",
+        "b_ff1a", "b_ff1b", "b_qkv", "b_out", "b_pw1", "b_pw2", "b_ff2a", "b_ff2b",
+        "ln_ff1_g", "ln_ff1_b", "ln_att_g", "ln_att_b", "ln_conv_g", "ln_conv_b", "ln_ff2_g", "ln_ff2_b", "ln_out_g", "ln_out_b",
+        "pos_u", "pos_v", "dw_w", "dw_b", "bn_g", "bn_b", "bn_rm", "bn_rv", "bn_nbt")]
+        + [(n, _c.c_float) for n in ("ln_eps", "bn_eps", "bn_momentum", "p_drop", "p_ff", "p_att", "fc_factor")]
+        + [(n, _c.c_int) for n in ("d", "d_ff", "n_heads", "ksz")])
+
+
 SIGNATURES = {
     "ia_version": (_c.c_char_p, []),
     "ia_rnnt_workspace_bytes": (_sz, [_i, _i, _i]),
@@ -65,6 +76,8 @@ SIGNATURES = {
     "ia_ctc_workspace_bytes": (_sz, [_i, _i, _i]),
     "ia_ctc_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "ia_ctc_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "ia_conformer_prefix_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
+    "ia_conformer_prefix_fwd": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _c.c_uint, _c.c_uint, _i, _vp, _sz, _vp]),
     "ia_layernorm_bwd": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _f, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "ia_layernorm_bwd_scratch_elems": (_i64, [_i, _i]),
     "ia_silu_dropout": (_i, [_vp, _i64, _i, _f, _c.c_uint, _vp, _vp]),

@@ -1,0 +1,101 @@
+// Host-side executor of the no-autograd Conformer prefix: ONE call enqueues all 14 kernels of every frozen block
+// (ConformerLayer.forward, A/parts/submodules/conformer_modules.py:141-214) on the caller's stream.
+// The Python loop it replaces spent 17 us of host time per launch (ctypes marshalling + torch.empty) -- 3.1 ms per
+// training step for 13 frozen blocks, the same order as the GPU time of those blocks; here the per-launch host cost is
+// the HIP launch itself.  No device code in this file: it only sequences the extern "C" entry points.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "indicasr.h"
+
+namespace {
+inline size_t up256(size_t x) { return (x + 255) / 256 * 256; }
+
+struct PrefixWs {
+    size_t y, h, qkv, pl, ctx, c2, z, sums, c3, vt, scr, total;
+};
+
+PrefixWs prefix_ws(int B, int T, int d, int d_ff, int H, int ksz, int pos_rows) {
+    const size_t N = (size_t)B * T;
+    PrefixWs w;
+    size_t o = 0;
+    w.y = o;    o = up256(o + N * d * 2);
+    w.h = o;    o = up256(o + N * d_ff * 2);
+    w.qkv = o;  o = up256(o + N * 3 * d * 2);
+    w.pl = o;   o = up256(o + (size_t)pos_rows * d * 2);
+    w.ctx = o;  o = up256(o + N * d * 2);
+    w.c2 = o;   o = up256(o + N * 2 * d * 2);
+    w.z = o;    o = up256(o + N * d * 4);
+    w.sums = o; o = up256(o + 2 * (size_t)d * 4);
+    w.c3 = o;   o = up256(o + N * d * 2);
+    w.vt = o;   o = up256(o + ia_attn_vt_elems(B, T, H) * 2);
+    w.scr = o;  o = up256(o + (size_t)ia_dwconv_scratch_elems(B, T, d, ksz) * 4);
+    w.total = o;
+    return w;
+}
+}  // namespace
+
+extern "C" size_t ia_conformer_prefix_ws_bytes(int B, int T, int d, int d_ff, int H, int ksz, int pos_rows) {
+    if (B <= 0 || T <= 0 || d <= 0 || d_ff <= 0 || H <= 0 || ksz <= 0 || pos_rows <= 0) return 0;
+    return prefix_ws(B, T, d, d_ff, H, ksz, pos_rows).total;
+}
+
+#define IA_TRY(call)               \
+    do {                           \
+        const int rc_ = (call);    \
+        if (rc_ != IA_OK) return rc_; \
+    } while (0)
+
+extern "C" int ia_conformer_prefix_fwd(const ia_block_params* layers, int n_layers, float* x, const void* pos_emb,
+                                       int pos_rows, const int64_t* lens, int B, int T, unsigned seed_base,
+                                       unsigned seed_stride, int training, void* workspace, size_t workspace_bytes,
+                                       ia_stream_t stream) {
+    if (!layers || n_layers <= 0 || !x || !pos_emb || !lens || !workspace || B <= 0 || T <= 0) return IA_INVALID_VALUE;
+    const ia_block_params& l0 = layers[0];
+    const int d = l0.d, d_ff = l0.d_ff, H = l0.n_heads, dk = d / (H > 0 ? H : 1), ksz = l0.ksz;
+    if (pos_rows < 2 * T - 1) return IA_INVALID_VALUE;
+    const PrefixWs w = prefix_ws(B, T, d, d_ff, H, ksz, pos_rows);
+    if (workspace_bytes < w.total) return IA_WORKSPACE_TOO_SMALL;
+    char* ws = (char*)workspace;
+    void *y = ws + w.y, *h = ws + w.h, *qkv = ws + w.qkv, *pl = ws + w.pl, *ctx = ws + w.ctx, *c2 = ws + w.c2, *c3 = ws + w.c3,
+         *vt = ws + w.vt;
+    float *z = (float*)(ws + w.z), *sums = (float*)(ws + w.sums), *scr = (float*)(ws + w.scr);
+    const int N = B * T;
+    // LayerNorm in front of the first block's first feed-forward; later ones are chained behind the previous norm_out
+    IA_TRY(ia_layernorm(x, d, N, d, l0.ln_ff1_g, l0.ln_ff1_b, l0.ln_eps, nullptr, 0, nullptr, nullptr, y, d, stream));
+    for (int li = 0; li < n_layers; ++li) {
+        const ia_block_params& L = layers[li];
+        if (L.d != d || L.d_ff != d_ff || L.n_heads != H || L.ksz != ksz) return IA_INVALID_VALUE;
+        const unsigned seed = seed_base + seed_stride * (unsigned)li;
+        const float p = training ? L.p_drop : 0.f, pff = training ? L.p_ff : 0.f, patt = training ? L.p_att : 0.f;
+        // 1/2 feed-forward
+        IA_TRY(ia_gemm_bf16(y, d, L.w_ff1a, d, N, d_ff, d, L.b_ff1a, 1, pff, seed + 1, 1.f, nullptr, 0, nullptr, 0, h, d_ff, stream));
+        IA_TRY(ia_gemm_bf16(h, d_ff, L.w_ff1b, d_ff, N, d, d_ff, L.b_ff1b, 0, p, seed + 2, L.fc_factor, x, d, x, d, nullptr, 0, stream));
+        // self-attention
+        IA_TRY(ia_layernorm(x, d, N, d, L.ln_att_g, L.ln_att_b, L.ln_eps, nullptr, 0, nullptr, nullptr, y, d, stream));
+        IA_TRY(ia_gemm_bf16(y, d, L.w_qkv, d, N, 3 * d, d, L.b_qkv, 0, 0.f, 0, 1.f, nullptr, 0, nullptr, 0, qkv, 3 * d, stream));
+        IA_TRY(ia_gemm_bf16(pos_emb, d, L.w_pos, d, pos_rows, d, d, nullptr, 0, 0.f, 0, 1.f, nullptr, 0, nullptr, 0, pl, d, stream));
+        IA_TRY(ia_relpos_attention(qkv, pl, L.pos_u, L.pos_v, lens, B, T, H, dk, patt, seed + 7, vt, ctx, stream));
+        IA_TRY(ia_gemm_bf16(ctx, d, L.w_out, d, N, d, d, L.b_out, 0, p, seed + 3, 1.f, x, d, x, d, nullptr, 0, stream));
+        // convolution module
+        IA_TRY(ia_layernorm(x, d, N, d, L.ln_conv_g, L.ln_conv_b, L.ln_eps, nullptr, 0, nullptr, nullptr, y, d, stream));
+        IA_TRY(ia_gemm_bf16(y, d, L.w_pw1, d, N, 2 * d, d, L.b_pw1, 0, 0.f, 0, 1.f, nullptr, 0, nullptr, 0, c2, 2 * d, stream));
+        IA_TRY(ia_glu_dwconv(c2, lens, B, T, d, ksz, L.dw_w, L.dw_b, z, sums, sums + d, scr, stream));
+        IA_TRY(ia_bn_silu(z, N, d, sums, sums + d, L.bn_g, L.bn_b, L.bn_rm, L.bn_rv, L.bn_nbt, L.bn_momentum, L.bn_eps,
+                          training ? 1 : 0, c3, stream));
+        IA_TRY(ia_gemm_bf16(c3, d, L.w_pw2, d, N, d, d, L.b_pw2, 0, p, seed + 4, 1.f, x, d, x, d, nullptr, 0, stream));
+        // 1/2 feed-forward
+        IA_TRY(ia_layernorm(x, d, N, d, L.ln_ff2_g, L.ln_ff2_b, L.ln_eps, nullptr, 0, nullptr, nullptr, y, d, stream));
+        IA_TRY(ia_gemm_bf16(y, d, L.w_ff2a, d, N, d_ff, d, L.b_ff2a, 1, pff, seed + 5, 1.f, nullptr, 0, nullptr, 0, h, d_ff, stream));
+        IA_TRY(ia_gemm_bf16(h, d_ff, L.w_ff2b, d_ff, N, d, d_ff, L.b_ff2b, 0, p, seed + 6, L.fc_factor, x, d, x, d, nullptr, 0, stream));
+        // norm_out, with the next block's first LayerNorm chained in registers
+        if (li + 1 < n_layers) {
+            const ia_block_params& Nx = layers[li + 1];
+            IA_TRY(ia_layernorm(x, d, N, d, L.ln_out_g, L.ln_out_b, L.ln_eps, x, d, Nx.ln_ff1_g, Nx.ln_ff1_b, y, d, stream));
+        } else {
+            IA_TRY(ia_layernorm(x, d, N, d, L.ln_out_g, L.ln_out_b, L.ln_eps, x, d, nullptr, nullptr, nullptr, 0, stream));
+        }
+    }
+    return IA_OK;
+}

@@ -301,9 +301,15 @@ class ConformerEncoder(nn.Module):
         B, T, d = x.shape
         xr = x.float().reshape(B * T, d).contiguous()
         pe = pos_emb.reshape(-1, d).to(torch.bfloat16).contiguous()
-        l0 = self.layers[0]
-        y = fast.layernorm(xr, l0.norm_feed_forward1.weight, l0.norm_feed_forward1.bias, l0.norm_feed_forward1.eps)
         base = (self.fast_seed * 2654435761) & 0x7FFFFFFF
+        l0 = self.layers[0]
+        bn_ok = all(l.conv.batch_norm.track_running_stats for l in self.layers[:n_fast])
+        same_mode = all(l.training == l0.training for l in self.layers[:n_fast])
+        if fast.attention_supported(T, l0.self_attn.d_k) and bn_ok and same_mode:
+            # native executor: one C call enqueues the 14 kernels of every block (csrc/block_exec.hip)
+            fast.conformer_prefix(list(self.layers[:n_fast]), xr, pe, length, B, T, base, 16, l0.training)
+            return xr.view(B, T, d), n_fast
+        y = fast.layernorm(xr, l0.norm_feed_forward1.weight, l0.norm_feed_forward1.bias, l0.norm_feed_forward1.eps)
         for l in range(n_fast):
             nxt = self.layers[l + 1].norm_feed_forward1 if l + 1 < n_fast else None
             xr, y = self.layers[l].forward_fast(xr, y, length, pe, B, T, base + 16 * l, nxt)

@@ -297,3 +297,69 @@ def conv_subsampling(feats_bft, conv1, conv2, lin):
     y = torch.empty(B * T2, d, dtype=torch.float32, device=dev)
     gemm(o2.view(B * T2, F2 * N), wl, lin.bias, out_f32=y, want_bf16=False)
     return y.view(B, T2, d)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Native executor of the no-autograd Conformer prefix (csrc/block_exec.hip): one C call for all frozen blocks.
+_BLOCK_PARAMS = {}
+
+
+def _block_params(layer):
+    """ia_block_params of one ConformerLayer, cached until one of its tensors changes (version / storage / weight epoch)."""
+    ff1, ff2, att, cv, bn = layer.feed_forward1, layer.feed_forward2, layer.self_attn, layer.conv, layer.conv.batch_norm
+    watch = (ff1.linear1.weight, ff1.linear2.weight, att.linear_q.weight, att.linear_k.weight, att.linear_v.weight,
+             att.linear_pos.weight, att.linear_out.weight, cv.pointwise_conv1.weight, cv.pointwise_conv2.weight,
+             ff2.linear1.weight, ff2.linear2.weight, att.linear_q.bias, att.linear_k.bias, att.linear_v.bias,
+             cv.depthwise_conv.weight)
+    ver = tuple(p._version for p in watch) + tuple(p.data_ptr() for p in watch) + \
+        ((WEIGHT_EPOCH,) if any(p.requires_grad for p in watch) else ()) + \
+        (layer.dropout.p, ff1.dropout.p, ff2.dropout.p, att.dropout_rate)
+    hit = _BLOCK_PARAMS.get(id(layer))
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    d = ff1.linear1.weight.shape[1]
+    keep = dict(
+        w_ff1a=bf16_shadow(ff1.linear1.weight), w_ff1b=bf16_shadow(ff1.linear2.weight),
+        w_qkv=bf16_shadow(att.linear_q.weight, att.linear_k.weight, att.linear_v.weight), w_pos=bf16_shadow(att.linear_pos.weight),
+        w_out=bf16_shadow(att.linear_out.weight), w_pw1=bf16_shadow(cv.pointwise_conv1.weight),
+        w_pw2=bf16_shadow(cv.pointwise_conv2.weight), w_ff2a=bf16_shadow(ff2.linear1.weight), w_ff2b=bf16_shadow(ff2.linear2.weight),
+        b_ff1a=ff1.linear1.bias, b_ff1b=ff1.linear2.bias, b_qkv=f32_cat(att.linear_q.bias, att.linear_k.bias, att.linear_v.bias),
+        b_out=att.linear_out.bias, b_pw1=cv.pointwise_conv1.bias, b_pw2=cv.pointwise_conv2.bias, b_ff2a=ff2.linear1.bias,
+        b_ff2b=ff2.linear2.bias,
+        ln_ff1_g=layer.norm_feed_forward1.weight, ln_ff1_b=layer.norm_feed_forward1.bias, ln_att_g=layer.norm_self_att.weight,
+        ln_att_b=layer.norm_self_att.bias, ln_conv_g=layer.norm_conv.weight, ln_conv_b=layer.norm_conv.bias,
+        ln_ff2_g=layer.norm_feed_forward2.weight, ln_ff2_b=layer.norm_feed_forward2.bias, ln_out_g=layer.norm_out.weight,
+        ln_out_b=layer.norm_out.bias, pos_u=att.pos_bias_u, pos_v=att.pos_bias_v, dw_w=cv.depthwise_conv.weight,
+        dw_b=cv.depthwise_conv.bias, bn_g=bn.weight, bn_b=bn.bias, bn_rm=bn.running_mean, bn_rv=bn.running_var,
+        bn_nbt=bn.num_batches_tracked)
+    bp = _lib.BlockParams()
+    for k, t in keep.items():
+        setattr(bp, k, t.data_ptr())
+    bp.ln_eps, bp.bn_eps = float(layer.norm_out.eps), float(bn.eps)
+    bp.bn_momentum = float(bn.momentum if bn.momentum is not None else 0.1)
+    bp.p_drop, bp.p_ff, bp.p_att = float(layer.dropout.p), float(ff1.dropout.p), float(att.dropout_rate)
+    bp.fc_factor = float(layer.fc_factor)
+    bp.d, bp.d_ff, bp.n_heads, bp.ksz = d, ff1.linear1.weight.shape[0], att.h, cv.depthwise_conv.weight.shape[-1]
+    _BLOCK_PARAMS[id(layer)] = (ver, bp, keep)
+    return bp
+
+
+_PREFIX_WS = {}
+
+
+def conformer_prefix(layers, xr, pos_emb_bf16, lens, B, T, seed_base, seed_stride, training):
+    """Run `layers` (ConformerLayer list) over the fp32 residual stream xr [B*T, d] in place with ONE native call."""
+    L = _lib.lib()
+    arr = (_lib.BlockParams * len(layers))(*[_block_params(l) for l in layers])
+    p0 = arr[0]
+    n = L.ia_conformer_prefix_ws_bytes(B, T, p0.d, p0.d_ff, p0.n_heads, p0.ksz, pos_emb_bf16.shape[0])
+    key = (xr.device.index, torch.cuda.current_stream(xr.device).cuda_stream)
+    ws = _PREFIX_WS.get(key)
+    if ws is None or ws.numel() < n:
+        ws = _PREFIX_WS[key] = torch.empty(n, dtype=torch.uint8, device=xr.device)
+    import ctypes
+    st = L.ia_conformer_prefix_fwd(ctypes.addressof(arr), len(layers), _lib.ptr(xr), _lib.ptr(pos_emb_bf16), pos_emb_bf16.shape[0],
+                                   _lib.ptr(lens), B, T, int(seed_base) & 0xFFFFFFFF, int(seed_stride), int(bool(training)),
+                                   _lib.ptr(ws), n, _lib.stream_ptr())
+    _lib.check(st, "ia_conformer_prefix_fwd")
+    return xr
