@@ -97,26 +97,34 @@ __global__ __launch_bounds__(256) void bn_silu_kernel(const float* __restrict__ 
                                                       float* __restrict__ running_mean, float* __restrict__ running_var,
                                                       int64_t* __restrict__ num_batches, float momentum, float eps,
                                                       int training, __bf16* __restrict__ out) {
-    const int64_t total4 = n_rows * d / 4;
+    // y = x*scale[c] + shift[c] with the per-channel pair computed once per workgroup into LDS (d <= 1024)
+    __shared__ float s_scale[1024], s_shift[1024];
     const float inv_n = 1.f / (float)n_rows;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
-        const int col = (int)((i * 4) % d);
-        const float4 x = reinterpret_cast<const float4*>(z)[i];
-        float xv[4] = {x.x, x.y, x.z, x.w};
-        union { uint2 u; __bf16 h[4]; } o;
+    for (int cch = threadIdx.x; cch < d; cch += 256) {
+        float mean, var;
+        if (training) {
+            mean = bn_sum[cch] * inv_n;
+            var = fmaxf(bn_sumsq[cch] * inv_n - mean * mean, 0.f);
+        } else {
+            mean = running_mean[cch]; var = running_var[cch];
+        }
+        const float sc = rsqrtf(var + eps) * gamma[cch];
+        s_scale[cch] = sc;
+        s_shift[cch] = beta[cch] - mean * sc;
+    }
+    __syncthreads();
+    const int64_t total8 = n_rows * d / 8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total8; i += (int64_t)gridDim.x * 256) {
+        const int col = (int)((i * 8) % d);
+        const float4 x0 = reinterpret_cast<const float4*>(z)[2 * i], x1 = reinterpret_cast<const float4*>(z)[2 * i + 1];
+        const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+        union { uint4 u; __bf16 h[8]; } o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float mean, var;
-            if (training) {
-                mean = bn_sum[col + j] * inv_n;
-                var = fmaxf(bn_sumsq[col + j] * inv_n - mean * mean, 0.f);
-            } else {
-                mean = running_mean[col + j]; var = running_var[col + j];
-            }
-            const float y = (xv[j] - mean) * rsqrtf(var + eps) * gamma[col + j] + beta[col + j];
+        for (int j = 0; j < 8; ++j) {
+            const float y = xv[j] * s_scale[col + j] + s_shift[col + j];
             o.h[j] = (__bf16)(y / (1.f + __expf(-y)));
         }
-        reinterpret_cast<uint2*>(out)[i] = o.u;
+        reinterpret_cast<uint4*>(out)[i] = o.u;
     }
 }
 
@@ -201,12 +209,13 @@ extern "C" int ia_bn_silu(const float* z, int64_t n_rows, int d, const float* bn
                           const float* gamma, const float* beta, float* running_mean, float* running_var,
                           int64_t* num_batches_tracked, float momentum, float eps, int training, void* out,
                           ia_stream_t stream) {
-    if (!z || !gamma || !beta || !out || n_rows <= 1 || d <= 0 || d % 4 != 0) return IA_INVALID_VALUE;
+    if (!z || !gamma || !beta || !out || n_rows <= 1 || d <= 0 || d % 8 != 0) return IA_INVALID_VALUE;
+    if (d > 1024) return IA_UNSUPPORTED;
     if (training && (!bn_sum || !bn_sumsq)) return IA_INVALID_VALUE;
     if (!training && (!running_mean || !running_var)) return IA_INVALID_VALUE;
     hipStream_t st = (hipStream_t)stream;
-    const int64_t total4 = n_rows * d / 4;
-    const int grid = (int)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
+    const int64_t total8 = n_rows * d / 8;
+    const int grid = (int)((total8 + 255) / 256 < 1024 ? (total8 + 255) / 256 : 1024);
     hipLaunchKernelGGL(bn_silu_kernel, dim3(grid), dim3(256), 0, st, z, n_rows, d, bn_sum, bn_sumsq, gamma, beta,
                        running_mean, running_var, num_batches_tracked, momentum, eps, training, (__bf16*)out);
     IA_RETURN_IF_LAUNCH_FAILED();
