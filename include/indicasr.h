@@ -133,15 +133,18 @@ int ia_joint_dh_reduce(const void* dh, const void* f, const void* g, const int64
                        float dropout_p, unsigned seed, void* scratch, ia_stream_t stream);
 size_t ia_joint_dh_reduce_scratch_bytes(int B, int T, int U1, int H);
 /* ia_joint_dh_fused: the dH GEMM, the relu/dropout mask and both reductions of ia_joint_dh_reduce in ONE kernel (dH only
- * exists as MFMA accumulators):  df[b,t,:] (written for t < act_len rounded up to 16; caller zeroes df) and dg[b,u,:] +=
- * (f32 atomics, one per element and frame slice; caller zeroes dg).  G = ia_joint_backward_g's in-place output
- * [B*T*U1, LD] f16; Wt = W transposed and zero padded to [H, ia_joint_dh_k()] f16 (Wt[h][v] = W[v][h], dropout scale
- * folded as in the forward).  Supported when ia_joint_dh_fused_supported(U1, H, LD): H % 128 == 0, LD <= 288. */
+ * exists as MFMA accumulators; workgroup = utterance x 16 frames x 320 hidden units, waves partitioned along the hidden
+ * axis so both reductions are wave-local).  df[b,t,:] written for t < act_len rounded up to 16 (caller zeroes df);
+ * dg[b,u,:] written for every u (16-frame partial rows in `scratch` = ia_joint_dh_fused_scratch_bytes + a finishing
+ * sum; no atomics).  G = ia_joint_backward_g's in-place output [B*T*U1, LD] f16; Wt = W transposed and zero padded to
+ * [H, ia_joint_dh_k()] f16 (Wt[h][v] = W[v][h], dropout scale folded as in the forward).
+ * Supported when ia_joint_dh_fused_supported(U1, H, LD): H % 80 == 0, LD <= 288. */
 int ia_joint_dh_fused_supported(int U1, int H, int LD);
 int ia_joint_dh_k(void);
+size_t ia_joint_dh_fused_scratch_bytes(int B, int T, int U1, int H);
 int ia_joint_dh_fused(const void* G, const void* Wt, const void* f, const void* g, const int64_t* act_lens,
                       const int64_t* label_lens, float* df, float* dg, int B, int T, int U1, int H, int LD,
-                      float inv_kappa, float dropout_p, unsigned seed, ia_stream_t stream);
+                      float inv_kappa, float dropout_p, unsigned seed, void* scratch, ia_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Conformer block forward building blocks (bf16 projections, fp32 residual stream).

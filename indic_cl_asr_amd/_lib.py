@@ -47,7 +47,8 @@ SIGNATURES = {
     "ia_joint_dh_reduce_scratch_bytes": (_sz, [_i, _i, _i, _i]),
     "ia_joint_dh_fused_supported": (_i, [_i, _i, _i]),
     "ia_joint_dh_k": (_i, []),
-    "ia_joint_dh_fused": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _c.c_uint, _vp]),
+    "ia_joint_dh_fused": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _c.c_uint, _vp, _vp]),
+    "ia_joint_dh_fused_scratch_bytes": (_sz, [_i, _i, _i, _i]),
     "ia_gemm_bf16": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _f, _c.c_uint, _f, _vp, _i, _vp, _i, _vp, _i, _vp]),
     "ia_subsample_conv1": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ia_subsample_conv2": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),

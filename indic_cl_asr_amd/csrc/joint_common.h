@@ -24,16 +24,18 @@ __device__ __forceinline__ unsigned hash32(unsigned x) {  // murmur3 finaliser
 
 // Dropout keep-mask for the 8 hidden units [kg*8, kg*8+8) of lattice cell `cell`: bit j set = keep.
 // Shared (by construction) with the backward kernels: depends only on (seed, cell, kg).
+// 4 bytes of x compared with thr at once: returns bit j = (byte j of x >= thr), thr in [1, 255] (uniform).
+__device__ __forceinline__ unsigned ge4_u8(unsigned x, unsigned thr) {
+    const unsigned H = 0x80808080u;
+    const unsigned h = (x | H) - ((thr & 0x7Fu) * 0x01010101u);  // per byte: bit 7 = (x & 0x7f) >= (thr & 0x7f), no borrows
+    const unsigned m = ((thr & 0x80u) ? (x & h) : (x | h)) & H;  // fold in the top bit of each byte
+    return (((m >> 7) * 0x00204081u) >> 21) & 0xFu;              // gather bits 0,8,16,24 into a nibble
+}
+
 __device__ __forceinline__ unsigned dropout_keep8(unsigned seed, unsigned cell, unsigned kg, unsigned thr) {
     const unsigned base = cell * 0x9E3779B1u + kg * 0x85EBCA77u + seed;
     const unsigned r0 = hash32(base), r1 = hash32(base ^ 0x68E31DA4u);
-    unsigned m = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        m |= (((r0 >> (8 * j)) & 0xFFu) >= thr ? 1u : 0u) << j;
-        m |= (((r1 >> (8 * j)) & 0xFFu) >= thr ? 1u : 0u) << (4 + j);
-    }
-    return m;
+    return ge4_u8(r0, thr) | (ge4_u8(r1, thr) << 4);
 }
 
 __device__ __forceinline__ h8 apply_keep8(h8 v, unsigned m) {

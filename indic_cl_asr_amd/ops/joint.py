@@ -12,9 +12,9 @@ import torch
 from .. import _lib
 
 JOINT_MAX_V = 272
-# csrc/joint_dh.hip fuses the dH GEMM with its mask and reductions; measured 2.7 ms against 1.4 + 0.4 ms for the
-# library GEMM + ia_joint_dh_reduce at bs32 x 15 s (joint backward), so the unfused path is the default.
-USE_FUSED_DH = False
+# csrc/joint_dh.hip fuses the dH GEMM with its mask and reductions (1.4 ms against 1.4 + 0.6 ms for the library GEMM +
+# ia_joint_dh_reduce at bs32 x 15 s); False selects the unfused path (also the fallback for H % 80 != 0).
+USE_FUSED_DH = True
 
 
 def fused_joint_supported(H, V, device):
@@ -90,9 +90,10 @@ class _FusedJointRNNT(torch.autograd.Function):
             # dH = G @ W, relu/dropout mask and both reductions in one MFMA kernel (dH never reaches memory)
             Wt = torch.zeros(H, L.ia_joint_dh_k(), dtype=torch.float16, device=dev)
             Wt[:, :JOINT_MAX_V] = Wp.t()
+            scr = torch.empty(L.ia_joint_dh_fused_scratch_bytes(B, T, U1, H), dtype=torch.uint8, device=dev)
             st = L.ia_joint_dh_fused(_lib.ptr(G), _lib.ptr(Wt), _lib.ptr(f16), _lib.ptr(g16), _lib.ptr(act_lens),
                                      _lib.ptr(label_lens), _lib.ptr(df), _lib.ptr(dg), B, T, U1, H, LD, 1.0 / kappa, p, seed,
-                                     _lib.stream_ptr())
+                                     _lib.ptr(scr), _lib.stream_ptr())
             _lib.check(st, "ia_joint_dh_fused")
         else:
             dH = torch.mm(G, Wp[:LD])  # [cells, H] f16 (plain library GEMM)

@@ -75,7 +75,8 @@ def test_fused_joint_dropout_mask_consistent_between_forward_and_backward():
         assert math.isclose(bb.grad[v].item(), fd, rel_tol=0.05, abs_tol=0.02), (v, bb.grad[v].item(), fd)
 
 
-@pytest.mark.parametrize("B,T,U1,H,V,p", [(3, 45, 21, 256, 257, 0.25), (2, 33, 17, 128, 100, 0.0), (4, 70, 100, 640, 257, 0.2)])
+@pytest.mark.parametrize("B,T,U1,H,V,p", [(3, 45, 21, 320, 257, 0.25), (2, 33, 17, 320, 100, 0.0), (4, 70, 100, 640, 257, 0.2),
+                                         (2, 19, 5, 960, 130, 0.1)])
 def test_fused_hidden_gradient_kernel_matches_gemm_plus_reduce_path(B, T, U1, H, V, p):
     """csrc/joint_dh.hip (dH GEMM + relu/dropout mask + both reductions in one kernel) against the unfused
     library-GEMM + ia_joint_dh_reduce path on identical inputs, ragged lengths, dropout on and off."""
@@ -93,7 +94,7 @@ def test_fused_hidden_gradient_kernel_matches_gemm_plus_reduce_path(B, T, U1, H,
             fc, gc = f.clone().requires_grad_(True), g.clone().requires_grad_(True)
             J.fused_joint_rnnt(fc, gc, W, b, labels, fl.cuda(), gl.cuda(), V - 1, dropout_p=p, seed=77).sum().backward()
         finally:
-            J.USE_FUSED_DH = False
+            J.USE_FUSED_DH = True
         outs.append((fc.grad.clone(), gc.grad.clone()))
     for a, r, what in ((outs[0][0], outs[1][0], "df"), (outs[0][1], outs[1][1], "dg")):
         tol = 4e-3 * r.abs().max().item() + 1e-6      # the unfused path rounds dHidden to f16
