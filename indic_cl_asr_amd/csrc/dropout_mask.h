@@ -7,14 +7,15 @@ __device__ __forceinline__ unsigned ia_dm_hash32(unsigned x) {
     x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
     return x;
 }
+// 4 bytes of x compared with thr at once: returns bit j = (byte j of x >= thr), thr in [1, 255] (uniform)
+__device__ __forceinline__ unsigned ia_ge4_u8(unsigned x, unsigned thr) {
+    const unsigned H = 0x80808080u;
+    const unsigned h = (x | H) - ((thr & 0x7Fu) * 0x01010101u);  // per byte: bit 7 = (x & 0x7f) >= (thr & 0x7f), no borrows
+    const unsigned m = ((thr & 0x80u) ? (x & h) : (x | h)) & H;  // fold in the top bit of each byte
+    return (((m >> 7) * 0x00204081u) >> 21) & 0xFu;              // gather bits 0,8,16,24 into a nibble
+}
 __device__ __forceinline__ unsigned ia_keep8(unsigned seed, unsigned gm, unsigned N, unsigned gn, unsigned thr) {
     const unsigned base = (gm * N + gn) * 0x9E3779B1u + seed;
     const unsigned r0 = ia_dm_hash32(base), r1 = ia_dm_hash32(base ^ 0x68E31DA4u);
-    unsigned m = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        m |= (((r0 >> (8 * j)) & 0xFFu) >= thr ? 1u : 0u) << j;
-        m |= (((r1 >> (8 * j)) & 0xFFu) >= thr ? 1u : 0u) << (4 + j);
-    }
-    return m;
+    return ia_ge4_u8(r0, thr) | (ia_ge4_u8(r1, thr) << 4);
 }
