@@ -294,6 +294,15 @@ int ia_ctc_backward(const float* log_probs, const int64_t* targets, const int64_
                     int B, int T, int V, int S, int blank, const float* nll_grad, float* grad, void* workspace,
                     size_t workspace_bytes, ia_stream_t stream);
 
+/* ia_gemm_tn_bf16: weight gradient of a projection, dW[n,k] = sum_m dY[m,n] X[m,k] (f32, written) and optionally
+ * db[n] = sum_m dY[m,n] (NULL to skip): both operands row-major over the contracted frame axis m (bf16, row strides
+ * ldy/ldx multiples of 8), tiles transposed on the fly by ds_read_b64_tr_b16, split-K partial tiles in `scratch`
+ * (f32 x ia_gemm_tn_scratch_elems) + a finishing sum.  n, k multiples of 8.  Replaces autograd's x^T @ dy of
+ * nn.Linear / pointwise Conv1d in the trainable Conformer blocks. */
+int64_t ia_gemm_tn_scratch_elems(int M, int n, int k);
+int ia_gemm_tn_bf16(const void* dY, int ldy, const void* X, int ldx, int M, int n, int k, float* dW, float* db,
+                    float* scratch, ia_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Native executor of the no-autograd Conformer prefix (frozen blocks / teacher / eval): one call enqueues the 14
  * kernels of each of `n_layers` blocks (ConformerLayer.forward, conformer_modules.py:141-214) on `stream`.

@@ -1,0 +1,195 @@
+// Weight-gradient GEMM of the trainable projections for gfx950:   dW[n,k] = sum_m dY[m,n] * X[m,k]   (+ db[n] = sum_m dY[m,n])
+//
+// Both operands are row-major over the contracted index m (the frame axis: 12032 rows at bs32 x 15 s), i.e. the MFMA
+// fragments (8 consecutive m for one n / one k) are COLUMNS of the tiles as they sit in memory.  The tiles are staged
+// row-major into LDS with coalesced 16-byte loads (XOR-swizzled chunks) and read back with gfx950's transposing LDS read
+// ds_read_b64_tr_b16: per 16-lane group it fetches a 4-row x 16-column block and hands lane i column i -- two of them
+// form one 16x16x32 operand fragment, for A (dY columns) and B (X columns) alike.  Split-K over m across workgroups;
+// every workgroup writes its [128 x 128] partial tile, ia_partials_finish adds the slices (no atomics, deterministic).
+// The bias gradient rides along as one extra MFMA per A fragment against an all-ones B fragment.
+// (The library's TN GEMM launches 16-40 workgroups for these shapes: 70-80 us; its batched split-K form floors at
+// ~27 us whatever the size.)
+#include <hip/hip_bf16.h>
+
+#include "ia_common.h"
+#include "partials.h"
+
+namespace {
+
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int TN_BN = 128;   // output rows (n) per workgroup
+constexpr int TN_BK = 128;   // output columns (k) per workgroup
+constexpr int TN_MS = 64;    // contracted rows per step
+constexpr int TN_ROWB = 256; // LDS bytes per tile row (128 bf16)
+constexpr int TN_TILE = TN_MS * TN_ROWB;
+
+// byte offset of 16-byte chunk ch (0..15) of row `row` in a [64][128 x bf16] tile: chunk index XOR-swizzled so that
+// both the row-wise store and the transposed 4-row block reads are conflict-free (cdna_hip_programming.md T10, image b)
+__device__ __forceinline__ int tn_off(int row, int ch) { return TN_ROWB * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+
+// LDS byte addresses (address space 3) of the two 4-row blocks of one 16x16x32 operand fragment: 8 consecutive m =
+// rows r0..r0+7 for column col0 + (lane & 15).  Lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of its block.
+__device__ __forceinline__ void tn_frag_addr(unsigned tile_lds, int r0, int col0, int lane, unsigned* a0, unsigned* a1) {
+    const int l16 = lane & 15, q = l16 >> 2, p = l16 & 3;
+    const int ch = (col0 >> 3) + (p >> 1);
+    *a0 = tile_lds + tn_off(r0 + q, ch) + 8 * (p & 1);
+    *a1 = tile_lds + tn_off(r0 + 4 + q, ch) + 8 * (p & 1);
+}
+__device__ __forceinline__ bf4 tn_tr_read(unsigned addr) {
+    bf4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+__device__ __forceinline__ bf8 tn_join(bf4 lo, bf4 hi) {
+    bf8 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { o[j] = lo[j]; o[4 + j] = hi[j]; }
+    return o;
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const __bf16* __restrict__ dY, int ldy, const __bf16* __restrict__ X,
+                                                         int ldx, int M, int n, int k, int rows_per_split,
+                                                         float* __restrict__ part, float* __restrict__ part_b) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TN_TILE];  // dY tile | X tile
+    unsigned char* sY = smem;
+    unsigned char* sX = smem + TN_TILE;
+    const unsigned ldsY = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)sY);
+    const unsigned ldsX = ldsY + TN_TILE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, q4 = lane >> 4;
+    const int wn = wave >> 1, wk = wave & 1;                 // 2 x 2 waves, 64 x 64 outputs each
+    const int ntk = (k + TN_BK - 1) / TN_BK;
+    const int n0 = (blockIdx.x / ntk) * TN_BN, k0 = (blockIdx.x % ntk) * TN_BK;
+    const int split = blockIdx.y;
+    const int m_beg = split * rows_per_split;
+    int m_end = m_beg + rows_per_split; m_end = m_end < M ? m_end : M;
+    const bool do_bias = part_b != nullptr && k0 == 0 && wk == 0;
+
+    f4 acc[4][4], accb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        accb[i] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+    }
+    bf8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.f;
+
+    // loader: 64 rows x 16 chunks per tile = 1024 chunks -> 4 per thread per tile
+    uint4 ry[4], rx[4];
+#define TN_LOAD(m0_)                                                                                               \
+    do {                                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                            \
+            const int idx_ = tid + 256 * i, row_ = idx_ >> 4, ch_ = idx_ & 15;                                     \
+            const int m_ = (m0_) + row_;                                                                           \
+            const bool okm_ = m_ < m_end;                                                                          \
+            const int cy_ = n0 + ch_ * 8, cx_ = k0 + ch_ * 8;                                                      \
+            ry[i] = (okm_ && cy_ < n) ? *reinterpret_cast<const uint4*>(dY + (size_t)m_ * ldy + cy_) : make_uint4(0, 0, 0, 0); \
+            rx[i] = (okm_ && cx_ < k) ? *reinterpret_cast<const uint4*>(X + (size_t)m_ * ldx + cx_) : make_uint4(0, 0, 0, 0);  \
+        }                                                                                                          \
+    } while (0)
+#define TN_STORE()                                                                                                 \
+    do {                                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                            \
+            const int idx_ = tid + 256 * i, row_ = idx_ >> 4, ch_ = idx_ & 15;                                     \
+            *reinterpret_cast<uint4*>(sY + tn_off(row_, ch_)) = ry[i];                                             \
+            *reinterpret_cast<uint4*>(sX + tn_off(row_, ch_)) = rx[i];                                             \
+        }                                                                                                          \
+    } while (0)
+
+    TN_LOAD(m_beg);
+    for (int m0 = m_beg; m0 < m_end; m0 += TN_MS) {
+        __syncthreads();  // previous step's fragment reads are done
+        TN_STORE();
+        __syncthreads();
+        if (m0 + TN_MS < m_end) TN_LOAD(m0 + TN_MS);
+#pragma unroll
+        for (int ks = 0; ks < TN_MS / 32; ++ks) {
+            // all 16 transposed reads of the k-step in flight, ONE wait that the fragment registers are tied to (the
+            // compiler does not know the asm reads LDS asynchronously: without the tie it may consume them early)
+            bf4 alo[4], ahi[4], blo[4], bhi[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                unsigned a0, a1;
+                tn_frag_addr(ldsY, ks * 32 + q4 * 8, wn * 64 + i * 16, lane, &a0, &a1);
+                alo[i] = tn_tr_read(a0); ahi[i] = tn_tr_read(a1);
+                tn_frag_addr(ldsX, ks * 32 + q4 * 8, wk * 64 + i * 16, lane, &a0, &a1);
+                blo[i] = tn_tr_read(a0); bhi[i] = tn_tr_read(a1);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(alo[0]), "+v"(alo[1]), "+v"(alo[2]), "+v"(alo[3]), "+v"(ahi[0]), "+v"(ahi[1]), "+v"(ahi[2]),
+                           "+v"(ahi[3]), "+v"(blo[0]), "+v"(blo[1]), "+v"(blo[2]), "+v"(blo[3]), "+v"(bhi[0]), "+v"(bhi[1]),
+                           "+v"(bhi[2]), "+v"(bhi[3])
+                         :
+                         : "memory");
+            bf8 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { af[i] = tn_join(alo[i], ahi[i]); bfr[i] = tn_join(blo[i], bhi[i]); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                if (do_bias) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, accb[i], 0, 0, 0);
+            }
+        }
+    }
+#undef TN_LOAD
+#undef TN_STORE
+    // partial tile: C layout lane = (col = k index c, rows = n index 4*q4 + r)
+    float* prow = part + (size_t)split * n * k;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gn = n0 + wn * 64 + i * 16 + q4 * 4 + r;
+            if (gn < n) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int gk = k0 + wk * 64 + j * 16 + c;
+                    if (gk < k) prow[(size_t)gn * k + gk] = acc[i][j][r];
+                }
+                if (do_bias && c == 0) part_b[(size_t)split * n + gn] = accb[i][r];
+            }
+        }
+}
+
+inline int tn_splits(int M, int n, int k) {
+    const int tiles = ((n + TN_BN - 1) / TN_BN) * ((k + TN_BK - 1) / TN_BK);
+    int s = (320 + tiles - 1) / tiles;
+    const int cap = (M + TN_MS - 1) / TN_MS;
+    s = s < 1 ? 1 : (s > cap ? cap : s);
+    return s;
+}
+}  // namespace
+
+extern "C" int64_t ia_gemm_tn_scratch_elems(int M, int n, int k) {
+    if (M <= 0 || n <= 0 || k <= 0) return 0;
+    return (int64_t)tn_splits(M, n, k) * ((int64_t)n * k + n);
+}
+
+extern "C" int ia_gemm_tn_bf16(const void* dY, int ldy, const void* X, int ldx, int M, int n, int k, float* dW, float* db,
+                               float* scratch, ia_stream_t stream) {
+    if (!dY || !X || !dW || !scratch || M <= 0 || n <= 0 || k <= 0) return IA_INVALID_VALUE;
+    if (n % 8 != 0 || k % 8 != 0 || ldy % 8 != 0 || ldx % 8 != 0 || !ia_is_aligned(dY, 16) || !ia_is_aligned(X, 16)) return IA_UNSUPPORTED;
+    const int S = tn_splits(M, n, k);
+    int rps = (M + S - 1) / S;
+    rps = (rps + TN_MS - 1) / TN_MS * TN_MS;
+    const int Seff = (M + rps - 1) / rps;
+    float* part = scratch;
+    float* part_b = db ? scratch + (size_t)Seff * n * k : nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(((n + TN_BN - 1) / TN_BN) * ((k + TN_BK - 1) / TN_BK), Seff), blk(256);
+    hipLaunchKernelGGL(gemm_tn_kernel, grid, blk, 0, st, (const __bf16*)dY, ldy, (const __bf16*)X, ldx, M, n, k, rps, part, part_b);
+    IA_RETURN_IF_LAUNCH_FAILED();
+    ia_partials_finish_wide(part, Seff, (int64_t)n * k, dW, st);
+    IA_RETURN_IF_LAUNCH_FAILED();
+    if (db) {
+        ia_partials_finish(part_b, Seff, n, n, db, db, st);
+        IA_RETURN_IF_LAUNCH_FAILED();
+    }
+    return IA_OK;
+}

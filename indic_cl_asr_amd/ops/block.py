@@ -43,16 +43,18 @@ def _branch_grad(dxr, alpha, p, seed):
 
 
 def _lin_bwd(dyb, xb, wb, need_dx=True):
-    """dyb [M,n] bf16, xb [M,k] bf16, wb [n,k] bf16 -> (dx bf16 [M,k] or None, dW f32 [n,k], db f32 [n])."""
+    """dyb [M,n] bf16, xb [M,k] bf16, wb [n,k] bf16 -> (dx bf16 [M,k] or None, dW f32 [n,k], db f32 [n]).
+    Data gradient: library GEMM; weight + bias gradient: csrc/gemm_tn.hip (transposing LDS reads, split-K partial tiles)."""
     M, n = dyb.shape
     k = xb.shape[1]
     dx = torch.mm(dyb, wb) if need_dx else None
-    S = next((s for s in (8, 4, 2) if M % s == 0 and M // s >= 256), 1)
-    if S > 1:
-        dW = torch.bmm(dyb.view(S, M // S, n).transpose(1, 2), xb.view(S, M // S, k), out_dtype=torch.float32).sum(0)
-    else:
-        dW = torch.mm(dyb.t(), xb, out_dtype=torch.float32)
-    return dx, dW, fast.colsum(dyb)
+    L = _lib.lib()
+    dW = torch.empty(n, k, dtype=torch.float32, device=dyb.device)
+    db = torch.empty(n, dtype=torch.float32, device=dyb.device)
+    st = L.ia_gemm_tn_bf16(_ptr(dyb), dyb.stride(0), _ptr(xb), xb.stride(0), M, n, k, _ptr(dW), _ptr(db),
+                           _ptr(fast.scratch(dyb.device, L.ia_gemm_tn_scratch_elems(M, n, k))), _lib.stream_ptr())
+    _lib.check(st, "ia_gemm_tn_bf16")
+    return dx, dW, db
 
 
 def _silu_dropout(h_pre, p, seed):
