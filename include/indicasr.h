@@ -297,7 +297,7 @@ int ia_ctc_backward(const float* log_probs, const int64_t* targets, const int64_
 /* ia_gemm_tn_bf16: weight gradient of a projection, dW[n,k] = sum_m dY[m,n] X[m,k] (f32, written) and optionally
  * db[n] = sum_m dY[m,n] (NULL to skip): both operands row-major over the contracted frame axis m (bf16, row strides
  * ldy/ldx multiples of 8), tiles transposed on the fly by ds_read_b64_tr_b16, split-K partial tiles in `scratch`
- * (f32 x ia_gemm_tn_scratch_elems) + a finishing sum.  n, k multiples of 8.  Replaces autograd's x^T @ dy of
+ * (f32 x ia_gemm_tn_scratch_elems) + a finishing sum (one pass when db == dW + n*k).  n, k multiples of 8.  Replaces autograd's x^T @ dy of
  * nn.Linear / pointwise Conv1d in the trainable Conformer blocks. */
 int64_t ia_gemm_tn_scratch_elems(int M, int n, int k);
 int ia_gemm_tn_bf16(const void* dY, int ldy, const void* X, int ldx, int M, int n, int k, float* dW, float* db,

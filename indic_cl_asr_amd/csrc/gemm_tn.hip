@@ -52,7 +52,8 @@ __device__ __forceinline__ bf8 tn_join(bf4 lo, bf4 hi) {
 
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const __bf16* __restrict__ dY, int ldy, const __bf16* __restrict__ X,
                                                          int ldx, int M, int n, int k, int rows_per_split,
-                                                         float* __restrict__ part, float* __restrict__ part_b) {
+                                                         float* __restrict__ part, float* __restrict__ part_b,
+                                                         size_t row_stride) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TN_TILE];  // dY tile | X tile
     unsigned char* sY = smem;
     unsigned char* sX = smem + TN_TILE;
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const __bf16* __restric
 #undef TN_LOAD
 #undef TN_STORE
     // partial tile: C layout lane = (col = k index c, rows = n index 4*q4 + r)
-    float* prow = part + (size_t)split * n * k;
+    float* prow = part + (size_t)split * row_stride;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const __bf16* __restric
                     const int gk = k0 + wk * 64 + j * 16 + c;
                     if (gk < k) prow[(size_t)gn * k + gk] = acc[i][j][r];
                 }
-                if (do_bias && c == 0) part_b[(size_t)split * n + gn] = accb[i][r];
+                if (do_bias && c == 0) part_b[(size_t)split * row_stride + gn] = accb[i][r];
             }
         }
 }
@@ -179,17 +180,24 @@ extern "C" int ia_gemm_tn_bf16(const void* dY, int ldy, const void* X, int ldx, 
     int rps = (M + S - 1) / S;
     rps = (rps + TN_MS - 1) / TN_MS * TN_MS;
     const int Seff = (M + rps - 1) / rps;
+    // partial row of one split = [n*k tile values | n bias sums]: when db directly follows dW in memory one pass finishes both
+    const size_t row_stride = (size_t)n * k + n;
     float* part = scratch;
-    float* part_b = db ? scratch + (size_t)Seff * n * k : nullptr;
+    float* part_b = db ? scratch + (size_t)n * k : nullptr;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(((n + TN_BN - 1) / TN_BN) * ((k + TN_BK - 1) / TN_BK), Seff), blk(256);
-    hipLaunchKernelGGL(gemm_tn_kernel, grid, blk, 0, st, (const __bf16*)dY, ldy, (const __bf16*)X, ldx, M, n, k, rps, part, part_b);
+    hipLaunchKernelGGL(gemm_tn_kernel, grid, blk, 0, st, (const __bf16*)dY, ldy, (const __bf16*)X, ldx, M, n, k, rps, part, part_b,
+                       row_stride);
     IA_RETURN_IF_LAUNCH_FAILED();
-    ia_partials_finish_wide(part, Seff, (int64_t)n * k, dW, st);
-    IA_RETURN_IF_LAUNCH_FAILED();
-    if (db) {
-        ia_partials_finish(part_b, Seff, n, n, db, db, st);
-        IA_RETURN_IF_LAUNCH_FAILED();
+    if (db == dW + (size_t)n * k) {
+        ia_partials_finish_wide(part, Seff, (int64_t)row_stride, dW, st);
+    } else {
+        ia_partials_finish_wide_strided(part, Seff, (int64_t)n * k, (int64_t)row_stride, dW, st);
+        if (db) {
+            IA_RETURN_IF_LAUNCH_FAILED();
+            ia_partials_finish_wide_strided(part_b, Seff, (int64_t)n, (int64_t)row_stride, db, st);
+        }
     }
+    IA_RETURN_IF_LAUNCH_FAILED();
     return IA_OK;
 }

@@ -33,25 +33,29 @@ __global__ __launch_bounds__(1024) void ia_partials_finish_kernel(const float* _
 
 // Wide matrices with few partial rows (split-K GEMM tiles: C = n*k, G = splits): one thread per 4 columns.
 __global__ __launch_bounds__(256) void ia_partials_finish_wide_kernel(const float* __restrict__ part, int G, int64_t C4,
-                                                                      float* __restrict__ out) {
+                                                                      int64_t S4, float* __restrict__ out) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < C4; i += (int64_t)gridDim.x * 256) {
         const float4* p = reinterpret_cast<const float4*>(part) + i;
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
         int g = 0;
         for (; g + 1 < G; g += 2) {
-            const float4 x = p[(int64_t)g * C4], y = p[(int64_t)(g + 1) * C4];
+            const float4 x = p[(int64_t)g * S4], y = p[(int64_t)(g + 1) * S4];
             a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
             b.x += y.x; b.y += y.y; b.z += y.z; b.w += y.w;
         }
-        if (g < G) { const float4 x = p[(int64_t)g * C4]; a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w; }
+        if (g < G) { const float4 x = p[(int64_t)g * S4]; a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w; }
         reinterpret_cast<float4*>(out)[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
     }
 }
 
-inline void ia_partials_finish_wide(const float* part, int G, int64_t C, float* out, hipStream_t st) {  // C % 4 == 0
+// C columns summed over G rows of stride `stride` floats (C, stride multiples of 4)
+inline void ia_partials_finish_wide_strided(const float* part, int G, int64_t C, int64_t stride, float* out, hipStream_t st) {
     const int64_t c4 = C / 4, blocks = (c4 + 255) / 256;
     hipLaunchKernelGGL(ia_partials_finish_wide_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, part, G,
-                       c4, out);
+                       c4, stride / 4, out);
+}
+inline void ia_partials_finish_wide(const float* part, int G, int64_t C, float* out, hipStream_t st) {
+    ia_partials_finish_wide_strided(part, G, C, C, out, st);
 }
 
 inline void ia_partials_finish(const float* part, int G, int C, int C0, float* out0, float* out1, hipStream_t st) {

@@ -49,8 +49,8 @@ def _lin_bwd(dyb, xb, wb, need_dx=True):
     k = xb.shape[1]
     dx = torch.mm(dyb, wb) if need_dx else None
     L = _lib.lib()
-    dW = torch.empty(n, k, dtype=torch.float32, device=dyb.device)
-    db = torch.empty(n, dtype=torch.float32, device=dyb.device)
+    buf = torch.empty(n * k + n, dtype=torch.float32, device=dyb.device)  # dW | db contiguous: one finishing pass
+    dW, db = buf[:n * k].view(n, k), buf[n * k:]
     st = L.ia_gemm_tn_bf16(_ptr(dyb), dyb.stride(0), _ptr(xb), xb.stride(0), M, n, k, _ptr(dW), _ptr(db),
                            _ptr(fast.scratch(dyb.device, L.ia_gemm_tn_scratch_elems(M, n, k))), _lib.stream_ptr())
     _lib.check(st, "ia_gemm_tn_bf16")
