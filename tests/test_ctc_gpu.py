@@ -33,3 +33,27 @@ def test_ctc_matches_oracle(B, T, V, S):
     # fp32 alpha+beta at |log-lik| ~ 2e3 (T = 376) carries ~1e-4 absolute error per posterior, as ATen's own fp32 kernels do
     atol = 2e-5 if T <= 100 else 4e-4
     assert np.allclose(lpc.grad.cpu().numpy(), grad_ref * w.numpy()[:, None, None], rtol=2e-3, atol=atol)
+
+
+def test_ctc_head_hip_matches_aten_linear():
+    """Single-language CTC head (decoder._CtcHeadHip: padded bf16 GEMM forward, library dgrad + ia_gemm_tn_bf16 for the
+    weight and bias gradients) against F.linear on the same bf16-rounded operands."""
+    import torch.nn.functional as F
+    from indic_cl_asr_amd.decoder import _CtcHeadHip
+    torch.manual_seed(3)
+    B, T, d, V = 3, 70, 128, 257
+    x = torch.randn(B, T, d, device="cuda")
+    w = (torch.randn(V, d, device="cuda") * 0.1)
+    b = torch.randn(V, device="cuda") * 0.1
+    dy = torch.randn(B, T, V, device="cuda")
+    xa, wa, ba = (t.clone().requires_grad_(True) for t in (x, w, b))
+    ya = _CtcHeadHip.apply(xa, wa, ba)
+    ya.backward(dy)
+    xr, wr, br = (t.bfloat16().float().requires_grad_(True) for t in (x, w, b))
+    br = b.clone().requires_grad_(True)
+    yr = F.linear(xr, wr, br)
+    yr.backward(dy.bfloat16().float())
+    def rel(a, r):
+        return (a.float() - r).norm().item() / (r.norm().item() + 1e-12)
+    assert rel(ya, yr) < 5e-3
+    assert rel(xa.grad, xr.grad) < 1e-2 and rel(wa.grad, wr.grad) < 1e-2 and rel(ba.grad, br.grad) < 1e-2
