@@ -208,9 +208,9 @@ def colsum(x_bf16):
 
 
 class _LinearHip(torch.autograd.Function):
-    """y = x W^T + b for the trainable blocks: forward on the HIP GEMM (bias in the epilogue, bf16 out), data gradient
-    as a library GEMM, weight gradient as a batched split-K GEMM over row chunks (hipBLASLt's single TN GEMM launches
-    16-40 workgroups for these [256..1024 x 256..1024 x 12032] shapes: 70-80 us vs 28 us), bias gradient by ia_colsum."""
+    """y = x W^T + b for trainable projections outside the fused blocks (joint enc / pred): forward on the HIP GEMM (bias
+    in the epilogue, bf16 out), data gradient as a library GEMM, weight + bias gradient by csrc/gemm_tn.hip (hipBLASLt's
+    single TN GEMM launches 16-40 workgroups for these [256..1024 x 256..1024 x 12032] shapes: 70-80 us vs 17 us)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -233,15 +233,21 @@ class _LinearHip(torch.autograd.Function):
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.mm(dyb, wb).view(shp).to(xdt)
-        if ctx.needs_input_grad[1]:
-            S = next((s for s in (8, 4, 2) if M % s == 0 and M // s >= 256), 1)
-            if S > 1:
-                dW = torch.bmm(dyb.view(S, M // S, N).transpose(1, 2), xb.view(S, M // S, K), out_dtype=torch.float32).sum(0)
+        if ctx.needs_input_grad[1] or (bdt is not None and ctx.needs_input_grad[2]):
+            if N % 8 == 0 and K % 8 == 0:
+                L = _lib.lib()
+                buf = torch.empty(N * K + N, dtype=torch.float32, device=dyb.device)
+                dWf, dbf = buf[:N * K].view(N, K), buf[N * K:]
+                st = L.ia_gemm_tn_bf16(_lib.ptr(dyb), dyb.stride(0), _lib.ptr(xb), xb.stride(0), M, N, K, _lib.ptr(dWf), _lib.ptr(dbf),
+                                       _lib.ptr(scratch(dyb.device, L.ia_gemm_tn_scratch_elems(M, N, K))), _lib.stream_ptr())
+                _lib.check(st, "ia_gemm_tn_bf16")
             else:
-                dW = torch.mm(dyb.t(), xb, out_dtype=torch.float32)
-            dW = dW.view(wshape).to(wdt)
-        if bdt is not None and ctx.needs_input_grad[2]:
-            db = colsum(dyb).to(bdt)
+                dWf = torch.mm(dyb.t(), xb, out_dtype=torch.float32)
+                dbf = dyb.float().sum(0)
+            if ctx.needs_input_grad[1]:
+                dW = dWf.view(wshape).to(wdt)
+            if bdt is not None and ctx.needs_input_grad[2]:
+                db = dbf.to(bdt)
         return dx, dW, db
 
 
