@@ -19,7 +19,7 @@
 
 namespace {
 
-constexpr int DW_TT = 8;          // output frames per wave pass
+constexpr int DW_TT = 16;         // output frames per wave pass
 constexpr int DW_TB = 4 * DW_TT;  // frames per workgroup (4 waves)
 
 // taps of an odd ksz <= KMAX kernel centred in a KMAX window (zeros outside)
