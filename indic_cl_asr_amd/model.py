@@ -185,18 +185,22 @@ class EncDecHybridRNNTCTCModel(nn.Module):
         h_enc = [subsampled_length(mel_frame_count(int(n), self.cfg.n_fft, self.cfg.n_window_stride)) for n in h_sig]
 
         # The prediction network only meets the encoder in the joint: its persistent LSTM kernel occupies 40 of the 256
-        # CUs, so it runs on a side stream under the encoder (autograd replays its backward on that stream as well, under
-        # the encoder blocks' backward).
+        # CUs, so it runs on a side stream under the encoder.  It is ISSUED after the encoder on purpose: autograd runs
+        # ready nodes in reverse creation order, so its backward (replayed on the same side stream) is then enqueued
+        # before the encoder blocks' backward and overlaps it even when the host runs barely ahead of the GPU (profilers,
+        # multi-rank runs), instead of trailing the step on an idle GPU; the side stream only waits for the event recorded before the encoder was enqueued, not for the encoder itself.
         side = self._side_stream(signal.device) if self.overlap_decoder and signal.is_cuda else None
         if side is not None:
             main = torch.cuda.current_stream(signal.device)
-            side.wait_stream(main)
+            inputs_ready = torch.cuda.Event()
+            inputs_ready.record(main)
+        encoded, encoded_len = self.forward(input_signal=signal, input_signal_length=signal_len)
+        if side is not None:
+            side.wait_event(inputs_ready)
             with torch.cuda.stream(side):
                 decoder, target_length, states = self.decoder(targets=transcript, target_length=transcript_len)
             for t in (transcript, transcript_len):
                 t.record_stream(side)
-        encoded, encoded_len = self.forward(input_signal=signal, input_signal_length=signal_len)
-        if side is not None:
             main.wait_stream(side)
             decoder.record_stream(main)
         else:
