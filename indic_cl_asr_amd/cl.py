@@ -75,9 +75,11 @@ class FlatParams:
         return FlatDict(self, torch.zeros_like(self.theta))
 
     def clone_theta(self) -> FlatDict:
+        flush_pending_updates()
         return FlatDict(self, self.theta.clone())
 
     def params_dict(self) -> FlatDict:
+        flush_pending_updates()
         return self._theta_views
 
     def grads_dict(self) -> FlatDict:
@@ -96,6 +98,7 @@ class FlatParams:
         """Run with the parameters temporarily pointing at another flat buffer (LwF teacher forward) -- no
         torch.save/torch.load ping-pong and no barriers (R/cl_baseline_lwf.py:220-234 does both per batch)."""
         from .ops import fast
+        flush_pending_updates()
         try:
             for n, p in zip(self.names, self.params):
                 p.data = other[n]
@@ -134,6 +137,8 @@ def get_grads(model) -> FlatDict:
 
 def set_grads(model, grad_dict):
     """R/utils.py:316-321.  A FlatDict produced by get_penalty_grads already IS the flat gradient buffer."""
+    flush_pending_updates()
+    flush_pending_updates()
     f = flat_of(model)
     if isinstance(grad_dict, FlatDict) and grad_dict.flat.data_ptr() != f.grad.data_ptr():
         f.grad.copy_(grad_dict.flat)
@@ -144,6 +149,7 @@ def set_grads(model, grad_dict):
 
 def save_model(model, path):
     """R/utils.py:265-271: trainable-only state dict (same interchange format)."""
+    flush_pending_updates()
     torch.save({n: p.data.clone() for n, p in getattr(model, "module", model).named_parameters() if p.requires_grad}, path)
 
 
@@ -152,6 +158,7 @@ def ewc_penalty_into_grads(flat: FlatParams, fisher: FlatDict, checkpoint: FlatD
                            monitor_out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """grad <- 2*lambda*F*(theta-theta*) (pre-load, autograd accumulates on top: R/cl_baseline_ewc.py:228-231);
     returns a 0-dim device tensor = mean_k mean|penalty_k| (the 'ewc_penalty' monitor, :74-80)."""
+    flush_pending_updates()
     L = _lib.lib()
     seg = torch.zeros(len(flat.entries), dtype=torch.float32, device=flat.theta.device)
     st = L.ia_cl_penalty(_lib.ptr(flat.theta), _lib.ptr(checkpoint.flat), _lib.ptr(fisher.flat), 2.0 * float(e_lambda),
@@ -198,6 +205,7 @@ def mas_penalty_add_grads(flat: FlatParams, importance: FlatDict, checkpoint: Fl
     """Adds d/dtheta [mas_lambda * sum omega (theta-theta*)^2] to the flat gradient buffer and returns the
     un-weighted penalty value as a 0-dim device tensor ('mass_loss', R/cl_baseline_mas.py:70-75,231-234).
     The reference obtains the same gradient through autograd on `loss + mass_loss*mas_lambda`."""
+    flush_pending_updates()
     val = torch.zeros(1, dtype=torch.float32, device=flat.theta.device)
     st = _lib.lib().ia_cl_penalty(_lib.ptr(flat.theta), _lib.ptr(checkpoint.flat), _lib.ptr(importance.flat),
                                   2.0 * float(mas_lambda), _lib.ptr(flat.grad), 1, _lib.ptr(flat.chunk_table),
@@ -209,6 +217,7 @@ def mas_penalty_add_grads(flat: FlatParams, importance: FlatDict, checkpoint: Fl
 def penalty(model, main_importance: FlatDict, prev_params: FlatDict):
     """Signature of R/cl_baseline_mas.py:70.  Returns the penalty VALUE (no autograd graph); pair it with
     mas_penalty_add_grads() after backward, or use MASRegulariser which does both."""
+    flush_pending_updates()
     flat = flat_of(model)
     val = torch.zeros(1, dtype=torch.float32, device=flat.theta.device)
     st = _lib.lib().ia_cl_penalty(_lib.ptr(flat.theta), _lib.ptr(prev_params.flat), _lib.ptr(main_importance.flat), 0.0,
@@ -261,6 +270,7 @@ def lwf_kd_loss(loss, prob, prob_, pred_store_list, store_list, knowledge_distil
 def lwf_teacher_forward(model, flat: FlatParams, teacher: FlatDict, batch, lang_ids, host_lengths=None):
     """Teacher pass with the previous task's weights resident in HBM (R/cl_baseline_lwf.py:213-232 semantics:
     no_grad, store_sub_enc + detach)."""
+    flush_pending_updates()
     m = getattr(model, "module", model)
     with torch.no_grad(), flat.weights(teacher):
         m.joint.store_sub_enc, m.joint.detach_sub_enc = True, True
@@ -278,7 +288,7 @@ class FusedAdamW:
     exists -- the reference wraps the model in DDP but never arms its reducer."""
 
     def __init__(self, model_or_flat, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, group=None,
-                 bf16_shadow=None):
+                 bf16_shadow=None, defer_update=True):
         self.flat = model_or_flat if isinstance(model_or_flat, FlatParams) else flat_of(model_or_flat)
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.exp_avg = torch.zeros_like(self.flat.theta)
@@ -289,9 +299,14 @@ class FusedAdamW:
             bf16_shadow = self.flat.theta.is_cuda
         self.shadow = torch.zeros(self.flat.numel, dtype=torch.bfloat16, device=self.flat.theta.device) if bf16_shadow else None
         self.param_groups = [dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, params=self.flat.params)]
+        self.defer_update = defer_update   # data parallel only: overlap the gradient all-reduce with the next forward
+        self._pending, self._zero_after_flush = None, False
 
     def zero_grad(self, set_to_none: bool = False):
-        self.flat.zero_grad()
+        if self._pending is not None:
+            self._zero_after_flush = True   # the deferred update still has to consume these gradients
+        else:
+            self.flat.zero_grad()
 
     def allreduce_grads(self):
         if dist.is_available() and dist.is_initialized():
@@ -301,8 +316,38 @@ class FusedAdamW:
                 return 1.0 / ws
         return 1.0
 
+    def _world(self):
+        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+
     def step(self, grad_scale: Optional[float] = None):
-        scale = self.allreduce_grads() * (1.0 if grad_scale is None else grad_scale)
+        """Single process: AdamW now.  Data parallel with `defer_update` (default): the all-reduce of the flat gradient is
+        launched asynchronously and the AdamW kernel is deferred to flush(), which the model calls right before the first
+        module that reads trainable weights in the NEXT forward -- the exchange over xGMI then runs under the front end,
+        subsampling and the frozen encoder prefix, none of which read trainable weights, so the result is bit-identical to
+        updating immediately.  Everything here that reads or swaps the flat weights flushes first."""
+        self.flush()
+        ws = self._world()
+        gs = 1.0 if grad_scale is None else grad_scale
+        if ws > 1 and self.defer_update:
+            work = dist.all_reduce(self.flat.grad, group=self.group, async_op=True)
+            self._pending = (work, gs / ws)
+            _PENDING_OPTIMIZERS.add(self)
+            return
+        self._apply(self.allreduce_grads() * gs)
+
+    def flush(self):
+        if self._pending is None:
+            return
+        work, scale = self._pending
+        self._pending = None
+        _PENDING_OPTIMIZERS.discard(self)
+        work.wait()
+        self._apply(scale)
+        if self._zero_after_flush:
+            self._zero_after_flush = False
+            self.flat.zero_grad()
+
+    def _apply(self, scale):
         self.step_count += 1
         g = self.param_groups[0]
         st = _lib.lib().ia_adamw_step(_lib.ptr(self.flat.theta), _lib.ptr(self.flat.grad), _lib.ptr(self.exp_avg),
@@ -310,9 +355,24 @@ class FusedAdamW:
                                       float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), self.step_count,
                                       float(scale), _lib.ptr(self.shadow), _lib.stream_ptr())
         _lib.check(st, "ia_adamw_step")
+        if self.flat.theta.is_cuda:
+            global LAST_UPDATE_EVENT
+            LAST_UPDATE_EVENT = torch.cuda.Event()
+            LAST_UPDATE_EVENT.record()
         from .ops import fast
         fast.bump_weight_epoch()  # the kernel rewrote theta by raw pointer: bf16 weight shadows are stale now
         if self.shadow is not None:  # ... and were re-made by the same kernel: hand the views to the shadow cache
             for (n, o, k, shape), q in zip(self.flat.entries, self.flat.params):
                 if q.dim() >= 2:
                     fast.register_flat_shadow(q, self.shadow[o:o + k].view(shape[0], -1))
+
+
+_PENDING_OPTIMIZERS = set()
+LAST_UPDATE_EVENT = None   # recorded on the stream of the latest AdamW launch (side streams wait for it)
+
+
+def flush_pending_updates():
+    """Apply every deferred optimizer update (FusedAdamW.step under data parallelism).  Called by the model before the
+    first module that reads trainable weights, and by every helper here that reads or swaps the flat weights."""
+    for opt in list(_PENDING_OPTIMIZERS):
+        opt.flush()

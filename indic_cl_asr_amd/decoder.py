@@ -24,6 +24,12 @@ def label_collate(labels, device=None):
     return out
 
 
+def _flush_pending():
+    from . import cl
+    if cl._PENDING_OPTIMIZERS:
+        cl.flush_pending_updates()
+
+
 class LSTMDropout(nn.Module):
     def __init__(self, input_size, hidden_size, dropout, forget_gate_bias=1.0):
         super().__init__()
@@ -72,6 +78,7 @@ class RNNTDecoder(nn.Module):
         return g.transpose(0, 1), hid
 
     def forward(self, targets, target_length, states=None):
+        _flush_pending()
         y = label_collate(targets)
         g, states = self.predict(y, state=states, add_sos=True)  # (B, U+1, H)
         return g.transpose(1, 2), target_length, states          # (B, H, U+1)
@@ -146,6 +153,7 @@ class RNNTJoint(nn.Module):
         """Fused joint + loss over sub-batches (rnnt.py:1403-1561).  Returns (loss, wer, wer_num, wer_denom);
         `host_lengths` = (enc_lens list, tgt_lens list) lets the loop narrow each sub-batch without a
         device->host sync (the reference calls .max() on device tensors per sub-batch, :1440-1441)."""
+        _flush_pending()
         enc = encoder_outputs.transpose(1, 2)
         dec = decoder_outputs.transpose(1, 2)
         if (encoder_lengths is None) or (transcript_lengths is None):
@@ -287,6 +295,7 @@ class ConvASRDecoder(nn.Module):
         return torch.cat([torch.arange(i * v, (i + 1) * v, device=device), torch.tensor([self._num_classes - 1], device=device)])
 
     def forward(self, encoder_output, language_ids=None):
+        _flush_pending()
         w = self.decoder_layers[0].weight.squeeze(-1)  # [n, d]
         b = self.decoder_layers[0].bias
         x = encoder_output.transpose(1, 2)  # [B,T,d]

@@ -245,6 +245,9 @@ class ConformerEncoder(nn.Module):
 
     def forward(self, audio_signal, length):
         """audio_signal [B,feat,Tm] f32, length [B] i64 -> (encoded [B,d,T'], encoded_len [B] i64)."""
+        from . import cl
+        if cl._PENDING_OPTIMIZERS and any(p.requires_grad for p in self.pre_encode.parameters()):
+            cl.flush_pending_updates()   # deferred data-parallel update: the subsampling weights are about to be read
         with self._amp(audio_signal):
             with (torch.no_grad() if self.encoder_frozen_till > 0 else nullcontext()):
                 from .ops import fast
@@ -275,6 +278,10 @@ class ConformerEncoder(nn.Module):
                     with torch.no_grad():
                         if self.layers[0].fast_supported(x):
                             x, lth = self._fast_prefix(x, length, pos_emb, n_fast)
+            # a deferred data-parallel optimizer update (cl.FusedAdamW.step) lands here: everything above read frozen
+            # weights only, so the gradient all-reduce ran under it
+            if cl._PENDING_OPTIMIZERS:
+                cl.flush_pending_updates()
             # trainable suffix: one autograd node per block on the HIP kernels (ops/block.py), ATen composition otherwise
             blk_ok = False
             if (self.use_fast_path and self.use_fused_blocks and self.cfg.compute_dtype == "bf16" and x.is_cuda

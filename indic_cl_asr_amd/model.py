@@ -197,6 +197,9 @@ class EncDecHybridRNNTCTCModel(nn.Module):
         encoded, encoded_len = self.forward(input_signal=signal, input_signal_length=signal_len)
         if side is not None:
             side.wait_event(inputs_ready)
+            from . import cl
+            if cl.LAST_UPDATE_EVENT is not None:   # a deferred optimizer update was applied on the main stream inside forward
+                side.wait_event(cl.LAST_UPDATE_EVENT)
             with torch.cuda.stream(side):
                 decoder, target_length, states = self.decoder(targets=transcript, target_length=transcript_len)
             for t in (transcript, transcript_len):
