@@ -171,11 +171,37 @@ class EncDecHybridRNNTCTCModel(nn.Module):
         encoded, encoded_len = self.encoder(audio_signal=processed_signal, length=processed_signal_length)
         return encoded, encoded_len
 
+    # ------------------------------------------------------------------ greedy decoding / WER
+    @torch.no_grad()
+    def decode(self, encoded, encoded_len, language_ids, max_symbols=10):
+        """Greedy transducer hypotheses (language-local token ids) with the prediction net and joint frozen in eval mode
+        (rnnt_decoding.py: `with self.decoder.as_frozen(), self.joint.as_frozen()`)."""
+        from .decoding import greedy_rnnt_decode
+        modes = (self.decoder.training, self.joint.training)
+        self.decoder.eval(); self.joint.eval()
+        try:
+            return greedy_rnnt_decode(self, encoded, encoded_len, language_ids, max_symbols)
+        finally:
+            self.decoder.train(modes[0]); self.joint.train(modes[1])
+
+    @torch.no_grad()
+    def batch_wer(self, encoded, encoded_len, log_probs, transcript, transcript_len, language_ids):
+        from .decoding import greedy_ctc_decode, word_error_rate
+        lens = transcript_len.tolist()
+        refs = [row[:n] for row, n in zip(transcript.tolist(), lens)]
+        det = getattr(self, "detokenize", None)
+        wer = word_error_rate(self.decode(encoded.detach(), encoded_len, language_ids), refs, det)[0]
+        wer_ctc = word_error_rate(greedy_ctc_decode(log_probs.detach(), encoded_len), refs, det)[0]
+        return wer, wer_ctc
+
     # ------------------------------------------------------------------ training_step (:859-930)
-    def training_step(self, batch, lang_ids, return_probs=False, host_lengths=None):
+    def training_step(self, batch, lang_ids, return_probs=False, host_lengths=None, compute_wer=False):
         """batch = (signal [B,L] f32, signal_len [B] i64, transcript [B,U] i64, transcript_len [B] i64), all on the
         device.  `host_lengths` = (signal_len list, transcript_len list): optional host copies (the collate
-        function has them) that remove the only device->host read the sub-batch loop needs."""
+        function has them) that remove the only device->host read the sub-batch loop needs.
+        `compute_wer`: the reference decodes every training batch greedily for its monitor (compute_wer = True,
+        hybrid_rnnt_ctc_models.py:877-912: one host-driven micro-step loop per frame); here it is opt-in and the monitor
+        carries NaN otherwise (token-level rates unless `self.detokenize` is set, decoding.py)."""
         signal, signal_len, transcript, transcript_len = batch
         language_ids = lang_ids
         if host_lengths is None:
@@ -221,6 +247,9 @@ class EncDecHybridRNNTCTCModel(nn.Module):
         vals = torch.stack([rnnt_only.detach().float(), ctc_loss.detach().float(), loss_value.detach().float()])
         monitor = StepMonitor({'training_batch_wer': torch.tensor(float('nan')), 'training_batch_wer_ctc': float('nan')},
                               ('train_rnnt_loss', 'train_ctc_loss', 'train_loss'), vals)
+        if compute_wer:
+            wer, wer_ctc = self.batch_wer(encoded, encoded_len, log_probs, transcript, transcript_len, language_ids)
+            monitor['training_batch_wer'], monitor['training_batch_wer_ctc'] = wer, wer_ctc
         self._step += 1
         if return_probs:
             return loss_value, monitor, log_probs

@@ -542,3 +542,46 @@ def lwf_kd_loss(loss, prob, prob_, pred_store_list, store_list, kd, kd_ctx):
     rnnt_kd = rnnt_kd / len(store_list)
     total = loss * (1 - kd) + kd * ((1 - kd_ctx) * rnnt_kd + kd_ctx * ctc_kd_loss)
     return total, rnnt_kd, ctc_kd_loss
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Greedy decoding + WER, plain per-utterance restatements for the parity tests.
+def greedy_rnnt_decode_ref(model, encoded, encoded_len, lang, max_symbols=10):
+    """Per-utterance, frame-by-frame restatement of GreedyBatchedRNNTInfer._greedy_decode_blank_as_pad_loop_frames
+    (rnnt_greedy_decoding.py:711-909).  Processing utterances one at a time is equivalent to the batched loop: the
+    per-frame blank mask is sticky per utterance and an utterance's state only advances on its own non-blank symbols.
+    SOS and "no symbol yet" are the zero embedding (blank_as_pad, rnnt.py:524-792)."""
+    dec, joint = model.decoder, model.joint
+    head = joint.joint_net[-1][lang]
+    blank = head.weight.shape[0] - 1
+    H = dec.prediction["embed"].weight.shape[1]
+    out = []
+    with torch.no_grad():
+        for b in range(encoded.shape[0]):
+            f_all = joint.enc(encoded[b].transpose(0, 1).float())                    # [T, Hj]
+            hidden, last, toks = None, None, []
+            for t in range(int(encoded_len[b])):
+                symbols = 0
+                while symbols < max_symbols:
+                    y = torch.zeros(1, 1, H) if last is None else dec.prediction["embed"](torch.tensor([[last]]))
+                    g, hp = dec.prediction["dec_rnn"](y.transpose(0, 1), hidden)      # [1,1,H]
+                    logits = head(torch.relu(f_all[t] + joint.pred(g[0, 0].float())))
+                    k = int(logits.argmax())
+                    if k == blank:
+                        break
+                    toks.append(k); last = k; hidden = hp; symbols += 1
+            out.append(toks)
+    return out
+
+
+def greedy_ctc_decode_ref(log_probs, lengths, blank):
+    out = []
+    for b in range(log_probs.shape[0]):
+        prev, toks = None, []
+        for t in range(int(lengths[b])):
+            k = int(log_probs[b, t].argmax())
+            if k != blank and k != prev:
+                toks.append(k)
+            prev = k
+        out.append(toks)
+    return out

@@ -1,0 +1,91 @@
+"""Greedy decoding + WER: the batched device loop against the per-utterance oracle restatement, the
+CTC collapse rule, and the edit-distance metric on known answers (wer.py:58-60 uses editdistance.eval)."""
+import pytest
+import torch
+
+from oracle import step_ref as S
+
+
+def _models(seed=0):
+    from indic_cl_asr_amd.config import model_config
+    from indic_cl_asr_amd.model import EncDecHybridRNNTCTCModel
+    torch.manual_seed(seed)
+    o = S.OracleHybridModel(d_model=32, n_layers=2, n_heads=4, pred_hidden=24, joint_hidden=24, languages=['hi', 'ta'],
+                            vocab_per_lang=16, fused_batch_size=2)
+    with torch.no_grad():   # make non-blank symbols likely enough to exercise the inner loop
+        for l in ('hi', 'ta'):
+            o.joint.joint_net[-1][l].bias[-1] -= 1.0
+    m = EncDecHybridRNNTCTCModel(model_config('tiny', n_layers=2, compute_dtype='fp32', dither=0.0))
+    m.load_state_dict(o.state_dict())
+    return o.eval(), m.eval()
+
+
+def test_edit_distance_and_wer_known_answers():
+    from indic_cl_asr_amd.decoding import WER, _edit_distance, word_error_rate
+    assert _edit_distance("kitten", "sitting") == 3
+    assert _edit_distance([1, 2, 3], [1, 2, 3]) == 0 and _edit_distance([], [1, 2]) == 2 and _edit_distance([5], []) == 1
+    wer, s, w = word_error_rate([[1, 2, 3], [4]], [[1, 3], [4, 5, 6]])
+    assert (s, w) == (1 + 2, 5) and abs(wer - 0.6) < 1e-12
+    words = {1: "the", 2: "cat", 3: "sat", 4: "mat"}
+    det = lambda ids: " ".join(words[i] for i in ids)
+    m = WER(detokenize=det)
+    m.update([[1, 2, 3]], [[1, 2, 4]]); m.update([[1]], [[1, 2]])
+    assert m.compute() == (2 / 5, 2, 5)
+    m.reset()
+    assert m.compute()[0] == float("inf")
+
+
+def test_greedy_rnnt_matches_per_utterance_oracle_cpu():
+    from indic_cl_asr_amd.decoding import greedy_rnnt_decode
+    o, m = _models()
+    g = torch.Generator().manual_seed(3)
+    enc = torch.randn(4, 32, 23, generator=g)
+    lens = torch.tensor([23, 17, 9, 1])
+    for lang in ('hi', 'ta'):
+        hyp = greedy_rnnt_decode(m, enc, lens, [lang] * 4, max_symbols=3)
+        ref = S.greedy_rnnt_decode_ref(o, enc, lens, lang, max_symbols=3)
+        assert hyp == ref
+        assert any(len(h) > 0 for h in hyp)                 # the test is not vacuous
+        assert max(len(h) for h in hyp) <= 3 * 23
+
+
+def test_greedy_ctc_collapse_rule():
+    from indic_cl_asr_amd.decoding import greedy_ctc_decode
+    g = torch.Generator().manual_seed(5)
+    lp = torch.randn(3, 19, 6, generator=g).log_softmax(-1)
+    lens = torch.tensor([19, 11, 0])
+    assert greedy_ctc_decode(lp, lens) == S.greedy_ctc_decode_ref(lp, lens, blank=5)
+    hand = torch.full((1, 6, 3), -10.0)
+    for t, k in enumerate([0, 0, 2, 1, 1, 0]):              # blank = 2: "0 0 _ 1 1 0" -> 0 1 0
+        hand[0, t, k] = 0.0
+    assert greedy_ctc_decode(hand, torch.tensor([6])) == [[0, 1, 0]]
+
+
+@pytest.mark.gpu
+def test_greedy_rnnt_on_device_matches_oracle():
+    from indic_cl_asr_amd.decoding import greedy_rnnt_decode
+    o, m = _models(seed=1)
+    m = m.cuda()
+    g = torch.Generator().manual_seed(7)
+    enc = torch.randn(5, 32, 31, generator=g)
+    lens = torch.tensor([31, 30, 12, 5, 1])
+    hyp = greedy_rnnt_decode(m, enc.cuda(), lens.cuda(), ['hi'] * 5, max_symbols=4)
+    ref = S.greedy_rnnt_decode_ref(o, enc, lens, 'hi', max_symbols=4)
+    same = sum(h == r for h, r in zip(hyp, ref))
+    assert same >= 4, (hyp, ref)    # fp32 GPU vs CPU argmax ties may flip one path; sequences must agree otherwise
+
+
+@pytest.mark.gpu
+def test_training_step_monitor_carries_batch_wer_when_asked():
+    o, m = _models()
+    m = m.cuda()
+    m.train(); m.spec_augment_enabled = False
+    g = torch.Generator().manual_seed(11)
+    sig = torch.randn(3, 8000, generator=g) * 0.1
+    sl = torch.tensor([8000, 6000, 4000]); tr = torch.randint(0, 16, (3, 6), generator=g); tl = torch.tensor([6, 3, 1])
+    batch = tuple(t.cuda() for t in (sig, sl, tr, tl))
+    loss, mon = m.training_step(batch, ['hi'] * 3, compute_wer=True)
+    for key in ('training_batch_wer', 'training_batch_wer_ctc'):
+        assert isinstance(mon[key], float) and mon[key] >= 0.0 and mon[key] == mon[key]
+    loss2, mon2 = m.training_step(batch, ['hi'] * 3)
+    assert mon2['training_batch_wer_ctc'] != mon2['training_batch_wer_ctc']     # NaN when not requested
