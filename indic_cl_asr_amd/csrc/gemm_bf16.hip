@@ -64,8 +64,14 @@ __global__ __launch_bounds__(G_THREADS, (BM == 128 ? 3 : 4)) void gemm_bf16_nt_k
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, q = lane >> 4;
     const int wm = wave >> 1, wn = wave & 1;
+    // XCD-aware tile order: workgroup ids go round-robin over the 8 XCDs, so the ntn column tiles that share one row
+    // tile of A are given ids congruent mod 8 and consecutive in that XCD's dispatch order -- the A tile is then fetched
+    // into ONE XCD's L2 once instead of into all eight (W is small and lives in every L2).
     const int ntn = (a.N + BN - 1) / BN;
-    const int m0 = (blockIdx.x / ntn) * BM, n0 = (blockIdx.x % ntn) * BN;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int mt = xcd + 8 * (slot / ntn);
+    if (mt * BM >= a.M) return;  // padding workgroups of the last group of 8 row tiles (uniform)
+    const int m0 = mt * BM, n0 = (slot % ntn) * BN;
 
     static_assert(BV == 4 && (AV == 2 || AV == 4), "staging registers are named (arrays end up in scratch)");
     ConvRow crow[4];
@@ -211,7 +217,8 @@ template <int BM, int BN, bool CONV = false>
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
     constexpr int STAGE = (BM + BN) * G_ROWB, EPI = 64 * (BN + 4) * 4;
     const size_t lds = STAGE > EPI ? STAGE : EPI;
-    const int grid = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
+    const int grid = 8 * ((ntm + 7) / 8) * ntn;  // row tiles padded to a multiple of the 8 XCDs (see the kernel's tile order)
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<BM, BN, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return IA_LAUNCH_FAILED;
