@@ -81,10 +81,14 @@ __global__ __launch_bounds__(AT_THREADS, 2) void relpos_attn_kernel(
     const int c = lane & 15, q4 = lane >> 4;
     const int d = H * AT_DK;
     const int nqt = (T + 63) / 64;
-    int bid = blockIdx.x;
-    const int qt = bid % nqt; bid /= nqt;
-    const int h = bid % H;
-    const int b = bid / H;
+    // XCD-aware order: the nqt query tiles of one (utterance, head) read the same K / V^T / position rows; their workgroup
+    // ids are congruent mod 8 (one XCD, consecutive dispatch) so that those rows are fetched into one L2, once
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int bh = xcd + 8 * (slot / nqt);
+    if (bh >= B * H) return;
+    const int qt = slot % nqt;
+    const int h = bh % H;
+    const int b = bh / H;
     const int len = (int)lens[b];
     const int iw = qt * 64 + wave * 16;  // first query of this wave
     // wave-private scratch: the bf16 band [16][AT_LDB] (the reference's autocast holds matrix_bd in 16 bits as well), later
@@ -537,7 +541,7 @@ extern "C" int ia_relpos_attention(const void* qkv, const void* pos_proj, const 
     if (hipFuncSetAttribute((const void*)relpos_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return IA_LAUNCH_FAILED;
     const int nqt = (T + 63) / 64;
-    hipLaunchKernelGGL(relpos_attn_kernel, dim3(B * H * nqt), dim3(AT_THREADS), lds, st, (const __bf16*)qkv,
+    hipLaunchKernelGGL(relpos_attn_kernel, dim3(8 * ((B * H + 7) / 8) * nqt), dim3(AT_THREADS), lds, st, (const __bf16*)qkv,
                        (const __bf16*)pos_proj, (const __bf16*)vt_scratch, bias_u, bias_v, lens, (__bf16*)ctx, B, T, H, Tp,
                        1.0f / sqrtf((float)dk), seed, thr, keep_scale);
     IA_RETURN_IF_LAUNCH_FAILED();
