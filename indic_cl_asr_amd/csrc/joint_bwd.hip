@@ -171,9 +171,10 @@ __global__ __launch_bounds__(256) void joint_dg_finish_kernel(const float* __res
 // The tile goes through LDS as 16-byte chunks whose chunk index is XOR-swizzled with (row >> 3): the transposed read
 // (8 rows x one column per thread, rows 8 apart across neighbouring lanes) then touches 8 different chunks instead of
 // one bank 8 times (16-byte aligned rows make every 8-row stride a multiple of 32 banks).  The next tile's rows and
-// cell scalars are loaded into registers before the barrier, so their latency hides under the transposed write-out.
+// cell scalars are loaded into registers before the barrier, so their latency hides under the transposed write-out;
+// rows are addressed as one flat contiguous region (4 KB per load / store instruction).
 constexpr int GT_CELLS = 64;
-constexpr int GT_NV = 9;  // 16-byte chunks per thread per tile: 4 threads per row, LD/8 <= 36 chunks per row
+constexpr int GT_NV = 9;  // 16-byte chunks per thread per tile: 64 * (LD/8 <= 36) / 256
 __global__ __launch_bounds__(256, 3) void joint_grad_h_t_kernel(_Float16* __restrict__ x, const float4* __restrict__ cs,
                                                              int64_t cells, int LD, int V, int blank, float kappa,
                                                              _Float16* __restrict__ gt, int S, int Kc, int nch) {
@@ -182,41 +183,49 @@ __global__ __launch_bounds__(256, 3) void joint_grad_h_t_kernel(_Float16* __rest
     const _Float16* tileh = reinterpret_cast<const _Float16*>(smem);
     const int vpr = LD / 8;
     const int64_t ntiles = (int64_t)S * (Kc / GT_CELLS);
-    // thread = one tile row (cell) x every 4th chunk of it: a single cell-scalar record per thread
-    const int rr = threadIdx.x >> 2, c4 = threadIdx.x & 3;
+    // the tile's 64 rows are one contiguous LD*128-byte region: thread i takes 16-byte chunks i, i+256, ... of it (every
+    // load / in-place store instruction covers 4 KB of consecutive memory); the 64 cell-scalar records go through LDS
+    float4* scs = reinterpret_cast<float4*>(smem + (size_t)GT_CELLS * nch * 16);   // [GT_CELLS]
+    const int nitems = GT_CELLS * vpr;
+    int rr[GT_NV], cv[GT_NV];
+#pragma unroll
+    for (int k = 0; k < GT_NV; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        rr[k] = (i < nitems) ? i / vpr : -1;
+        cv[k] = (i < nitems) ? i - (i / vpr) * vpr : 0;
+    }
     uint4 px[GT_NV];
-    float4 pc;
+    float4 pc = make_float4(IA_NEG_INF, 0.f, 0.f, 0.f);
 #define GT_LOAD(tile_id_)                                                                                    \
     do {                                                                                                     \
-        const int64_t cell_ = (tile_id_) * GT_CELLS + rr;                                                    \
-        const bool ok_ = cell_ < cells;                                                                      \
-        pc = ok_ ? cs[cell_] : make_float4(IA_NEG_INF, 0.f, 0.f, 0.f);                                       \
-        _Pragma("unroll") for (int k = 0; k < GT_NV; ++k) {                                                  \
-            const int cv_ = c4 + 4 * k;                                                                      \
-            px[k] = (ok_ && cv_ < vpr && pc.x != IA_NEG_INF)                                                 \
-                        ? reinterpret_cast<const uint4*>(x + cell_ * LD)[cv_] : make_uint4(0, 0, 0, 0);      \
-        }                                                                                                    \
+        const int64_t c0_ = (tile_id_) * GT_CELLS;                                                           \
+        if (threadIdx.x < GT_CELLS)                                                                          \
+            pc = (c0_ + threadIdx.x < cells) ? cs[c0_ + threadIdx.x] : make_float4(IA_NEG_INF, 0.f, 0.f, 0.f); \
+        const uint4* src_ = reinterpret_cast<const uint4*>(x + c0_ * LD);                                    \
+        _Pragma("unroll") for (int k = 0; k < GT_NV; ++k)                                                    \
+            px[k] = (rr[k] >= 0 && c0_ + rr[k] < cells) ? src_[threadIdx.x + 256 * k] : make_uint4(0, 0, 0, 0); \
     } while (0)
     int64_t tile_id = blockIdx.x;
     if (tile_id < ntiles) GT_LOAD(tile_id);
     for (; tile_id < ntiles; tile_id += gridDim.x) {
         const int64_t cell0 = tile_id * GT_CELLS;
+        if (threadIdx.x < GT_CELLS) scs[threadIdx.x] = pc;
+        __syncthreads();
         {
-            const float4 sc = pc;
-            const int64_t cell = cell0 + rr;
-            const bool live = sc.x != IA_NEG_INF;
-            const int w = __float_as_int(sc.w);
-            const int lab = (w & 0x7fffffff) - 1;
-            const float sign = (w < 0) ? -kappa : kappa;
+            uint4* dst = reinterpret_cast<uint4*>(x + cell0 * LD);
 #pragma unroll
             for (int k = 0; k < GT_NV; ++k) {
-                const int cvk = c4 + 4 * k;
-                if (cvk >= vpr) continue;
+                if (rr[k] < 0) continue;
+                const float4 sc = scs[rr[k]];
+                const int64_t cell = cell0 + rr[k];
                 union { uint4 u; _Float16 h[8]; } io;
                 io.u = make_uint4(0, 0, 0, 0);
-                if (live) {
+                if (sc.x != IA_NEG_INF) {
                     io.u = px[k];
-                    const int v0 = cvk * 8;
+                    const int w = __float_as_int(sc.w);
+                    const int lab = (w & 0x7fffffff) - 1;
+                    const float sign = (w < 0) ? -kappa : kappa;
+                    const int v0 = cv[k] * 8;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const int v = v0 + j;
@@ -226,8 +235,8 @@ __global__ __launch_bounds__(256, 3) void joint_grad_h_t_kernel(_Float16* __rest
                         io.h[j] = (v < V) ? (_Float16)(g * sign) : (_Float16)0.f;
                     }
                 }
-                if (cell < cells) reinterpret_cast<uint4*>(x + cell * LD)[cvk] = io.u;
-                tile[rr * nch + (cvk ^ ((rr >> 3) & 7))] = io.u;
+                if (cell < cells) dst[threadIdx.x + 256 * k] = io.u;
+                tile[rr[k] * nch + (cv[k] ^ ((rr[k] >> 3) & 7))] = io.u;
             }
         }
         const int64_t next = tile_id + gridDim.x;
@@ -326,8 +335,8 @@ extern "C" int ia_joint_backward_g(void* logits_inout, const int64_t* labels, co
     if (gt_out) {
         const int64_t ntiles = (int64_t)S * (Kc / GT_CELLS);
         const int nch = ((LD / 8) + 7) / 8 * 8;  // chunks per LDS row: room for the XOR-swizzled index
-        if (LD / 8 > 4 * GT_NV) return IA_UNSUPPORTED;
-        const size_t lds = (size_t)GT_CELLS * nch * 16;
+        if (GT_CELLS * (LD / 8) > 256 * GT_NV) return IA_UNSUPPORTED;
+        const size_t lds = (size_t)GT_CELLS * nch * 16 + GT_CELLS * sizeof(float4);
         hipLaunchKernelGGL(joint_grad_h_t_kernel, dim3((unsigned)(ntiles < 16384 ? ntiles : 16384)), dim3(256), lds, st,
                            (_Float16*)logits_inout, (const float4*)(ws + w.off_cs), cells, LD, V, blank, kappa,
                            (_Float16*)gt_out, S, Kc, nch);
