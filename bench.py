@@ -69,9 +69,11 @@ class HipEvents:
         assert self.hip.hipEventCreate(ctypes.byref(e)) == 0
         return e
 
-    def hook(self, B, T, U1, V, elem_bytes=4, passes=2):
-        """passes = lattice-sized streams the kernel must move: fp32 path read logits + write grads (2);
-        fused f16 path read logits + write G in place + write G^T for the split-K weight-gradient GEMM (3)."""
+    def hook(self, B, T, U1, V, elem_bytes=4, passes=2, kernel=None):
+        """passes = lattice-sized streams the kernel must move: read logits + write grads (2); the
+        library-GEMM fallback of the f16 path also writes G^T for the split-K weight-gradient GEMM (3)."""
+        if kernel is not None:
+            self.kernel_name = kernel
         if not self.enabled:
             return None
         a, b = self._new(), self._new()
@@ -168,8 +170,6 @@ def main():
 
     events = HipEvents()
     rnnt_mod.PROFILE_HOOK = events.hook
-    if model.joint.use_fused and args.dtype == "bf16":
-        events.kernel_name = "joint_grad_h_t_kernel"  # the fused path's f16 gradient kernel (in place + transposed copy)
 
     def step():
         opt.zero_grad()

@@ -118,8 +118,13 @@ int ia_rnnt_lattice(const int64_t* act_lens, const int64_t* label_lens, int B, i
                     int need_backward, float* costs, void* workspace, size_t workspace_bytes, ia_stream_t stream);
 int ia_joint_backward_g(void* logits_inout, const int64_t* labels, const int64_t* act_lens, const int64_t* label_lens,
                         int B, int T, int U1, int V, int LD, int blank, float fastemit_lambda, const float* cost_grad,
-                        float kappa, void* gt_out, int S, int Kc, void* workspace, size_t workspace_bytes,
-                        ia_stream_t stream, void* grad_kernel_start_event, void* grad_kernel_stop_event);
+                        float kappa, void* gt_out, int S, int Kc, float* dbias_out, float* dbias_scratch, void* workspace,
+                        size_t workspace_bytes, ia_stream_t stream, void* grad_kernel_start_event,
+                        void* grad_kernel_stop_event);
+/* dbias_out (optional, NULL to skip; only with gt_out == NULL): receives sum_cells G[cell, v] for v < LD (f32, un-scaled:
+ * the bias gradient of the per-language head times kappa), accumulated by the gradient kernel itself in registers;
+ * dbias_scratch = ia_joint_backward_g_dbias_scratch_elems(LD) floats of per-workgroup partial rows. */
+int64_t ia_joint_backward_g_dbias_scratch_elems(int LD);
 /* gt_out (optional, NULL to skip): additionally receives G transposed in the chunked K-contiguous layout
  * GT[s][v][kc] f16 (S chunks of Kc cells, Kc % 64 == 0, S*Kc >= B*T*U1, cells beyond the lattice zero), the A operand
  * of the split-K weight-gradient GEMM  dW[v,h] = sum_s GT[s] @ HT[s]^T  with HT from ia_joint_hidden_t:
@@ -145,6 +150,19 @@ size_t ia_joint_dh_fused_scratch_bytes(int B, int T, int U1, int H);
 int ia_joint_dh_fused(const void* G, const void* Wt, const void* f, const void* g, const int64_t* act_lens,
                       const int64_t* label_lens, float* df, float* dg, int B, int T, int U1, int H, int LD,
                       float inv_kappa, float dropout_p, unsigned seed, void* scratch, ia_stream_t stream);
+/* ia_joint_dw_fused: weight gradient of the per-language Linear(H -> V) of the joint (A/modules/rnnt.py:1694-1703,
+ * applied in joint_after_projection :1633-1647) straight from G and the encoder / prediction projections:
+ *   dW[v*H + h] = sum_cells G[cell,v] * keep*relu(f[b,t,h] + g[b,u,h])          ([LD, H] f32)
+ * (un-scaled: the caller divides by kappa and the dropout keep probability; the bias gradient comes from
+ * ia_joint_backward_g's dbias_out).  The hidden tensor is regenerated tile by
+ * tile in LDS (same counter-based dropout mask as the forward), so neither hidden^T nor a transposed copy of G exists.
+ * Split-K over the lattice cells: partial tiles in `scratch` (ia_joint_dw_fused_scratch_elems floats) + a finishing sum.
+ * The steps are laid out per utterance and the utterance's prediction rows g[b, :, tile] stay resident in LDS.
+ * Supported when ia_joint_dw_fused_supported(U1, H, LD): U1 <= 128, H % 8 == 0, LD % 8 == 0, LD <= 288; B*T*U1 < 2^31. */
+int ia_joint_dw_fused_supported(int U1, int H, int LD);
+int64_t ia_joint_dw_fused_scratch_elems(int B, int T, int U1, int H, int LD);
+int ia_joint_dw_fused(const void* G, const void* f, const void* g, int B, int T, int U1, int H, int LD, float dropout_p,
+                      unsigned seed, float* dW, float* scratch, ia_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Conformer block forward building blocks (bf16 projections, fp32 residual stream).

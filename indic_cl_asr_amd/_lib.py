@@ -9,7 +9,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libindicasr_hip.so")
+LIB_PATH = os.environ.get("IA_LIB_PATH") or os.path.join(_HERE, "libindicasr_hip.so")  # IA_LIB_PATH: developer override
 
 IA_OK = 0
 _STATUS = {-1: "IA_INVALID_VALUE", -2: "IA_WORKSPACE_TOO_SMALL", -3: "IA_LAUNCH_FAILED", -4: "IA_UNSUPPORTED"}
@@ -40,7 +40,9 @@ SIGNATURES = {
     "ia_joint_ld": (_i, [_i]),
     "ia_joint_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _c.c_uint, _vp, _i, _vp, _sz, _vp]),
     "ia_rnnt_lattice": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _sz, _vp]),
-    "ia_joint_backward_g": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _f, _vp, _i, _i, _vp, _sz, _vp, _vp, _vp]),
+    "ia_joint_backward_g": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _f, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp,
+                                 _vp]),
+    "ia_joint_backward_g_dbias_scratch_elems": (_i64, [_i]),
     "ia_joint_hidden_t": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _c.c_uint, _vp]),
     "ia_joint_hidden": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _c.c_uint, _vp]),
     "ia_joint_dh_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _c.c_uint, _vp, _vp]),
@@ -49,6 +51,9 @@ SIGNATURES = {
     "ia_joint_dh_k": (_i, []),
     "ia_joint_dh_fused": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _c.c_uint, _vp, _vp]),
     "ia_joint_dh_fused_scratch_bytes": (_sz, [_i, _i, _i, _i]),
+    "ia_joint_dw_fused_supported": (_i, [_i, _i, _i]),
+    "ia_joint_dw_fused_scratch_elems": (_i64, [_i, _i, _i, _i, _i]),
+    "ia_joint_dw_fused": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _c.c_uint, _vp, _vp, _vp]),
     "ia_gemm_bf16": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _f, _c.c_uint, _f, _vp, _i, _vp, _i, _vp, _i, _vp]),
     "ia_subsample_conv1": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ia_subsample_conv2": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),

@@ -9,6 +9,7 @@
 //   joint_dh_reduce ..... one pass over dHidden: apply the relu/dropout mask (recomputed from f,g), unscale, and reduce
 //                         over u -> d f[b,t,:] (registers) and over t -> d g[b,u,:] (16-frame partial rows + a finishing sum).
 #include "joint_common.h"
+#include "partials.h"
 #include "rnnt_ws.h"
 
 namespace {
@@ -257,6 +258,119 @@ __global__ __launch_bounds__(256, 3) void joint_grad_h_t_kernel(_Float16* __rest
 #undef GT_LOAD
 }
 
+// The in-place gradient kernel of the fused weight-gradient path (joint_dw.hip needs no transposed copy): persistent
+// workgroups over flat 64-cell tiles -- the tile's rows are one contiguous LD*128-byte region, thread i owns its 16-byte
+// chunks i, i+256, ... (every load / store instruction covers 4 KB of consecutive memory); the next tile's rows and cell
+// records are in flight while the current one is computed.  Because 64*(LD/8) is a multiple of LD/8, chunk k of a
+// thread holds the SAME eight vocabulary columns in every tile: the bias gradient db[v] = sum_cells G[cell,v] is a
+// per-thread register accumulation (unrounded f32), folded per workgroup through LDS into one partial row + a finishing sum.
+constexpr int GD_MAX_WG = 512;   // 2 workgroups per CU resident: one round
+__global__ __launch_bounds__(256, 2) void joint_grad_h_db_kernel(_Float16* __restrict__ x, const float4* __restrict__ cs,
+                                                                 int64_t cells, int LD, int V, int blank, float kappa,
+                                                                 float* __restrict__ db_part) {
+    __shared__ float4 scs[2][GT_CELLS];
+    __shared__ __attribute__((aligned(16))) float red[3 * 256 * 8];
+    const int vpr = LD / 8;
+    const int64_t ntiles = (cells + GT_CELLS - 1) / GT_CELLS;
+    const int nitems = GT_CELLS * vpr;
+    const int tid = threadIdx.x;
+    int rr[GT_NV], cv[GT_NV];
+#pragma unroll
+    for (int k = 0; k < GT_NV; ++k) {
+        const int i = tid + 256 * k;
+        rr[k] = (i < nitems) ? i / vpr : -1;
+        cv[k] = (i < nitems) ? i - (i / vpr) * vpr : 0;
+    }
+    float dbacc[GT_NV][8];
+#pragma unroll
+    for (int k = 0; k < GT_NV; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dbacc[k][j] = 0.f;
+    uint4 px[GT_NV];
+    float4 pc = make_float4(IA_NEG_INF, 0.f, 0.f, 0.f);
+    int64_t tile_id = blockIdx.x;
+    int par = 0;
+    if (tile_id < ntiles) {
+        const int64_t c0 = tile_id * GT_CELLS, left = cells - c0;
+        const int nv = (int)(left < GT_CELLS ? left : GT_CELLS) * vpr;   // >= vpr
+        if (tid < GT_CELLS) pc = cs[c0 + (tid < left ? tid : 0)];
+        const uint4* src = reinterpret_cast<const uint4*>(x + c0 * LD);
+#pragma unroll
+        for (int k = 0; k < GT_NV; ++k) px[k] = src[tid + 256 * k < nv ? tid + 256 * k : nv - 1];
+    }
+    for (; tile_id < ntiles; tile_id += gridDim.x, par ^= 1) {
+        const int64_t cell0 = tile_id * GT_CELLS;
+        if (tid < GT_CELLS) scs[par][tid] = pc;
+        __syncthreads();   // one barrier per tile: the record buffer alternates
+        // the next tile of this workgroup (the last one is re-read once: the loop stays branch-free); chunk k's successor
+        // is requested as soon as chunk k has been consumed, so no second register set is needed
+        int64_t next = tile_id + gridDim.x;
+        next = next < ntiles ? next : tile_id;
+        const int64_t n0 = next * GT_CELLS, nleft = cells - n0;
+        const int nnv = (int)(nleft < GT_CELLS ? nleft : GT_CELLS) * vpr;
+        const uint4* nsrc = reinterpret_cast<const uint4*>(x + n0 * LD);
+        if (tid < GT_CELLS) pc = cs[n0 + (tid < nleft ? tid : 0)];
+        uint4* dst = reinterpret_cast<uint4*>(x + cell0 * LD);
+#pragma unroll
+        for (int k = 0; k < GT_NV; ++k) {
+            if (rr[k] < 0) continue;
+            const float4 sc = scs[par][rr[k]];
+            const int64_t cell = cell0 + rr[k];
+            union { uint4 u; _Float16 h[8]; } io;
+            io.u = px[k];
+            px[k] = nsrc[tid + 256 * k < nnv ? tid + 256 * k : nnv - 1];
+            const bool live = sc.x != IA_NEG_INF && cell < cells;
+            const int w = __float_as_int(sc.w);
+            const int lab = (w & 0x7fffffff) - 1;
+            const float sign = (w < 0) ? -kappa : kappa;
+            const float c0 = live ? sc.x : 0.f;
+            const int v0 = cv[k] * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int v = v0 + j;
+                float g = __expf((float)io.h[j] + c0);
+                if (v == blank) g -= sc.y;
+                if (v == lab) g -= sc.z;
+                g = (v < V && live) ? g * sign : 0.f;   // (exp of a dead cell's logit may overflow: select, never multiply)
+                dbacc[k][j] += g;
+                io.h[j] = (_Float16)g;
+            }
+            if (cell < cells) dst[tid + 256 * k] = io.u;
+        }
+    }
+    // fold the per-thread column sums: three rounds of three chunk slots through LDS, thread c owns columns c, c + 256
+    float colsum[2] = {0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+            float4* dstp = reinterpret_cast<float4*>(red + ((size_t)kk * 256 + tid) * 8);
+            const int k = 3 * r + kk;
+            dstp[0] = make_float4(dbacc[k][0], dbacc[k][1], dbacc[k][2], dbacc[k][3]);
+            dstp[1] = make_float4(dbacc[k][4], dbacc[k][5], dbacc[k][6], dbacc[k][7]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const int col = tid + 256 * o;
+            if (col >= LD) continue;
+            const int cc = col >> 3, j = col & 7;
+            for (int kk = 0; kk < 3; ++kk) {
+                const int k = 3 * r + kk;
+                int first = (cc - 256 * k) % vpr;       // owners of column chunk cc in slot k: first, first + vpr, ...
+                if (first < 0) first += vpr;
+                for (int t = first; t < 256 && t + 256 * k < nitems; t += vpr) colsum[o] += red[((size_t)kk * 256 + t) * 8 + j];
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+        const int col = tid + 256 * o;
+        if (col < LD) db_part[(size_t)blockIdx.x * LD + col] = colsum[o];
+    }
+}
+
 // hidden^T in the same chunked layout: HT[s][hh][kc], hh < H: keep*relu(f+g); hh == H: 1; else 0.
 template <bool DROPOUT>
 __global__ __launch_bounds__(256) void joint_hidden_t_kernel(const _Float16* __restrict__ f, const _Float16* __restrict__ g,
@@ -311,13 +425,19 @@ inline int grid_for(int64_t nvec) {
     int64_t b = (nvec + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
 }
+inline int gd_grid(int64_t cells) {
+    const int64_t ntiles = (cells + GT_CELLS - 1) / GT_CELLS;
+    return (int)(ntiles < GD_MAX_WG ? ntiles : GD_MAX_WG);
+}
 }  // namespace
+
+extern "C" int64_t ia_joint_backward_g_dbias_scratch_elems(int LD) { return LD > 0 ? (int64_t)GD_MAX_WG * LD : 0; }
 
 extern "C" int ia_joint_backward_g(void* logits_inout, const int64_t* labels, const int64_t* act_lens,
                                    const int64_t* label_lens, int B, int T, int U1, int V, int LD, int blank,
                                    float fastemit, const float* cost_grad, float kappa, void* gt_out, int S, int Kc,
-                                   void* workspace, size_t workspace_bytes, ia_stream_t stream, void* ev_start,
-                                   void* ev_stop) {
+                                   float* dbias_out, float* dbias_scratch, void* workspace, size_t workspace_bytes,
+                                   ia_stream_t stream, void* ev_start, void* ev_stop) {
     if (!logits_inout || !act_lens || !label_lens || !workspace || B <= 0 || T <= 0 || U1 <= 0) return IA_INVALID_VALUE;
     if (LD < V || LD % 8 != 0 || !ia_is_aligned(logits_inout, 16) || !ia_is_aligned(workspace, 256) || !(kappa > 0.f))
         return IA_INVALID_VALUE;
@@ -331,6 +451,8 @@ extern "C" int ia_joint_backward_g(void* logits_inout, const int64_t* labels, co
     if (rc != IA_OK) return rc;
     if (gt_out && (S <= 0 || Kc <= 0 || Kc % GT_CELLS != 0 || (int64_t)S * Kc < cells || !ia_is_aligned(gt_out, 16)))
         return IA_INVALID_VALUE;
+    if (dbias_out && (gt_out || !dbias_scratch || !ia_is_aligned(dbias_scratch, 16))) return IA_INVALID_VALUE;
+    if (dbias_out && (LD > 512 || GT_CELLS * (LD / 8) > 256 * GT_NV)) return IA_UNSUPPORTED;
     if (ev_start && hipEventRecord((hipEvent_t)ev_start, st) != hipSuccess) return IA_LAUNCH_FAILED;
     if (gt_out) {
         const int64_t ntiles = (int64_t)S * (Kc / GT_CELLS);
@@ -340,6 +462,15 @@ extern "C" int ia_joint_backward_g(void* logits_inout, const int64_t* labels, co
         hipLaunchKernelGGL(joint_grad_h_t_kernel, dim3((unsigned)(ntiles < 16384 ? ntiles : 16384)), dim3(256), lds, st,
                            (_Float16*)logits_inout, (const float4*)(ws + w.off_cs), cells, LD, V, blank, kappa,
                            (_Float16*)gt_out, S, Kc, nch);
+    } else if (dbias_out) {
+        const int grid = gd_grid(cells);
+        hipLaunchKernelGGL(joint_grad_h_db_kernel, dim3(grid), dim3(256), 0, st, (_Float16*)logits_inout,
+                           (const float4*)(ws + w.off_cs), cells, LD, V, blank, kappa, dbias_scratch);
+        IA_RETURN_IF_LAUNCH_FAILED();
+        if (ev_stop && hipEventRecord((hipEvent_t)ev_stop, st) != hipSuccess) return IA_LAUNCH_FAILED;
+        ia_partials_finish(dbias_scratch, grid, LD, LD, dbias_out, nullptr, st);
+        IA_RETURN_IF_LAUNCH_FAILED();
+        return IA_OK;
     } else {
         hipLaunchKernelGGL(joint_grad_h_kernel, dim3(grid_for(cells * (LD / 8))), dim3(256), 0, st, (_Float16*)logits_inout,
                            (const float4*)(ws + w.off_cs), cells, LD, V, blank, kappa);

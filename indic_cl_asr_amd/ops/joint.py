@@ -15,6 +15,9 @@ JOINT_MAX_V = 272
 # csrc/joint_dh.hip fuses the dH GEMM with its mask and reductions (1.4 ms against 1.4 + 0.6 ms for the library GEMM +
 # ia_joint_dh_reduce at bs32 x 15 s); False selects the unfused path (also the fallback for H % 80 != 0).
 USE_FUSED_DH = True
+# csrc/joint_dw.hip regenerates the hidden tile in LDS and contracts it with G row-major (transposing LDS reads): no
+# hidden^T tensor, no transposed copy of G.  False selects hidden^T + the batched split-K library GEMM.
+USE_FUSED_DW = True
 
 
 def fused_joint_supported(H, V, device):
@@ -71,17 +74,26 @@ class _FusedJointRNNT(torch.autograd.Function):
         ctx.saved = None
         dev = f16.device
         cg = gcosts.reshape(-1).float().contiguous()
-        hook = rl.PROFILE_HOOK(B, T, U1, V, 2, 3) if rl.PROFILE_HOOK is not None else None
-        ev0, ev1 = hook if hook is not None else (None, None)
-        # split-K layout for the weight gradient: S chunks of Kc lattice cells, both GEMM operands K-contiguous
         cells = B * T * U1
-        S = 64
-        Kc = ((cells + S - 1) // S + 63) // 64 * 64
-        LDH = H + 8
-        GT = torch.empty(S, LD, Kc, dtype=torch.float16, device=dev)
+        fused_dw = USE_FUSED_DW and cells < 2 ** 31 and L.ia_joint_dw_fused_supported(U1, H, LD)
+        GT, S, Kc = None, 0, 0
+        if not fused_dw:
+            # split-K layout for the library weight-gradient GEMM: S chunks of Kc lattice cells, both operands K-contiguous
+            S = 64
+            Kc = ((cells + S - 1) // S + 63) // 64 * 64
+            LDH = H + 8
+            GT = torch.empty(S, LD, Kc, dtype=torch.float16, device=dev)
+        hook = None
+        if rl.PROFILE_HOOK is not None:   # bench.py: HIP events around the gradient kernel on its launch stream
+            hook = rl.PROFILE_HOOK(B, T, U1, V, 2, 2 if fused_dw else 3, "joint_grad_h_db_kernel" if fused_dw else "joint_grad_h_t_kernel")
+        ev0, ev1 = hook if hook is not None else (None, None)
+        dbk = dbscr = None
+        if fused_dw:   # the gradient kernel also returns kappa * dbias (register column sums, partial rows in dbscr)
+            dbk = torch.empty(LD, dtype=torch.float32, device=dev)
+            dbscr = torch.empty(L.ia_joint_backward_g_dbias_scratch_elems(LD), dtype=torch.float32, device=dev)
         st = L.ia_joint_backward_g(_lib.ptr(logits), _lib.ptr(labels), _lib.ptr(act_lens), _lib.ptr(label_lens), B, T, U1, V,
-                                   LD, blank, fastemit, _lib.ptr(cg), kappa, _lib.ptr(GT), S, Kc, _lib.ptr(ws), nbytes,
-                                   _lib.stream_ptr(), ev0, ev1)
+                                   LD, blank, fastemit, _lib.ptr(cg), kappa, _lib.ptr(GT), S, Kc, _lib.ptr(dbk), _lib.ptr(dbscr),
+                                   _lib.ptr(ws), nbytes, _lib.stream_ptr(), ev0, ev1)
         _lib.check(st, "ia_joint_backward_g")
         G = logits  # [cells, LD] f16, = kappa * dL/dlogits
         df = torch.zeros(B, T, H, dtype=torch.float32, device=dev)
@@ -103,13 +115,23 @@ class _FusedJointRNNT(torch.autograd.Function):
                                       _lib.stream_ptr())
             _lib.check(st, "ia_joint_dh_reduce")
             del dH
-        HT = torch.empty(S, LDH, Kc, dtype=torch.float16, device=dev)
-        st = L.ia_joint_hidden_t(_lib.ptr(f16), _lib.ptr(g16), _lib.ptr(HT), B, T, U1, H, LDH, S, Kc, p, seed, _lib.stream_ptr())
-        _lib.check(st, "ia_joint_hidden_t")
-        # dW (+dbias in column H): batched split-K library GEMM over the chunks, f32 partials summed
-        dWx = torch.bmm(GT, HT.transpose(1, 2), out_dtype=torch.float32).sum(0)  # [LD, LDH]
-        dW = dWx[:V, :H] * (1.0 / (kappa * (1.0 - p)))
-        db = dWx[:V, H] * (1.0 / kappa)
+        if fused_dw:
+            dWk = torch.empty(LD, H, dtype=torch.float32, device=dev)
+            scr = torch.empty(L.ia_joint_dw_fused_scratch_elems(B, T, U1, H, LD), dtype=torch.float32, device=dev)
+            st = L.ia_joint_dw_fused(_lib.ptr(G), _lib.ptr(f16), _lib.ptr(g16), B, T, U1, H, LD, p, seed, _lib.ptr(dWk),
+                                     _lib.ptr(scr), _lib.stream_ptr())
+            _lib.check(st, "ia_joint_dw_fused")
+            dW = dWk[:V] * (1.0 / (kappa * (1.0 - p)))
+            db = dbk[:V] * (1.0 / kappa)
+        else:
+            HT = torch.empty(S, LDH, Kc, dtype=torch.float16, device=dev)
+            st = L.ia_joint_hidden_t(_lib.ptr(f16), _lib.ptr(g16), _lib.ptr(HT), B, T, U1, H, LDH, S, Kc, p, seed,
+                                     _lib.stream_ptr())
+            _lib.check(st, "ia_joint_hidden_t")
+            # dW (+dbias in column H): batched split-K library GEMM over the chunks, f32 partials summed
+            dWx = torch.bmm(GT, HT.transpose(1, 2), out_dtype=torch.float32).sum(0)  # [LD, LDH]
+            dW = dWx[:V, :H] * (1.0 / (kappa * (1.0 - p)))
+            db = dWx[:V, H] * (1.0 / kappa)
         return df.to(fdt), dg.to(gdt), dW.to(wdt), db.to(bdt), None, None, None, None, None, None, None, None
 
 

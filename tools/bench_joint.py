@@ -5,6 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from indic_cl_asr_amd.ops import joint as J
 from indic_cl_asr_amd.ops.joint import fused_joint_rnnt
+if os.environ.get('IA_FUSED_DW'):
+    J.USE_FUSED_DW = os.environ['IA_FUSED_DW'] == '1'
 if os.environ.get('IA_FUSED_DH'):
     J.USE_FUSED_DH = os.environ['IA_FUSED_DH'] == '1'
 

@@ -1,0 +1,19 @@
+"""Developer timing of ia_joint_dw_fused alone (random operands) at BASELINE config-2 shapes; IA_LIB_PATH selects a build."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from indic_cl_asr_amd import _lib
+L = _lib.lib()
+B, T, U1, H, LD, p = 32, 376, 106, 640, 264, 0.2
+G = (torch.randn(B * T * U1, LD, device="cuda") * 0.01).half()
+f = torch.randn(B, T, H, device="cuda").half(); g = torch.randn(B, U1, H, device="cuda").half()
+dW = torch.empty(LD, H, device="cuda")
+scr = torch.empty(L.ia_joint_dw_fused_scratch_elems(B, T, U1, H, LD), device="cuda")
+def run():
+    _lib.check(L.ia_joint_dw_fused(_lib.ptr(G), _lib.ptr(f), _lib.ptr(g), B, T, U1, H, LD, p, 7, _lib.ptr(dW), _lib.ptr(scr), _lib.stream_ptr()), "dw")
+run(); torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10): run()
+e1.record(); torch.cuda.synchronize()
+print(os.environ.get("IA_LIB_PATH", "default"), f"{e0.elapsed_time(e1) / 10:.3f} ms")
