@@ -92,7 +92,7 @@ int ia_rnnt_export_alphas_betas(const void* workspace, size_t workspace_bytes, c
  *
  *   f [B,T,H] f16 (encoder projection), g [B,U1,H] f16 (prediction projection), W [272,H] f16 (rows >= V zero; the
  *   caller pre-multiplies by 1/(1-dropout_p)), bias [V] f32.  Limits: V <= 272, H % 64 == 0 (IA_UNSUPPORTED else).
- *   logits out: [B*T*U1, LD] f16, LD = ia_joint_ld(V) (row stride in elements, 16-byte rows, columns >= V zero);
+ *   logits out: [B*T*U1, LD] f16, LD = ia_joint_ld(V) (row stride in elements, 16-byte rows, columns >= V hold -65504: exp() of them is exactly 0);
  *               rows outside an utterance's valid lattice are left untouched.
  *   workspace : same layout/size as ia_rnnt_workspace_bytes(B,T,U1); receives the denominators and the
  *               diagonal-major blank/label log-prob side arrays, i.e. exactly the state ia_rnnt_forward's first

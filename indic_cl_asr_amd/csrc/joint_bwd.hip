@@ -264,29 +264,32 @@ __global__ __launch_bounds__(256, 3) void joint_grad_h_t_kernel(_Float16* __rest
 // records are in flight while the current one is computed.  Because 64*(LD/8) is a multiple of LD/8, chunk k of a
 // thread holds the SAME eight vocabulary columns in every tile: the bias gradient db[v] = sum_cells G[cell,v] is a
 // per-thread register accumulation (unrounded f32), folded per workgroup through LDS into one partial row + a finishing sum.
-constexpr int GD_MAX_WG = 512;   // 2 workgroups per CU resident: one round
-__global__ __launch_bounds__(256, 2) void joint_grad_h_db_kernel(_Float16* __restrict__ x, const float4* __restrict__ cs,
-                                                                 int64_t cells, int LD, int V, int blank, float kappa,
-                                                                 float* __restrict__ db_part) {
+// Relies on the forward kernel's padding: logits columns >= V hold -65504, so their gradient is exactly 0 without a mask.
+constexpr int GD_MAX_WG = 512;   // 2 workgroups of 512 threads per CU resident: one round
+constexpr int GD_THREADS = 512;
+constexpr int GD_NV = 5;         // 16-byte chunks per thread per tile: ceil(64 * (LD/8 <= 36) / 512); 40 accumulators per thread
+__global__ __launch_bounds__(GD_THREADS, 4) void joint_grad_h_db_kernel(_Float16* __restrict__ x, const float4* __restrict__ cs,
+                                                                        int64_t cells, int LD, int V, int blank, float kappa,
+                                                                        float* __restrict__ db_part) {
     __shared__ float4 scs[2][GT_CELLS];
-    __shared__ __attribute__((aligned(16))) float red[3 * 256 * 8];
+    __shared__ __attribute__((aligned(16))) float red[GD_THREADS * 8];
     const int vpr = LD / 8;
     const int64_t ntiles = (cells + GT_CELLS - 1) / GT_CELLS;
     const int nitems = GT_CELLS * vpr;
     const int tid = threadIdx.x;
-    int rr[GT_NV], cv[GT_NV];
+    int rr[GD_NV], cv[GD_NV];
 #pragma unroll
-    for (int k = 0; k < GT_NV; ++k) {
-        const int i = tid + 256 * k;
+    for (int k = 0; k < GD_NV; ++k) {
+        const int i = tid + GD_THREADS * k;
         rr[k] = (i < nitems) ? i / vpr : -1;
         cv[k] = (i < nitems) ? i - (i / vpr) * vpr : 0;
     }
-    float dbacc[GT_NV][8];
+    float dbacc[GD_NV][8];
 #pragma unroll
-    for (int k = 0; k < GT_NV; ++k)
+    for (int k = 0; k < GD_NV; ++k)
 #pragma unroll
         for (int j = 0; j < 8; ++j) dbacc[k][j] = 0.f;
-    uint4 px[GT_NV];
+    uint4 px[GD_NV];
     float4 pc = make_float4(IA_NEG_INF, 0.f, 0.f, 0.f);
     int64_t tile_id = blockIdx.x;
     int par = 0;
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void joint_grad_h_db_kernel(_Float16* __res
         if (tid < GT_CELLS) pc = cs[c0 + (tid < left ? tid : 0)];
         const uint4* src = reinterpret_cast<const uint4*>(x + c0 * LD);
 #pragma unroll
-        for (int k = 0; k < GT_NV; ++k) px[k] = src[tid + 256 * k < nv ? tid + 256 * k : nv - 1];
+        for (int k = 0; k < GD_NV; ++k) px[k] = src[tid + GD_THREADS * k < nv ? tid + GD_THREADS * k : nv - 1];
     }
     for (; tile_id < ntiles; tile_id += gridDim.x, par ^= 1) {
         const int64_t cell0 = tile_id * GT_CELLS;
@@ -312,63 +315,52 @@ __global__ __launch_bounds__(256, 2) void joint_grad_h_db_kernel(_Float16* __res
         if (tid < GT_CELLS) pc = cs[n0 + (tid < nleft ? tid : 0)];
         uint4* dst = reinterpret_cast<uint4*>(x + cell0 * LD);
 #pragma unroll
-        for (int k = 0; k < GT_NV; ++k) {
+        for (int k = 0; k < GD_NV; ++k) {
             if (rr[k] < 0) continue;
             const float4 sc = scs[par][rr[k]];
             const int64_t cell = cell0 + rr[k];
             union { uint4 u; _Float16 h[8]; } io;
             io.u = px[k];
-            px[k] = nsrc[tid + 256 * k < nnv ? tid + 256 * k : nnv - 1];
+            px[k] = nsrc[tid + GD_THREADS * k < nnv ? tid + GD_THREADS * k : nnv - 1];
+            // dead cells: exponent offset -inf and zero subtrahends -> exactly 0; columns >= V hold the forward's -65504
+            // padding -> exp2 underflows to exactly 0: no per-element mask
             const bool live = sc.x != IA_NEG_INF && cell < cells;
             const int w = __float_as_int(sc.w);
-            const int lab = (w & 0x7fffffff) - 1;
             const float sign = (w < 0) ? -kappa : kappa;
-            const float c0 = live ? sc.x : 0.f;
+            const float c0l = live ? sc.x * 1.44269504088896f : IA_NEG_INF;   // exp(x + c0) = exp2(x * log2e + c0 * log2e)
+            const float yy = live ? sc.y : 0.f, zz = live ? sc.z : 0.f;
+            if (!live) io.u = make_uint4(0, 0, 0, 0);   // (the forward leaves cells outside the lattice unwritten)
             const int v0 = cv[k] * 8;
+            const int d = (w & 0x7fffffff) - 1 - v0;   // position of the label / blank column inside this chunk (or outside 0..7)
+            int e = blank - v0;
+            asm volatile("" : "+v"(e));                // (loop-invariant: keep the 40 compare masks out of scalar registers)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int v = v0 + j;
-                float g = __expf((float)io.h[j] + c0);
-                if (v == blank) g -= sc.y;
-                if (v == lab) g -= sc.z;
-                g = (v < V && live) ? g * sign : 0.f;   // (exp of a dead cell's logit may overflow: select, never multiply)
+                const float sub = (d == j) ? zz : ((e == j) ? yy : 0.f);
+                const float g = (__builtin_amdgcn_exp2f(__builtin_fmaf((float)io.h[j], 1.44269504088896f, c0l)) - sub) * sign;
                 dbacc[k][j] += g;
                 io.h[j] = (_Float16)g;
             }
-            if (cell < cells) dst[tid + 256 * k] = io.u;
+            if (cell < cells) dst[tid + GD_THREADS * k] = io.u;
         }
     }
-    // fold the per-thread column sums: three rounds of three chunk slots through LDS, thread c owns columns c, c + 256
-    float colsum[2] = {0.f, 0.f};
+    // fold the per-thread column sums: one round per chunk slot through LDS, thread c owns column c
+    float colsum = 0.f;
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
+    for (int k = 0; k < GD_NV; ++k) {
         __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < 3; ++kk) {
-            float4* dstp = reinterpret_cast<float4*>(red + ((size_t)kk * 256 + tid) * 8);
-            const int k = 3 * r + kk;
-            dstp[0] = make_float4(dbacc[k][0], dbacc[k][1], dbacc[k][2], dbacc[k][3]);
-            dstp[1] = make_float4(dbacc[k][4], dbacc[k][5], dbacc[k][6], dbacc[k][7]);
-        }
+        float4* dstp = reinterpret_cast<float4*>(red + (size_t)tid * 8);
+        dstp[0] = make_float4(dbacc[k][0], dbacc[k][1], dbacc[k][2], dbacc[k][3]);
+        dstp[1] = make_float4(dbacc[k][4], dbacc[k][5], dbacc[k][6], dbacc[k][7]);
         __syncthreads();
-#pragma unroll
-        for (int o = 0; o < 2; ++o) {
-            const int col = tid + 256 * o;
-            if (col >= LD) continue;
-            const int cc = col >> 3, j = col & 7;
-            for (int kk = 0; kk < 3; ++kk) {
-                const int k = 3 * r + kk;
-                int first = (cc - 256 * k) % vpr;       // owners of column chunk cc in slot k: first, first + vpr, ...
-                if (first < 0) first += vpr;
-                for (int t = first; t < 256 && t + 256 * k < nitems; t += vpr) colsum[o] += red[((size_t)kk * 256 + t) * 8 + j];
-            }
+        if (tid < LD) {
+            const int cc = tid >> 3, j = tid & 7;
+            int first = (cc - GD_THREADS * k) % vpr;       // owners of column chunk cc in slot k: first, first + vpr, ...
+            if (first < 0) first += vpr;
+            for (int t = first; t < GD_THREADS && t + GD_THREADS * k < nitems; t += vpr) colsum += red[(size_t)t * 8 + j];
         }
     }
-#pragma unroll
-    for (int o = 0; o < 2; ++o) {
-        const int col = tid + 256 * o;
-        if (col < LD) db_part[(size_t)blockIdx.x * LD + col] = colsum[o];
-    }
+    if (tid < LD) db_part[(size_t)blockIdx.x * LD + tid] = colsum;
 }
 
 // hidden^T in the same chunked layout: HT[s][hh][kc], hh < H: keep*relu(f+g); hh == H: 1; else 0.
@@ -452,7 +444,7 @@ extern "C" int ia_joint_backward_g(void* logits_inout, const int64_t* labels, co
     if (gt_out && (S <= 0 || Kc <= 0 || Kc % GT_CELLS != 0 || (int64_t)S * Kc < cells || !ia_is_aligned(gt_out, 16)))
         return IA_INVALID_VALUE;
     if (dbias_out && (gt_out || !dbias_scratch || !ia_is_aligned(dbias_scratch, 16))) return IA_INVALID_VALUE;
-    if (dbias_out && (LD > 512 || GT_CELLS * (LD / 8) > 256 * GT_NV)) return IA_UNSUPPORTED;
+    if (dbias_out && (LD > GD_THREADS || GT_CELLS * (LD / 8) > GD_THREADS * GD_NV)) return IA_UNSUPPORTED;
     if (ev_start && hipEventRecord((hipEvent_t)ev_start, st) != hipSuccess) return IA_LAUNCH_FAILED;
     if (gt_out) {
         const int64_t ntiles = (int64_t)S * (Kc / GT_CELLS);
@@ -464,7 +456,7 @@ extern "C" int ia_joint_backward_g(void* logits_inout, const int64_t* labels, co
                            (_Float16*)gt_out, S, Kc, nch);
     } else if (dbias_out) {
         const int grid = gd_grid(cells);
-        hipLaunchKernelGGL(joint_grad_h_db_kernel, dim3(grid), dim3(256), 0, st, (_Float16*)logits_inout,
+        hipLaunchKernelGGL(joint_grad_h_db_kernel, dim3(grid), dim3(GD_THREADS), 0, st, (_Float16*)logits_inout,
                            (const float4*)(ws + w.off_cs), cells, LD, V, blank, kappa, dbias_scratch);
         IA_RETURN_IF_LAUNCH_FAILED();
         if (ev_stop && hipEventRecord((hipEvent_t)ev_stop, st) != hipSuccess) return IA_LAUNCH_FAILED;

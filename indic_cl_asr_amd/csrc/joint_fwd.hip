@@ -160,7 +160,9 @@ __global__ __launch_bounds__(J_THREADS, 1) void joint_fwd_kernel(JointFwdArgs a)
     // ---- epilogue: per subtile s (one t), rows u = u0 + 4q + r, cols v = 16n + c
     float biasr[JNT];
 #pragma unroll
-    for (int n = 0; n < JNT; ++n) biasr[n] = (16 * n + c < a.V) ? a.bias[16 * n + c] : 0.f;
+    // columns >= V: W rows are zero, the 'bias' -65504 makes the stored padding logit the most negative f16 (exp -> exactly 0
+    // in the gradient kernels without a column mask); the max / sum below never look at them
+    for (int n = 0; n < JNT; ++n) biasr[n] = (16 * n + c < a.V) ? a.bias[16 * n + c] : -65504.f;
     // transpose scratch: per wave 16 rows x LDT bytes, LDT = JVP*2 + 16
     constexpr int LDT = JVP * 2 + 16;
     unsigned char* sT = sW + wave * (16 * LDT);
