@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void joint_hidden_kernel(const _Float16* __res
             y.v = *reinterpret_cast<const h8*>(g + (b * U1 + u) * H + kv * 8);
 #pragma unroll
             for (int j = 0; j < 4; ++j) o.p[j] = __builtin_elementwise_max(x.p[j] + y.p[j], zero2);
-            if (DROPOUT) o.v = apply_keep8(o.v, dropout_keep8(seed, (unsigned)cell, (unsigned)kv, thr));
+            if (DROPOUT) o.v = dropout_apply8(o.v, seed, (unsigned)cell, (unsigned)kv, thr);
         } else {
             o.u = make_uint4(0, 0, 0, 0);
             if (kv == hv) o.v[0] = (_Float16)1.f;  // ones column -> dbias row of the dW GEMM
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256) void joint_hidden_t_kernel(const _Float16* __r
                     y.v = *reinterpret_cast<const h8*>(g + (b * U1 + u) * H + hh0);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) val[j].p[e] = __builtin_elementwise_max(x.p[e] + y.p[e], zero2);
-                    if (DROPOUT) val[j].v = apply_keep8(val[j].v, dropout_keep8(seed, (unsigned)cell, (unsigned)hgi, thr));
+                    if (DROPOUT) val[j].v = dropout_apply8(val[j].v, seed, (unsigned)cell, (unsigned)hgi, thr);
                 } else if (hh0 == H) {
                     val[j].h[0] = (_Float16)1.f;  // ones row -> dbias
                 }

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(DW_THREADS, 1) void joint_dw_fused_kernel(DwArgs a)
             x_.u = pf[R][k];                                                                                      \
             y_.u = *reinterpret_cast<const uint4*>(gtile + pu[R][k] * DW_XROW + xch * 16);                        \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) z_.p[j] = __builtin_elementwise_max(x_.p[j] + y_.p[j], zero2); \
-            if (DROPOUT) z_.v = apply_keep8(z_.v, dropout_keep8(a.seed, cellb_ + r_, (unsigned)((h0 >> 3) + xch), a.thr)); \
+            if (DROPOUT) z_.v = dropout_apply8(z_.v, a.seed, cellb_ + r_, (unsigned)((h0 >> 3) + xch), a.thr); \
             const bool in_ = r_ < rows_;                                                                       \
             z_.u.x = in_ ? z_.u.x : 0u; z_.u.y = in_ ? z_.u.y : 0u; z_.u.z = in_ ? z_.u.z : 0u; z_.u.w = in_ ? z_.u.w : 0u; \
             *reinterpret_cast<uint4*>(sX_ + (k ? xoff1 : xoff0)) = z_.u;                                       \

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(J_THREADS, 1) void joint_fwd_kernel(JointFwdArgs a)
                 A[s] = z.v;
                 if (DROPOUT) {
                     const unsigned kg = (unsigned)((kc * JKC + ks * 32) / 8 + q);
-                    A[s] = apply_keep8(A[s], dropout_keep8(a.seed, cell_base + (unsigned)(s * a.U1), kg, a.thr));
+                    A[s] = dropout_apply8(A[s], a.seed, cell_base + (unsigned)(s * a.U1), kg, a.thr);
                 }
             }
 #pragma unroll

@@ -131,3 +131,58 @@ def test_fused_weight_gradient_kernel_matches_library_gemm_path(B, T, U1, H, V, 
     for a, r, what in ((outs[0][0], outs[1][0], "dW"), (outs[0][1], outs[1][1], "dbias")):
         tol = 1e-4 * r.abs().max().item() + 1e-6      # same f16 operands, f32 accumulation in a different order
         assert (a - r).abs().max().item() <= tol, (what, (a - r).abs().max().item(), r.abs().max().item())
+
+
+def _mask_replica(seed, cells, n_kg, thr):
+    """numpy restatement of csrc/joint_common.h dropout_words / ge4_u8_msb: keep[cell, kg, unit] (bool)."""
+    M = np.uint64(0xFFFFFFFF)
+    u = lambda v: np.uint64(v)
+
+    def mul24(a, b):
+        return ((a & u(0xFFFFFF)) * (u(b) & u(0xFFFFFF))) & M
+
+    def hash32(x):
+        x = u(x)
+        x ^= x >> u(16); x = (x * u(0x85ebca6b)) & M; x ^= x >> u(13); x = (x * u(0xc2b2ae35)) & M; x ^= x >> u(16)
+        return x
+
+    cell = np.arange(cells, dtype=np.uint64)[:, None]
+    kg = np.arange(n_kg, dtype=np.uint64)[None, :]
+    x = (cell ^ hash32(seed)) ^ mul24(kg, 0x9E3779)
+    x = x ^ (x >> u(16)); x = mul24(x, 0xA3D8B5)
+    x = x ^ (x >> u(13)); x = mul24(x, 0x6B2E5D)
+    r0 = x ^ (x >> u(15))
+    y = (x + u(0x3C6EF372)) & M
+    y = y ^ (y >> u(11)); y = mul24(y, 0x9C4D27)
+    r1 = y ^ (y >> u(14))
+    byts = [(r0 >> u(8 * i)) & u(255) for i in range(4)] + [(r1 >> u(8 * i)) & u(255) for i in range(4)]
+    return np.stack(byts, -1) >= thr
+
+
+def test_dropout_mask_matches_numpy_replica_and_is_unbiased():
+    """The joint's counter-based mask (24-bit-multiply hash, SWAR byte compare): the kernels reproduce the numpy replica bit
+    for bit, the keep rate is 1 - thr/256 per unit, neighbouring cells / chunks / units and different seeds are uncorrelated."""
+    from indic_cl_asr_amd import _lib
+    L = _lib.lib()
+    B, T, U1, H = 2, 40, 25, 128
+    cells, p = B * T * U1, 0.2
+    thr = int(p * 256 + 0.5)
+    f = torch.ones(B, T, H, dtype=torch.float16, device="cuda"); g = torch.zeros(B, U1, H, dtype=torch.float16, device="cuda")
+    keeps = []
+    for seed in (1234, 1235):
+        hid = torch.empty(cells, H + 8, dtype=torch.float16, device="cuda")
+        _lib.check(L.ia_joint_hidden(_lib.ptr(f), _lib.ptr(g), _lib.ptr(hid), B, T, U1, H, H + 8, p, seed, _lib.stream_ptr()), "hidden")
+        got = hid[:, :H].float().cpu().numpy().reshape(cells, H // 8, 8) > 0
+        ref = _mask_replica(seed, cells, H // 8, thr)
+        assert (got == ref).all()
+        keeps.append(ref)
+    k = _mask_replica(77, 200000, 80, thr).astype(np.float64)
+    assert abs(k.mean() - (1 - thr / 256)) < 2e-4
+    assert np.abs(k.mean((0, 1)) - (1 - thr / 256)).max() < 1e-3          # every unit position
+    c = k - k.mean()
+    corr = lambda a, b: abs(float((a * b).mean() / c.var()))
+    assert corr(c[:-1], c[1:]) < 2e-3 and corr(c[:-U1], c[U1:]) < 2e-3     # neighbouring cells (u and t directions)
+    assert corr(c[:, :-1], c[:, 1:]) < 2e-3                                # neighbouring chunks
+    assert max(corr(c[..., i], c[..., j]) for i in range(8) for j in range(i)) < 3e-3
+    a, b = keeps[0].astype(np.float64), keeps[1].astype(np.float64)        # consecutive seeds: unrelated masks
+    assert abs(float(((a - a.mean()) * (b - b.mean())).mean() / a.var())) < 2e-2
