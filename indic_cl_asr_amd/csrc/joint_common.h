@@ -9,7 +9,8 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-constexpr int JT = 16;          // t per workgroup
+constexpr int JS = 3;           // t per wave: 3 x 17 accumulator tiles = 204 registers (the AGPR half), everything else in VGPRs
+constexpr int JT = 4 * JS;      // t per workgroup (4 waves)
 constexpr int JU = 16;          // u per workgroup (= MFMA M)
 constexpr int JNT = 17;         // 16-wide column tiles: V <= 272
 constexpr int JVP = JNT * 16;   // 272

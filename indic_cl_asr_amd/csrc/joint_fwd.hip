@@ -8,13 +8,13 @@
 // bf16 VALU, which is why this path runs in f16 like the reference's own AMP mode) -- and the logits leave the chip
 // once, as f16 rows padded to LD columns (16-byte aligned rows, GEMM-ready for the backward).
 //
-// Tiling (v_mfma_f32_16x16x32_f16): workgroup = 4 waves = 16 t x 16 u lattice cells of one utterance; wave w owns
-// t = t0+4w..+3, i.e. 4 row-subtiles (one per t, 16 u each) x NT=17 column tiles (272 >= V): 272 accumulator
-// registers, one wave per SIMD.  W streams through LDS in 64-deep K chunks (double buffered, 144-byte padded rows:
+// Tiling (v_mfma_f32_16x16x32_f16): workgroup = 4 waves = 12 t x 16 u lattice cells of one utterance; wave w owns
+// t = t0+3w..+2, i.e. 3 row-subtiles (one per t, 16 u each) x NT=17 column tiles (272 >= V): 204 accumulator
+// registers (4 x 17 = 272 did not fit the 256-register AGPR half: ~100 accvgpr moves per K chunk), one wave per SIMD.  W streams through LDS in 64-deep K chunks (double buffered, 144-byte padded rows:
 // conflict-free ds_read_b128 B fragments shared by the 4 waves); f/g tiles stay in LDS for the whole K loop.
-// Epilogue per subtile: +bias, round to f16 (the denominator is computed from the ROUNDED logits, so the fused
-// log-softmax gradient sums to zero exactly as with autocast logits), row max / sum-exp with 16-lane DPP
-// reductions, transpose through LDS, coalesced 16-byte row stores, blank/label gathers into the diagonal-major
+// Epilogue per subtile (accumulators start from the bias and hold the transposed tile: 4 consecutive columns per lane):
+// round to f16 in pairs (the denominator is computed from the ROUNDED logits, so the fused log-softmax gradient sums
+// to zero exactly as with autocast logits), packed row max, sum-exp, 8-byte transposing LDS writes, coalesced 16-byte row stores, blank/label gathers into the diagonal-major
 // side arrays that rnnt_alpha_beta consumes.
 #include <hip/hip_fp16.h>
 
@@ -109,46 +109,64 @@ __global__ __launch_bounds__(J_THREADS, 1) void joint_fwd_kernel(JointFwdArgs a)
         if (tid < WREM) J_W_DST(buf_, WFULL) = wlast;                                                     \
     } while (0)
 
-    f4 acc[4][JNT];
+    // accumulators start from the bias (lane (c, q) owns columns 16n + 4q + r).  Columns >= V: W rows are zero and the
+    // "bias" -65504 makes the stored padding logit the most negative f16 -- it never wins the row maximum, its exp is exactly
+    // 0 in the denominator and in the gradient kernels: no column masks anywhere downstream
+    f4 acc[JS][JNT];
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int n = 0; n < JNT; ++n) {
+        f4 b4;
 #pragma unroll
-        for (int n = 0; n < JNT; ++n) acc[s][n] = (f4){0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < 4; ++r) { const int v = 16 * n + 4 * (lane >> 4) + r; b4[r] = v < a.V ? a.bias[v] : -65504.f; }
+#pragma unroll
+        for (int s = 0; s < JS; ++s) acc[s][n] = b4;
+    }
 
     const int nkc = H / JKC;
     J_W_LOAD(0);
     J_W_STORE(0);
     __syncthreads();
-    const int tw = t0 + wave * 4;  // first t of this wave
+    const int tw = t0 + wave * JS;  // first t of this wave
     const unsigned cell_base = (unsigned)(((size_t)b * a.T + tw) * a.U1 + u0 + c);  // + s*U1 per subtile
     const h2 zero2 = {(_Float16)0, (_Float16)0};
+    // A operands of k-step `kstep` (32 hidden units): relu(f + g) with the dropout mask, JS subtiles
+#define J_BUILD_A(dst_, kstep_)                                                                              \
+    do {                                                                                                     \
+        const int kbyte_ = ((kstep_) * 32 + q * 8) * 2;  /* byte offset of this lane's 8 k values in an f/g row */ \
+        const h8 gf_ = *reinterpret_cast<const h8*>(sG + c * frow + kbyte_);                                 \
+        _Pragma("unroll") for (int s = 0; s < JS; ++s) {                                                     \
+            const h8 ff_ = *reinterpret_cast<const h8*>(sF + (wave * JS + s) * frow + kbyte_);               \
+            union { h8 v; h2 p[4]; } x_, y_, z_;                                                             \
+            x_.v = gf_; y_.v = ff_;                                                                          \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) z_.p[j] = __builtin_elementwise_max(x_.p[j] + y_.p[j], zero2); \
+            dst_[s] = z_.v;                                                                                  \
+            if (DROPOUT) dst_[s] = dropout_apply8(dst_[s], a.seed, cell_base + (unsigned)(s * a.U1), (unsigned)((kstep_) * 4 + q), a.thr); \
+        }                                                                                                    \
+    } while (0)
+    // One wave per SIMD: nothing else hides LDS latency, so every k-step first requests ALL 17 W fragments, builds the NEXT
+    // k-step's hidden operands while they arrive (VALU under the LDS latency), then issues its 51 MFMAs.
+    // Operand order: the W fragment is the MFMA's A operand and the hidden fragment its B operand, i.e. the accumulators
+    // hold the TRANSPOSED tile -- lane (c, q) owns logits[u = u0 + c][v = 16n + 4q + r], four CONSECUTIVE vocabulary
+    // columns of one lattice cell: the epilogue packs / reduces / stores them as pairs and 8-byte words.
+    h8 Acur[JS], Anext[JS];
+    J_BUILD_A(Acur, 0);
+    const int nks = H / 32;
     for (int kc = 0; kc < nkc; ++kc) {
         if (kc + 1 < nkc) J_W_LOAD(kc + 1);
         const unsigned char* wb = sW + (kc & 1) * (JVP * JWROW);
 #pragma unroll
         for (int ks = 0; ks < JKC / 32; ++ks) {
-            const int kbyte = (kc * JKC + ks * 32 + q * 8) * 2;  // byte offset of this lane's 8 k values in an f/g row
-            const h8 gf = *reinterpret_cast<const h8*>(sG + c * frow + kbyte);
-            h8 A[4];
+            h8 Bf[JNT];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const h8 ff = *reinterpret_cast<const h8*>(sF + (wave * 4 + s) * frow + kbyte);
-                union { h8 v; h2 p[4]; } x, y, z;
-                x.v = gf; y.v = ff;
+            for (int n = 0; n < JNT; ++n) Bf[n] = *reinterpret_cast<const h8*>(wb + (n * 16 + c) * JWROW + (ks * 32 + q * 8) * 2);
+            const int knext = kc * (JKC / 32) + ks + 1;
+            J_BUILD_A(Anext, knext < nks ? knext : 0);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) z.p[j] = __builtin_elementwise_max(x.p[j] + y.p[j], zero2);
-                A[s] = z.v;
-                if (DROPOUT) {
-                    const unsigned kg = (unsigned)((kc * JKC + ks * 32) / 8 + q);
-                    A[s] = dropout_apply8(A[s], a.seed, cell_base + (unsigned)(s * a.U1), kg, a.thr);
-                }
-            }
+            for (int n = 0; n < JNT; ++n)
 #pragma unroll
-            for (int n = 0; n < JNT; ++n) {
-                const h8 Bf = *reinterpret_cast<const h8*>(wb + (n * 16 + c) * JWROW + (ks * 32 + q * 8) * 2);
+                for (int s = 0; s < JS; ++s) acc[s][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Bf[n], Acur[s], acc[s][n], 0, 0, 0);
 #pragma unroll
-                for (int s = 0; s < 4; ++s) acc[s][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[s], Bf, acc[s][n], 0, 0, 0);
-            }
+            for (int s = 0; s < JS; ++s) Acur[s] = Anext[s];
         }
         __syncthreads();               // everyone done reading buffer (kc&1)... and (kc+1)&1 from the previous round
         if (kc + 1 < nkc) {
@@ -156,55 +174,46 @@ __global__ __launch_bounds__(J_THREADS, 1) void joint_fwd_kernel(JointFwdArgs a)
             __syncthreads();
         }
     }
+#undef J_BUILD_A
 
-    // ---- epilogue: per subtile s (one t), rows u = u0 + 4q + r, cols v = 16n + c
-    float biasr[JNT];
-#pragma unroll
-    // columns >= V: W rows are zero, the 'bias' -65504 makes the stored padding logit the most negative f16 (exp -> exactly 0
-    // in the gradient kernels without a column mask); the max / sum below never look at them
-    for (int n = 0; n < JNT; ++n) biasr[n] = (16 * n + c < a.V) ? a.bias[16 * n + c] : -65504.f;
+    // ---- epilogue: per subtile s (one t): lane (c, q) holds row u = u0 + c, columns v = 16n + 4q + r
     // transpose scratch: per wave 16 rows x LDT bytes, LDT = JVP*2 + 16
     constexpr int LDT = JVP * 2 + 16;
     unsigned char* sT = sW + wave * (16 * LDT);
     const int64_t* lab = a.labels + (int64_t)b * (a.U1 - 1);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < JS; ++s) {
         const int t = tw + s;
-        float m[4] = {IA_NEG_INF, IA_NEG_INF, IA_NEG_INF, IA_NEG_INF};
+        // round to f16 in pairs (the denominator is computed from the ROUNDED logits), packed row maximum
+        h2 pk[JNT][2];
+        h2 mx = {(_Float16)-65504.f, (_Float16)-65504.f};
+#pragma unroll
+        for (int n = 0; n < JNT; ++n) {
+            pk[n][0] = (h2){(_Float16)acc[s][n][0], (_Float16)acc[s][n][1]};   // v_cvt_pk_f16_f32, round to nearest even
+            pk[n][1] = (h2){(_Float16)acc[s][n][2], (_Float16)acc[s][n][3]};
+            mx = __builtin_elementwise_max(mx, __builtin_elementwise_max(pk[n][0], pk[n][1]));
+        }
+        float m = fmaxf((float)mx[0], (float)mx[1]);
+        m = fmaxf(m, __shfl_xor(m, 16));   // the four q groups of row c
+        m = fmaxf(m, __shfl_xor(m, 32));
+        const float ml = -m * 1.44269504088896341f;
+        float sum = 0.f;
 #pragma unroll
         for (int n = 0; n < JNT; ++n)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const _Float16 xh = (_Float16)(acc[s][n][r] + biasr[n]);
-                acc[s][n][r] = (float)xh;  // keep the ROUNDED logit
-                if (16 * n + c < a.V) m[r] = fmaxf(m[r], acc[s][n][r]);
+            for (int e = 0; e < 2; ++e) {
+                sum += __builtin_amdgcn_exp2f(__builtin_fmaf((float)pk[n][e][0], 1.44269504088896341f, ml));
+                sum += __builtin_amdgcn_exp2f(__builtin_fmaf((float)pk[n][e][1], 1.44269504088896341f, ml));
             }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        // accumulator layout -> LDS rows [u_local = c][v]: one 8-byte word per column tile
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {  // reduce over the 16 lanes (c) of this q group: DPP inside a 16-lane row
-            m[r] = fmaxf(m[r], IA_DPP_F(m[r], m[r], 0xB1, 0xF));
-            m[r] = fmaxf(m[r], IA_DPP_F(m[r], m[r], 0x4E, 0xF));
-            m[r] = fmaxf(m[r], IA_DPP_F(m[r], m[r], 0x141, 0xF));
-            m[r] = fmaxf(m[r], IA_DPP_F(m[r], m[r], 0x140, 0xF));
+        for (int n = 0; n < JNT; ++n) {
+            union { h2 p[2]; uint2 u; } w2;
+            w2.p[0] = pk[n][0]; w2.p[1] = pk[n][1];
+            *reinterpret_cast<uint2*>(sT + c * LDT + (16 * n + 4 * q) * 2) = w2.u;
         }
-        float sum[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int n = 0; n < JNT; ++n)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (16 * n + c < a.V) sum[r] += __builtin_amdgcn_exp2f((acc[s][n][r] - m[r]) * 1.44269504088896341f);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            sum[r] += IA_DPP_F(0.f, sum[r], 0xB1, 0xF);
-            sum[r] += IA_DPP_F(0.f, sum[r], 0x4E, 0xF);
-            sum[r] += IA_DPP_F(0.f, sum[r], 0x141, 0xF);
-            sum[r] += IA_DPP_F(0.f, sum[r], 0x140, 0xF);
-        }
-        // C layout -> LDS rows [u_local = 4q + r][v]
-#pragma unroll
-        for (int n = 0; n < JNT; ++n)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                *reinterpret_cast<_Float16*>(sT + (4 * q + r) * LDT + (16 * n + c) * 2) = (_Float16)acc[s][n][r];
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS writes landed (scratch is wave-private)
         if (t < Tb) {
             // coalesced row stores: 16 rows x (LD*2/16) vectors
@@ -217,23 +226,20 @@ __global__ __launch_bounds__(J_THREADS, 1) void joint_fwd_kernel(JointFwdArgs a)
                     reinterpret_cast<uint4*>(a.logits + (((size_t)b * a.T + t) * a.U1 + u) * a.LD)[v] = val;
                 }
             }
-            // per-row scalars: lanes c == 0 own rows 4q + r
-            if (c == 0) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int ul = 4 * q + r, u = u0 + ul;
-                    if (u < Ub) {
-                        const float dn = -m[r] - 0.69314718055994531f * __builtin_amdgcn_logf(sum[r]);
-                        const int64_t cell = ((int64_t)b * a.T + t) * a.U1 + u;
-                        a.denom[cell] = dn;
-                        const size_t row = ((size_t)b * a.rows + RNNT_GUARD + (t + u)) * a.U1s;
-                        const float xb = (float)*reinterpret_cast<const _Float16*>(sT + ul * LDT + a.blank * 2);
-                        a.PB[row + u] = xb + dn;
-                        float lpl = 0.f;
-                        if (u < Ub - 1) lpl = (float)*reinterpret_cast<const _Float16*>(sT + ul * LDT + (int)lab[u] * 2) + dn;
-                        a.PL[row + u] = lpl;
-                        a.PLa[row + a.U1s + u + 1] = lpl;
-                    }
+            // per-row scalars: lanes q == 0 own row c
+            if (q == 0) {
+                const int ul = c, u = u0 + ul;
+                if (u < Ub) {
+                    const float dn = -m - 0.69314718055994531f * __builtin_amdgcn_logf(sum);
+                    const int64_t cell = ((int64_t)b * a.T + t) * a.U1 + u;
+                    a.denom[cell] = dn;
+                    const size_t row = ((size_t)b * a.rows + RNNT_GUARD + (t + u)) * a.U1s;
+                    const float xb = (float)*reinterpret_cast<const _Float16*>(sT + ul * LDT + a.blank * 2);
+                    a.PB[row + u] = xb + dn;
+                    float lpl = 0.f;
+                    if (u < Ub - 1) lpl = (float)*reinterpret_cast<const _Float16*>(sT + ul * LDT + (int)lab[u] * 2) + dn;
+                    a.PL[row + u] = lpl;
+                    a.PLa[row + a.U1s + u + 1] = lpl;
                 }
             }
         }
