@@ -10,8 +10,8 @@
 //
 // Tiling (v_mfma_f32_16x16x32_f16): workgroup = 4 waves = 12 t x 16 u lattice cells of one utterance; wave w owns
 // t = t0+3w..+2, i.e. 3 row-subtiles (one per t, 16 u each) x NT=17 column tiles (272 >= V): 204 accumulator
-// registers (4 x 17 = 272 did not fit the 256-register AGPR half: ~100 accvgpr moves per K chunk), one wave per SIMD.  W streams through LDS in 64-deep K chunks (double buffered, 144-byte padded rows:
-// conflict-free ds_read_b128 B fragments shared by the 4 waves); f/g tiles stay in LDS for the whole K loop.
+// registers (4 x 17 = 272 did not fit the 256-register AGPR half: ~100 accvgpr moves per K chunk), one wave per SIMD.  W streams through LDS in 64-deep K chunks (double buffered, loaded global -> LDS directly, XOR-swizzled 128-byte rows:
+// conflict-free ds_read_b128 fragments shared by the 4 waves); f/g tiles stay in LDS for the whole K loop.
 // Epilogue per subtile (accumulators start from the bias and hold the transposed tile: 4 consecutive columns per lane):
 // round to f16 in pairs (the denominator is computed from the ROUNDED logits, so the fused log-softmax gradient sums
 // to zero exactly as with autocast logits), packed row max, sum-exp, 8-byte transposing LDS writes, coalesced 16-byte row stores, blank/label gathers into the diagonal-major
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(J_THREADS, 1) void joint_fwd_kernel(JointFwdArgs a)
     const int frow = H * 2 + 16;                       // bytes per f/g row in LDS (padded)
     unsigned char* sF = smem;                          // JT rows
     unsigned char* sG = sF + JT * frow;                // JU rows
-    unsigned char* sW = sG + JU * frow;                // 2 x JVP x JWROW  (later reused as the transpose scratch)
+    unsigned char* sW = sG + JU * frow;                // 2 x JVP x 128 B  (later reused as the transpose scratch)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, q = lane >> 4;
 
@@ -74,40 +74,24 @@ __global__ __launch_bounds__(J_THREADS, 1) void joint_fwd_kernel(JointFwdArgs a)
             }
         }
     }
-    // ---- W chunk staging: JVP rows x 64 k (128 B) = 8 x 16-byte vectors per row
-    constexpr int WVEC = JVP * (JKC / 8);               // 2176 vectors per chunk
-    constexpr int WFULL = WVEC / J_THREADS;              // 8 full rounds ...
-    constexpr int WREM = WVEC - WFULL * J_THREADS;       // ... + 128 vectors (threads 0..127), kept in a named register
-    static_assert(WFULL == 8, "staging registers are named w0..w7");
-    uint4 w0, w1, w2, w3, w4, w5, w6, w7, wlast = make_uint4(0, 0, 0, 0);  // named: arrays here end up in scratch
-#define J_W_SRC(kc_, i_) \
-    reinterpret_cast<const uint4*>(a.W + (size_t)((tid + (i_) * J_THREADS) >> 3) * H + (kc_) * JKC)[(tid + (i_) * J_THREADS) & 7]
-#define J_W_DST(buf_, i_) \
-    *reinterpret_cast<uint4*>(sW + (buf_) * (JVP * JWROW) + ((tid + (i_) * J_THREADS) >> 3) * JWROW + ((tid + (i_) * J_THREADS) & 7) * 16)
-#define J_W_LOAD(kc_)                                                                                     \
-    do {                                                                                                  \
-        w0 = J_W_SRC(kc_, 0);                                                            \
-        w1 = J_W_SRC(kc_, 1);                                                            \
-        w2 = J_W_SRC(kc_, 2);                                                            \
-        w3 = J_W_SRC(kc_, 3);                                                            \
-        w4 = J_W_SRC(kc_, 4);                                                            \
-        w5 = J_W_SRC(kc_, 5);                                                            \
-        w6 = J_W_SRC(kc_, 6);                                                            \
-        w7 = J_W_SRC(kc_, 7);                                                            \
-        if (tid < WREM) wlast = J_W_SRC(kc_, WFULL);                                                      \
+    // ---- W chunk staging: JVP rows x 64 k (128 B per row) straight from global memory into LDS (global_load_lds_dwordx4:
+    // no staging registers, no ds_write, the data lands while the MFMAs run).  One instruction fills 1 KB of consecutive LDS
+    // = 8 rows x 8 chunks of 16 B with lane l at position l, so the layout is rows of 128 B WITHOUT padding and the
+    // conflict-free placement is done on the source side: physical chunk p of row r holds the row's chunk p ^ (r & 7).
+    // 34 such blocks per chunk: wave w fills blocks w, w + 4, ...
+    constexpr int WROW = JKC * 2;                        // 128 B
+    constexpr int WBUF = JVP * WROW;                     // 34 816 B per buffer
+    constexpr int WBLK = JVP / 8;                        // 34 blocks of 8 rows
+    const unsigned wsrc_lane = (unsigned)((lane >> 3) * H * 2 + 16 * ((lane & 7) ^ (lane >> 3)));   // byte offset inside a block's 8 rows
+#define J_W_ASYNC(kc_, buf_)                                                                             \
+    do {                                                                                                 \
+        for (int blk_ = wave; blk_ < WBLK; blk_ += 4) {                                                  \
+            const unsigned char* src_ = reinterpret_cast<const unsigned char*>(a.W + (size_t)(8 * blk_) * H + (kc_) * JKC) + wsrc_lane; \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,        \
+                                             (__attribute__((address_space(3))) void*)(sW + (buf_) * WBUF + blk_ * 1024), 16, 0, 0); \
+        }                                                                                                \
     } while (0)
-#define J_W_STORE(buf_)                                                                                   \
-    do {                                                                                                  \
-        J_W_DST(buf_, 0) = w0;                                                            \
-        J_W_DST(buf_, 1) = w1;                                                            \
-        J_W_DST(buf_, 2) = w2;                                                            \
-        J_W_DST(buf_, 3) = w3;                                                            \
-        J_W_DST(buf_, 4) = w4;                                                            \
-        J_W_DST(buf_, 5) = w5;                                                            \
-        J_W_DST(buf_, 6) = w6;                                                            \
-        J_W_DST(buf_, 7) = w7;                                                            \
-        if (tid < WREM) J_W_DST(buf_, WFULL) = wlast;                                                     \
-    } while (0)
+#define J_W_WAIT() __builtin_amdgcn_s_waitcnt(0x0F70)   /* vmcnt(0): this wave's LDS-DMA loads have landed */
 
     // accumulators start from the bias (lane (c, q) owns columns 16n + 4q + r).  Columns >= V: W rows are zero and the
     // "bias" -65504 makes the stored padding logit the most negative f16 -- it never wins the row maximum, its exp is exactly
@@ -123,8 +107,8 @@ __global__ __launch_bounds__(J_THREADS, 1) void joint_fwd_kernel(JointFwdArgs a)
     }
 
     const int nkc = H / JKC;
-    J_W_LOAD(0);
-    J_W_STORE(0);
+    J_W_ASYNC(0, 0);
+    J_W_WAIT();
     __syncthreads();
     const int tw = t0 + wave * JS;  // first t of this wave
     const unsigned cell_base = (unsigned)(((size_t)b * a.T + tw) * a.U1 + u0 + c);  // + s*U1 per subtile
@@ -152,13 +136,13 @@ __global__ __launch_bounds__(J_THREADS, 1) void joint_fwd_kernel(JointFwdArgs a)
     J_BUILD_A(Acur, 0);
     const int nks = H / 32;
     for (int kc = 0; kc < nkc; ++kc) {
-        if (kc + 1 < nkc) J_W_LOAD(kc + 1);
-        const unsigned char* wb = sW + (kc & 1) * (JVP * JWROW);
+        if (kc + 1 < nkc) J_W_ASYNC(kc + 1, (kc + 1) & 1);   // the other buffer: its readers passed the previous barrier
+        const unsigned char* wb = sW + (kc & 1) * WBUF;
 #pragma unroll
         for (int ks = 0; ks < JKC / 32; ++ks) {
             h8 Bf[JNT];
 #pragma unroll
-            for (int n = 0; n < JNT; ++n) Bf[n] = *reinterpret_cast<const h8*>(wb + (n * 16 + c) * JWROW + (ks * 32 + q * 8) * 2);
+            for (int n = 0; n < JNT; ++n) Bf[n] = *reinterpret_cast<const h8*>(wb + (n * 16 + c) * WROW + 16 * ((ks * 4 + q) ^ (c & 7)));
             const int knext = kc * (JKC / 32) + ks + 1;
             J_BUILD_A(Anext, knext < nks ? knext : 0);
 #pragma unroll
@@ -168,11 +152,8 @@ __global__ __launch_bounds__(J_THREADS, 1) void joint_fwd_kernel(JointFwdArgs a)
 #pragma unroll
             for (int s = 0; s < JS; ++s) Acur[s] = Anext[s];
         }
-        __syncthreads();               // everyone done reading buffer (kc&1)... and (kc+1)&1 from the previous round
-        if (kc + 1 < nkc) {
-            J_W_STORE((kc + 1) & 1);
-            __syncthreads();
-        }
+        J_W_WAIT();
+        __syncthreads();               // chunk kc+1 is in LDS for everyone; everyone is done reading buffer kc & 1
     }
 #undef J_BUILD_A
 
@@ -277,7 +258,7 @@ extern "C" int ia_joint_fwd(const void* f, const void* g, const void* W, const f
     a.seed = seed;
     a.thr = (unsigned)(dropout_p * 256.f + 0.5f);
     const int frow = H * 2 + 16;
-    const size_t lds = (size_t)(JT + JU) * frow + 2 * (size_t)JVP * JWROW;
+    const size_t lds = (size_t)(JT + JU) * frow + 2 * (size_t)JVP * JKC * 2;
     if (lds > 160 * 1024) return IA_UNSUPPORTED;
     const int nut = (U1 + JU - 1) / JU, ntt = (T + JT - 1) / JT;
     const dim3 grid((unsigned)((int64_t)B * ntt * nut)), blk(J_THREADS);
