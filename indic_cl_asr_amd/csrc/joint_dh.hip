@@ -10,7 +10,7 @@
 //
 // The waves of a workgroup are partitioned along the HIDDEN axis, not along the rows: workgroup = one utterance, 16
 // frames, 320 hidden units; wave w owns units [80w, 80w+80) and keeps its W^T slice (5 column tiles x 9 k-steps = 45
-// B fragments, 180 registers) resident for the workgroup's lifetime.  The G rows stream HBM -> registers -> LDS (64
+// B fragments, 180 registers) resident for the workgroup's lifetime.  The G rows stream HBM -> LDS directly (64
 // rows = 4 frames x 16 labels per pass, double buffered, every row read once per 320-unit half) and all four waves read
 // the same A fragments.  Because every wave sees all rows of its units, both reductions are wave-local: the sum over a
 // pass's 16 labels is 4 registers + two cross-row shuffles, accumulated per frame in an LDS row the wave owns (plain
@@ -31,7 +31,6 @@ constexpr int DH_NW = 80;                // hidden units per wave (5 column tile
 constexpr int DH_NB = 4 * DH_NW;         // hidden units per workgroup
 constexpr int DH_NT = DH_NW / 16;
 constexpr int DH_TT = 16;                // frames per workgroup (= the partial-row chunk of the d g finishing sum)
-constexpr int DH_NV = 9;                 // 16-byte chunks per loader thread per pass (4 threads per row, LD/8 <= 36)
 
 struct DhArgs {
     const _Float16* G; const _Float16* Wt; const _Float16* f; const _Float16* g;
@@ -80,33 +79,32 @@ __global__ __launch_bounds__(256, 1) void joint_dh_fused_kernel(DhArgs a) {
     for (int i = tid; i < DH_TT * DH_NB; i += 256) sdf[i] = 0.f;
     __syncthreads();
 
-    // ---- loader: thread = one tile row x every 4th 16-byte chunk of it
-    const int lrow = tid >> 2, lc4 = tid & 3, vpr = LD / 8;
-    const int lmt = lrow >> 4, lul = lrow & 15;
-    uint4 pre[DH_NV];
-#define DH_LOAD(ut_, pt_)                                                                                          \
+    // ---- loader: the pass's 64 G rows go global -> LDS directly (global_load_lds_dwordx4: no staging registers, no
+    // ds_write; the data lands while the previous pass is multiplied).  One instruction fills 1 KB = 64 consecutive 16-byte
+    // slots of the tile image (rows of 37 slots = 592 B): lane l of block k owns slot 64k + l = (row, column chunk); lanes
+    // on the 3-4 padding slots of a row stay idle (those slots keep their initial zeros).  Rows outside the tensor
+    // (t >= T or u >= U1) are fetched from a clamped address -- finite values -- and switched off through the keep table.
+    constexpr int DH_SLOTS = DH_AROW / 16;                         // 37
+    constexpr int DH_NBLK = (DH_ROWS * DH_SLOTS + 63) / 64;        // 37 blocks
+    const int vpr = LD / 8;
+#define DH_ASYNC(ut_, pt_, buf_)                                                                                   \
     do {                                                                                                           \
-        const int t_ = t0 + (pt_) * 4 + lmt, u_ = (ut_) * 16 + lul;                                                \
-        const bool ok_ = t_ < T && u_ < U1;                                                                        \
-        const uint4* src_ =                                                                                        \
-            reinterpret_cast<const uint4*>(a.G + (((size_t)b * T + (ok_ ? t_ : 0)) * U1 + (ok_ ? u_ : 0)) * LD);   \
-        _Pragma("unroll") for (int k = 0; k < DH_NV; ++k) {                                                        \
-            const int cv_ = lc4 + 4 * k;                                                                           \
-            pre[k] = (ok_ && cv_ < vpr) ? src_[cv_ < vpr ? cv_ : 0] : make_uint4(0, 0, 0, 0);                      \
+        for (int blk_ = wave; blk_ < DH_NBLK; blk_ += 4) {                                                         \
+            const int P_ = blk_ * 64 + lane;                                                                       \
+            const int row_ = P_ / DH_SLOTS, col_ = P_ - row_ * DH_SLOTS;                                           \
+            int t_ = t0 + (pt_) * 4 + (row_ >> 4); t_ = t_ < T ? t_ : T - 1;                                       \
+            int u_ = (ut_) * 16 + (row_ & 15); u_ = u_ < U1 ? u_ : U1 - 1;                                         \
+            const _Float16* src_ = a.G + (((size_t)b * T + t_) * U1 + u_) * LD + col_ * 8;                         \
+            if (row_ < DH_ROWS && col_ < vpr)                                                                      \
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,              \
+                                                 (__attribute__((address_space(3))) void*)(sA + (buf_) * (DH_ROWS * DH_AROW) + blk_ * 1024), 16, 0, 0); \
         }                                                                                                          \
     } while (0)
-#define DH_STORE(buf_)                                                                                             \
-    do {                                                                                                           \
-        unsigned char* dst_ = sA + (buf_) * (DH_ROWS * DH_AROW) + lrow * DH_AROW;                                  \
-        _Pragma("unroll") for (int k = 0; k < DH_NV; ++k) {                                                        \
-            const int cv_ = lc4 + 4 * k;                                                                           \
-            if (cv_ < vpr) *reinterpret_cast<uint4*>(dst_ + cv_ * 16) = pre[k];                                    \
-        }                                                                                                          \
-    } while (0)
+#define DH_WAIT() __builtin_amdgcn_s_waitcnt(0x0F70)   /* vmcnt(0) */
 
     const int npass = nut * npt;  // label tile outer, 4-frame pass inner
-    DH_LOAD(0, 0);
-    DH_STORE(0);
+    DH_ASYNC(0, 0, 0);
+    DH_WAIT();
     __syncthreads();
     unsigned char* smw = smask + wave * 1024;
     float dgacc[4][DH_NT];
@@ -118,7 +116,8 @@ __global__ __launch_bounds__(256, 1) void joint_dh_fused_kernel(DhArgs a) {
     for (int ps = 0; ps < npass; ++ps) {
         const int ut = ps / npt, pt = ps - ut * npt;
         const int u0 = ut * 16, tp = t0 + pt * 4;
-        if (ps + 1 < npass) DH_LOAD((ps + 1) / npt, (ps + 1) - ((ps + 1) / npt) * npt);  // in flight under this pass
+        if (ps + 1 < npass)   // the other buffer (its readers passed the previous barrier): lands under this pass
+            DH_ASYNC((ps + 1) / npt, (ps + 1) - ((ps + 1) / npt) * npt, (ps + 1) & 1);
         if (wave_on) {
             if (pt == 0) {
 #pragma unroll
@@ -137,14 +136,18 @@ __global__ __launch_bounds__(256, 1) void joint_dh_fused_kernel(DhArgs a) {
 #pragma unroll
                 for (int nt = 0; nt < DH_NT; ++nt) fh[mt][nt] = fp[nt * 16];
             }
-            if (DROPOUT) {
-                // keep bits of the pass's 64 cells x this wave's 10 unit groups: table[row][c>>3][nt] (8-byte groups)
+            {
+                // keep bits of the pass's 64 cells x this wave's 10 unit groups: table[row][c>>3][nt] (8-byte groups); rows
+                // outside the tensor (their G rows were fetched from a clamped address) get all-zero bits
 #pragma unroll
                 for (int i = 0; i < 2 * DH_NT; ++i) {  // 64 rows x 10 groups = 640 entries: exactly 10 per lane
                     const int e = lane + 64 * i, row = e / (2 * DH_NT), j = e - row * (2 * DH_NT);
                     const int nt = j >> 1, cp = j & 1;
-                    const unsigned cell = (unsigned)((((size_t)b * T + tp + (row >> 4)) * U1) + u0 + (row & 15));
-                    smw[row * 16 + cp * 8 + nt] = (unsigned char)dropout_keep8(a.seed, cell, (unsigned)((n0 >> 3) + j), a.thr);
+                    const int tr = tp + (row >> 4), ur = u0 + (row & 15);
+                    const unsigned cell = (unsigned)((((size_t)b * T + tr) * U1) + ur);
+                    unsigned bits = 0xFFu;
+                    if (DROPOUT) bits = dropout_keep8(a.seed, cell, (unsigned)((n0 >> 3) + j), a.thr);
+                    smw[row * 16 + cp * 8 + nt] = (unsigned char)((tr < T && ur < U1) ? bits : 0u);
                 }
             }
             // ---- MFMA: 64 rows x 80 units x K
@@ -154,28 +157,31 @@ __global__ __launch_bounds__(256, 1) void joint_dh_fused_kernel(DhArgs a) {
 #pragma unroll
                 for (int nt = 0; nt < DH_NT; ++nt) acc[mt][nt] = (f4){0.f, 0.f, 0.f, 0.f};
             const unsigned char* sAl = sA + (ps & 1) * (DH_ROWS * DH_AROW) + c * DH_AROW + q * 16;
+            // one wave per SIMD: the A fragments of k-step ks+1 are requested before the 20 MFMAs of k-step ks are issued
+            h8 Af[2][4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) Af[0][mt] = *reinterpret_cast<const h8*>(sAl + mt * 16 * DH_AROW);
 #pragma unroll
             for (int ks = 0; ks < DH_KS; ++ks) {
-                h8 Af[4];
+                if (ks + 1 < DH_KS) {
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) Af[mt] = *reinterpret_cast<const h8*>(sAl + mt * 16 * DH_AROW + ks * 64);
+                    for (int mt = 0; mt < 4; ++mt)
+                        Af[(ks + 1) & 1][mt] = *reinterpret_cast<const h8*>(sAl + mt * 16 * DH_AROW + (ks + 1) * 64);
+                }
 #pragma unroll
                 for (int nt = 0; nt < DH_NT; ++nt)
 #pragma unroll
                     for (int mt = 0; mt < 4; ++mt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Af[mt], Bf[nt][ks], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Af[ks & 1][mt], Bf[nt][ks], acc[mt][nt], 0, 0, 0);
             }
             // ---- epilogue on the accumulator layout: row = mt*16 + q*4 + r -> (t = tp+mt, u = u0+4q+r), col = nt*16+c
-            if (DROPOUT) __builtin_amdgcn_s_waitcnt(0xC07F);  // mask table written (wave-private, in-order LDS)
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // mask table written (wave-private, in-order LDS)
             float ssum[4][DH_NT];
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                 uint2 mrow[4];
-                if (DROPOUT) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        mrow[r] = *reinterpret_cast<const uint2*>(smw + (mt * 16 + q * 4 + r) * 16 + (c >> 3) * 8);
-                }
+                for (int r = 0; r < 4; ++r) mrow[r] = *reinterpret_cast<const uint2*>(smw + (mt * 16 + q * 4 + r) * 16 + (c >> 3) * 8);
 #pragma unroll
                 for (int nt = 0; nt < DH_NT; ++nt) {
                     float s = 0.f;
@@ -183,7 +189,7 @@ __global__ __launch_bounds__(256, 1) void joint_dh_fused_kernel(DhArgs a) {
                     for (int r = 0; r < 4; ++r) {
                         const _Float16 prea = fh[mt][nt] + gh[r][nt];  // the forward's f16 pre-activation
                         bool keep = (float)prea > 0.f;
-                        if (DROPOUT) {
+                        {
                             const unsigned w = (nt < 4) ? mrow[r].x : mrow[r].y;
                             keep = keep && (((w >> ((nt & 3) * 8 + (c & 7))) & 1u) != 0u);
                         }
@@ -227,11 +233,11 @@ __global__ __launch_bounds__(256, 1) void joint_dh_fused_kernel(DhArgs a) {
                 }
             }
         }
-        if (ps + 1 < npass) DH_STORE((ps + 1) & 1);
+        DH_WAIT();
         __syncthreads();
     }
-#undef DH_LOAD
-#undef DH_STORE
+#undef DH_ASYNC
+#undef DH_WAIT
     // ---- d f rows of this chunk (every label tile summed)
     if (wave_on) {
         for (int i = lane; i < DH_TT * DH_NW; i += 64) {
@@ -269,7 +275,7 @@ __global__ __launch_bounds__(256) void joint_dh_dg_finish_kernel(const float* __
 }  // namespace
 
 extern "C" int ia_joint_dh_fused_supported(int U1, int H, int LD) {
-    return (U1 >= 1 && H >= DH_NW && H % DH_NW == 0 && LD % 8 == 0 && LD >= 8 && LD <= DH_KP && LD / 8 <= 4 * DH_NV) ? 1 : 0;
+    return (U1 >= 1 && H >= DH_NW && H % DH_NW == 0 && LD % 8 == 0 && LD >= 8 && LD <= DH_KP) ? 1 : 0;
 }
 
 extern "C" int ia_joint_dh_k(void) { return DH_KP; }
