@@ -41,6 +41,14 @@ struct DhArgs {
     unsigned seed, thr;
 };
 
+// acc += A x B with the accumulator in architectural VGPRs and the B fragment in an AGPR ("a" constraint).  The 45 resident
+// W^T fragments (180 registers) then live in the accumulation-register half for the whole kernel: left to itself the
+// compiler keeps them in the 256 architectural VGPRs, has a single register quad left for the A fragments (one LDS read,
+// one full-latency wait, five MFMAs, repeat) and shuffles ~100 values per pass through v_accvgpr moves.
+__device__ __forceinline__ void dh_mfma(f4& acc, const h8& a_frag, const h8& b_frag) {
+    asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a_frag), "a"(b_frag));
+}
+
 template <bool DROPOUT>
 __global__ __launch_bounds__(256, 1) void joint_dh_fused_kernel(DhArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -157,6 +165,14 @@ __global__ __launch_bounds__(256, 1) void joint_dh_fused_kernel(DhArgs a) {
 #pragma unroll
                 for (int nt = 0; nt < DH_NT; ++nt) acc[mt][nt] = (f4){0.f, 0.f, 0.f, 0.f};
             const unsigned char* sAl = sA + (ps & 1) * (DH_ROWS * DH_AROW) + c * DH_AROW + q * 16;
+#define DH_TIE_ACC                                                                                                  \
+    "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]), "+v"(acc[0][4]), "+v"(acc[1][0]), "+v"(acc[1][1]),  \
+        "+v"(acc[1][2]), "+v"(acc[1][3]), "+v"(acc[1][4]), "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[2][2]), "+v"(acc[2][3]), \
+        "+v"(acc[2][4]), "+v"(acc[3][0]), "+v"(acc[3][1]), "+v"(acc[3][2]), "+v"(acc[3][3]), "+v"(acc[3][4])
+            static_assert(DH_NT == 5, "DH_TIE_ACC lists 4 x 5 accumulators");
+            // The MFMAs below are inline asm: the compiler's hazard recogniser does not see them.  Both waits are tied to every
+            // accumulator, so they sit after the VALU zero-fill / after the last MFMA and before any use.
+            asm volatile("s_nop 4" : DH_TIE_ACC);
             // one wave per SIMD: the A fragments of k-step ks+1 are requested before the 20 MFMAs of k-step ks are issued
             h8 Af[2][4];
 #pragma unroll
@@ -172,8 +188,10 @@ __global__ __launch_bounds__(256, 1) void joint_dh_fused_kernel(DhArgs a) {
                 for (int nt = 0; nt < DH_NT; ++nt)
 #pragma unroll
                     for (int mt = 0; mt < 4; ++mt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Af[ks & 1][mt], Bf[nt][ks], acc[mt][nt], 0, 0, 0);
+                        dh_mfma(acc[mt][nt], Af[ks & 1][mt], Bf[nt][ks]);
             }
+            asm volatile("s_nop 15\n\ts_nop 15" : DH_TIE_ACC);
+#undef DH_TIE_ACC
             // ---- epilogue on the accumulator layout: row = mt*16 + q*4 + r -> (t = tp+mt, u = u0+4q+r), col = nt*16+c
             __builtin_amdgcn_s_waitcnt(0xC07F);  // mask table written (wave-private, in-order LDS)
             float ssum[4][DH_NT];
