@@ -14,12 +14,16 @@ __global__ __launch_bounds__(1024) void ia_partials_finish_kernel(const float* _
     const int c = blockIdx.x * 64 + cl;
     float a0 = 0.f, a1 = 0.f;
     if (c < C) {
+        // eight independent loads in flight per thread: the kernel is a pure latency chain otherwise (G / 32 round trips)
         int r = rg;
-        for (; r + 16 < G; r += 32) {
-            a0 += part[(size_t)r * C + c];
-            a1 += part[(size_t)(r + 16) * C + c];
+        for (; r + 112 < G; r += 128) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = part[(size_t)(r + 16 * k) * C + c];
+            a0 += (v[0] + v[2]) + (v[4] + v[6]);
+            a1 += (v[1] + v[3]) + (v[5] + v[7]);
         }
-        if (r < G) a0 += part[(size_t)r * C + c];
+        for (; r < G; r += 16) a0 += part[(size_t)r * C + c];
     }
     red[rg][cl] = a0 + a1;
     __syncthreads();
