@@ -129,10 +129,11 @@ class EncDecHybridRNNTCTCModel(nn.Module):
         self.spec_augment_enabled = True
         self.dither_enabled = True
         self.overlap_decoder = True      # prediction network on a side HIP stream (training_step)
+        self.overlap_ctc = True          # CTC head + CTC loss on a second side stream, under the joint (training_step)
 
     @staticmethod
-    def _side_stream(device):
-        key = device.index if device.index is not None else torch.cuda.current_device()
+    def _side_stream(device, which=0):
+        key = (device.index if device.index is not None else torch.cuda.current_device(), which)
         st = _SIDE_STREAMS.get(key)
         if st is None:
             st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
@@ -234,14 +235,35 @@ class EncDecHybridRNNTCTCModel(nn.Module):
             decoder.record_stream(main)
         else:
             decoder, target_length, states = self.decoder(targets=transcript, target_length=transcript_len)
+        # The CTC branch (257-column head, log-softmax, a latency-bound lattice kernel with one workgroup per utterance) only
+        # needs the encoder output: it runs on a second side stream under the joint, which fills the GPU on its own.  Issued
+        # BEFORE the joint: autograd then replays its backward (on the same side stream) after the joint's backward has
+        # been enqueued, i.e. concurrently with it; a stream of its own, so that it never queues behind the LSTM backward.
+        side2 = self._side_stream(signal.device, 1) if self.overlap_ctc and signal.is_cuda else None
+        if side2 is not None:
+            main = torch.cuda.current_stream(signal.device)
+            enc_ready = torch.cuda.Event()
+            enc_ready.record(main)
+            side2.wait_event(enc_ready)
+            with torch.cuda.stream(side2):
+                log_probs = self.ctc_decoder(encoder_output=encoded, language_ids=language_ids)
+                ctc_loss = self.ctc_loss(log_probs=log_probs, targets=transcript, input_lengths=encoded_len,
+                                         target_lengths=transcript_len)
+            for t in (encoded, encoded_len, transcript, transcript_len):
+                t.record_stream(side2)
         self.joint.loss_scale_hint = (1.0 - self.ctc_loss_weight) / max(1, signal.shape[0])
         self.joint.dropout_seed = (self.seed * 2654435761 + self._step * 40503) & 0x7FFFFFFF
         loss_value, wer, _, _ = self.joint(encoder_outputs=encoded, decoder_outputs=decoder, encoder_lengths=encoded_len,
                                            transcripts=transcript, transcript_lengths=transcript_len, compute_wer=False,
                                            language_ids=language_ids, host_lengths=(h_enc, h_tgt))
-        log_probs = self.ctc_decoder(encoder_output=encoded, language_ids=language_ids)
-        ctc_loss = self.ctc_loss(log_probs=log_probs, targets=transcript, input_lengths=encoded_len,
-                                 target_lengths=transcript_len)
+        if side2 is not None:
+            main.wait_stream(side2)
+            ctc_loss.record_stream(main)
+            log_probs.record_stream(main)
+        else:
+            log_probs = self.ctc_decoder(encoder_output=encoded, language_ids=language_ids)
+            ctc_loss = self.ctc_loss(log_probs=log_probs, targets=transcript, input_lengths=encoded_len,
+                                     target_lengths=transcript_len)
         rnnt_only = loss_value
         loss_value = (1 - self.ctc_loss_weight) * loss_value + self.ctc_loss_weight * ctc_loss
         vals = torch.stack([rnnt_only.detach().float(), ctc_loss.detach().float(), loss_value.detach().float()])
