@@ -450,3 +450,30 @@ def test_fused_block_dropout_masks_replayed_in_backward():
         w.add_(eps * vw)
     fd = (fp - fm) / (2 * eps)
     assert abs(fd - an) <= 0.1 * abs(an) + 1e-3, (fd, an)
+
+
+def test_side_streams_do_not_change_the_step():
+    """The prediction network and the CTC branch run on side HIP streams under the encoder / the joint (model.py); the
+    loss must be bit-identical to the single-stream schedule and the gradients equal up to the run-to-run noise of the
+    library kernels this tiny fp32 model still uses (atomics in the convolution weight gradient)."""
+    _, m = _pair()
+    m.train()
+    sig, sl, tr, tl = (t.cuda() for t in _batch())
+    results = []
+    for overlap in (True, False):
+        m.overlap_decoder = m.overlap_ctc = overlap
+        m._step = 0
+        m.zero_grad(set_to_none=True)
+        loss, mon = m.training_step((sig, sl, tr, tl), ['hi'] * sig.shape[0])
+        loss.backward()
+        torch.cuda.synchronize()
+        results.append((loss.detach().clone(), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None},
+                        (mon['train_rnnt_loss'], mon['train_ctc_loss'])))
+    (l0, g0, m0), (l1, g1, m1) = results
+    assert torch.equal(l0, l1) and m0 == m1
+    assert g0.keys() == g1.keys()
+    for n in g0:
+        assert torch.allclose(g0[n], g1[n], rtol=1e-5, atol=1e-6 * float(g0[n].abs().max()) + 1e-12), n
+    for n in g0:   # the modules that only run our own (deterministic) kernels or plain ATen GEMMs
+        if n.startswith(("ctc_decoder.", "joint.joint_net.")):
+            assert torch.equal(g0[n], g1[n]), n
