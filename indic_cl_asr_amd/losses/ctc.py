@@ -31,6 +31,9 @@ class _CTCHip(torch.autograd.Function):
         lp, tg, il, tl, ws, n, blank, dt = ctx.saved
         ctx.saved = None
         B, T, V = lp.shape
+        from ..ops import joint as _joint
+        if _joint.LAST_GRAD_KERNEL_EVENT is not None:   # on a side stream under the joint's backward: start after its
+            torch.cuda.current_stream(lp.device).wait_event(_joint.LAST_GRAD_KERNEL_EVENT)   # HBM-bound gradient kernel
         grad = torch.empty_like(lp)
         g = gnll.reshape(-1).float().contiguous()
         st = _lib.lib().ia_ctc_backward(_lib.ptr(lp), _lib.ptr(tg), _lib.ptr(il), _lib.ptr(tl), B, T, V, tg.shape[1], blank,

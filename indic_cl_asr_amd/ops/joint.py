@@ -18,6 +18,10 @@ USE_FUSED_DH = True
 # csrc/joint_dw.hip regenerates the hidden tile in LDS and contracts it with G row-major (transposing LDS reads): no
 # hidden^T tensor, no transposed copy of G.  False selects hidden^T + the batched split-K library GEMM.
 USE_FUSED_DW = True
+# Recorded right after the HBM-bound gradient kernel of the latest backward: work that other streams run under the joint's
+# backward (the CTC branch, losses/ctc.py) waits for it, so that kernel has the memory system to itself and the MFMA-bound
+# hidden- / weight-gradient kernels are the ones that share the GPU.
+LAST_GRAD_KERNEL_EVENT = None
 
 
 def fused_joint_supported(H, V, device):
@@ -95,6 +99,9 @@ class _FusedJointRNNT(torch.autograd.Function):
                                    LD, blank, fastemit, _lib.ptr(cg), kappa, _lib.ptr(GT), S, Kc, _lib.ptr(dbk), _lib.ptr(dbscr),
                                    _lib.ptr(ws), nbytes, _lib.stream_ptr(), ev0, ev1)
         _lib.check(st, "ia_joint_backward_g")
+        global LAST_GRAD_KERNEL_EVENT
+        LAST_GRAD_KERNEL_EVENT = torch.cuda.Event()
+        LAST_GRAD_KERNEL_EVENT.record()
         G = logits  # [cells, LD] f16, = kappa * dL/dlogits
         df = torch.zeros(B, T, H, dtype=torch.float32, device=dev)
         dg = torch.zeros(B, U1, H, dtype=torch.float32, device=dev)
