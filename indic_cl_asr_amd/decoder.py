@@ -212,9 +212,12 @@ class RNNTJoint(nn.Module):
         for m in self.joint_net[:-1]:
             if isinstance(m, nn.Dropout) and self.training:
                 p = float(m.p)
+        from .ops import fast
         with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
-            f = self.enc(enc[:, :max_t])
-            g = self.pred(dec[:, :max_u + 1])
+            # (fast.linear: HIP GEMM forward, weight + bias gradient on csrc/gemm_tn.hip instead of a 16-workgroup library
+            # TN GEMM and a bf16 column reduction; falls back to F.linear outside its shape limits)
+            f = fast.linear(enc[:, :max_t], self.enc.weight, self.enc.bias)
+            g = fast.linear(dec[:, :max_u + 1], self.pred.weight, self.pred.bias)
         lk = self._loss._loss
         costs = fused_joint_rnnt(f, g, head.weight, head.bias, transcripts[:, :max_u].contiguous().long(),
                                  encoder_lengths.long(), transcript_lengths.long(), lk.blank, dropout_p=p,
