@@ -117,6 +117,41 @@ class SpectrogramAugmentation(nn.Module):
         return fs.int().contiguous(), fw.int().contiguous(), ts.int().contiguous(), tl.int().contiguous()
 
     @torch.no_grad()
+    def draw_host(self, lengths, n_freq, device, generator=None):
+        """Same spans as draw() drawn with a CPU generator from HOST lengths (training_step has them): one pinned buffer and one
+        asynchronous H2D copy instead of ~30 tiny device kernels at the head of every step."""
+        B = len(lengths)
+        length = torch.as_tensor(lengths, dtype=torch.int64)
+        if self.freq_masks > 0:
+            fs = torch.randint(0, n_freq - self.freq_width + 1, (B, self.freq_masks), generator=generator)
+            fw = torch.randint(0, self.freq_width + 1, (B, self.freq_masks), generator=generator)
+        else:
+            fs = fw = torch.zeros(B, 1, dtype=torch.int64)
+        if self.time_masks > 0:
+            if isinstance(self.time_width, float):
+                tw = (length * self.time_width).int().clamp(min=1)
+            else:
+                tw = torch.full((B,), int(self.time_width), dtype=torch.int32)
+            hi_start = (length - tw).clamp(min=1).unsqueeze(1).float()
+            hi_len = (tw + 1).unsqueeze(1).float()
+            u1 = torch.rand(B, self.time_masks, generator=generator)
+            u2 = torch.rand(B, self.time_masks, generator=generator)
+            ts = torch.minimum((u1 * hi_start).floor(), hi_start - 1).long()
+            tl = torch.minimum((u2 * hi_len).floor(), hi_len - 1).long()
+        else:
+            ts = tl = torch.zeros(B, 1, dtype=torch.int64)
+        parts = [fs.int().reshape(-1), fw.int().reshape(-1), ts.int().reshape(-1), tl.int().reshape(-1)]
+        sizes = [p.numel() for p in parts]
+        host = torch.empty(sum(sizes), dtype=torch.int32, pin_memory=torch.device(device).type == "cuda")
+        torch.cat(parts, out=host)
+        dev = host.to(device, non_blocking=True)
+        outs, o = [], 0
+        for p, n in zip((fs, fw, ts, tl), sizes):
+            outs.append(dev[o:o + n].view(p.shape))
+            o += n
+        return tuple(outs)
+
+    @torch.no_grad()
     def forward(self, input_spec, length, generator=None):
         spans = self.draw(length, input_spec.shape[1], generator)
         return ops.spec_augment_(input_spec.clone(), length, spans, self.mask_value)

@@ -159,10 +159,18 @@ class EncDecHybridRNNTCTCModel(nn.Module):
         if not has_proc:
             spans = None
             if self.spec_augmentation is not None and self.training and self.spec_augment_enabled:
-                flen = self.preprocessor.featurizer.get_seq_len(input_signal_length)
-                g = torch.Generator(device=input_signal.device)
-                g.manual_seed(self.seed * 1000003 + self._step)
-                spans = self.spec_augmentation.draw(flen, self.cfg.feat_in, g)
+                host_len, self._host_signal_len = getattr(self, "_host_signal_len", None), None
+                if host_len is not None and len(host_len) == input_signal.shape[0]:
+                    # training_step knows the lengths on the host: spans from a CPU generator, one asynchronous copy
+                    g = torch.Generator()
+                    g.manual_seed(self.seed * 1000003 + self._step)
+                    flen_h = [mel_frame_count(int(n), self.cfg.n_fft, self.cfg.n_window_stride) for n in host_len]
+                    spans = self.spec_augmentation.draw_host(flen_h, self.cfg.feat_in, input_signal.device, g)
+                else:
+                    flen = self.preprocessor.featurizer.get_seq_len(input_signal_length)
+                    g = torch.Generator(device=input_signal.device)
+                    g.manual_seed(self.seed * 1000003 + self._step)
+                    spans = self.spec_augmentation.draw(flen, self.cfg.feat_in, g)
             processed_signal, processed_signal_length = self.preprocessor(
                 input_signal=input_signal, length=input_signal_length, spec_aug=spans, dither=self.dither_enabled,
                 seed=self.seed * 7919 + self._step)
@@ -221,6 +229,7 @@ class EncDecHybridRNNTCTCModel(nn.Module):
             main = torch.cuda.current_stream(signal.device)
             inputs_ready = torch.cuda.Event()
             inputs_ready.record(main)
+        self._host_signal_len = h_sig   # lets forward() draw the SpecAugment spans on the host
         encoded, encoded_len = self.forward(input_signal=signal, input_signal_length=signal_len)
         if side is not None:
             side.wait_event(inputs_ready)

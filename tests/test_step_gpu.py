@@ -71,9 +71,11 @@ def test_training_step_loss_and_grads_match_oracle():
     from indic_cl_asr_amd.model import freeze_layer
     freeze_layer(m, 0); m.encoder.encoder_frozen_till = 0
     # SpecAugment with the spans the product draws for this step, replayed into the oracle
-    flen = m.preprocessor.featurizer.get_seq_len(batch[1].cuda())
-    gen = torch.Generator(device="cuda"); gen.manual_seed(m.seed * 1000003 + m._step)
-    fs, fw, ts, tw = [t.cpu().tolist() for t in m.spec_augmentation.draw(flen, 80, gen)]
+    # (training_step knows the lengths on the host and draws the spans with a CPU generator: features.SpecAugment.draw_host)
+    from indic_cl_asr_amd.features import mel_frame_count
+    gen = torch.Generator(); gen.manual_seed(m.seed * 1000003 + m._step)
+    flen_h = [mel_frame_count(int(n), m.cfg.n_fft, m.cfg.n_window_stride) for n in batch[1].tolist()]
+    fs, fw, ts, tw = [t.cpu().tolist() for t in m.spec_augmentation.draw_host(flen_h, 80, "cuda", gen)]
     spans = ([list(zip(a, b)) for a, b in zip(fs, fw)], [list(zip(a, b)) for a, b in zip(ts, tw)])
     lo, mo = o.training_step(batch, ['hi'] * 5, spec_aug=spans)
     lo.backward()
