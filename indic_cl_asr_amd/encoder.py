@@ -243,8 +243,10 @@ class ConformerEncoder(nn.Module):
             return torch.autocast(device_type="cuda", dtype=torch.bfloat16)
         return nullcontext()
 
-    def forward(self, audio_signal, length):
-        """audio_signal [B,feat,Tm] f32, length [B] i64 -> (encoded [B,d,T'], encoded_len [B] i64)."""
+    def forward(self, audio_signal, length, subsampled_len=None):
+        """audio_signal [B,feat,Tm] f32, length [B] i64 -> (encoded [B,d,T'], encoded_len [B] i64).
+        `subsampled_len`: optional precomputed [B] i64 device tensor of the output lengths (the caller knew the lengths on
+        the host: saves the half-dozen tiny integer kernels of the frame-count rule)."""
         from . import cl
         if cl._PENDING_OPTIMIZERS and any(p.requires_grad for p in self.pre_encode.parameters()):
             cl.flush_pending_updates()   # deferred data-parallel update: the subsampling weights are about to be read
@@ -256,10 +258,12 @@ class ConformerEncoder(nn.Module):
                         and not (torch.is_grad_enabled() and any(p.requires_grad for p in pe.parameters()))
                         and fast.subsample_supported(pe.conv[0].weight.shape[0], self.d_model, self.cfg.feat_in)):
                     x = fast.conv_subsampling(audio_signal, pe.conv[0], pe.conv[2], pe.out)
-                    length = subsampled_length(length)
+                    length = subsampled_length(length) if subsampled_len is None else subsampled_len
                 else:
                     x = audio_signal.transpose(1, 2)
                     x, length = pe(x, length)
+                    if subsampled_len is not None:
+                        length = subsampled_len
                 length = length.to(torch.int64)
                 T = x.size(1)
                 x, pos_emb = self.pos_enc(x)

@@ -67,13 +67,15 @@ class AudioToMelSpectrogramPreprocessor(nn.Module):
         self.featurizer = FilterbankFeaturizer(cfg)
 
     @torch.no_grad()
-    def forward(self, input_signal, length, spec_aug=None, dither=True, seed=0):
+    def forward(self, input_signal, length, spec_aug=None, dither=True, seed=0, seq_len=None):
         """-> (processed_signal [B, feat_in, Tm] f32, processed_length [B] i64).
+        `seq_len`: optional precomputed frame counts ([B] i64 device tensor, same rule, from host lengths).
         `spec_aug`: optional (freq_starts, freq_widths, time_starts, time_widths) i32 [B,M] device tensors applied
         in the normalisation epilogue."""
         f = self.featurizer
         use_dither = bool(dither and self.training and f.dither > 0)
-        seq_len = f.get_seq_len(length)
+        if seq_len is None:
+            seq_len = f.get_seq_len(length)
         x = ops.log_mel(input_signal, f.window, f.fb[0], n_fft=f.n_fft, hop=f.hop_length, preemph=f.preemph,
                         dither=f.dither if use_dither else 0.0, seed=seed, log_guard=f.log_zero_guard_value)
         x = ops.normalize_mask(x, seq_len, spec_aug)

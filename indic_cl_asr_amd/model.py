@@ -156,11 +156,22 @@ class EncDecHybridRNNTCTCModel(nn.Module):
         if (has_input ^ has_proc) is False:
             raise ValueError(f"{self} Arguments ``input_signal`` and ``input_signal_length`` are mutually exclusive "
                              " with ``processed_signal`` and ``processed_signal_len`` arguments.")
+        sub_len = None
         if not has_proc:
             spans = None
+            flen_dev = None
+            host_len, self._host_signal_len = getattr(self, "_host_signal_len", None), None   # (one-shot hint of training_step)
+            if host_len is not None and len(host_len) != input_signal.shape[0]:
+                host_len = None
+            if host_len is not None and input_signal.is_cuda:
+                # the lengths are known on the host (training_step): frame counts before / after subsampling by the integer
+                # rule, one pinned asynchronous copy instead of ~12 tiny integer kernels
+                fl = [mel_frame_count(int(n), self.cfg.n_fft, self.cfg.n_window_stride) for n in host_len]
+                both = torch.tensor([fl, [subsampled_length(n) for n in fl]], dtype=torch.int64).pin_memory()
+                both = both.to(input_signal.device, non_blocking=True)
+                flen_dev, sub_len = both[0], both[1]
             if self.spec_augmentation is not None and self.training and self.spec_augment_enabled:
-                host_len, self._host_signal_len = getattr(self, "_host_signal_len", None), None
-                if host_len is not None and len(host_len) == input_signal.shape[0]:
+                if host_len is not None:
                     # training_step knows the lengths on the host: spans from a CPU generator, one asynchronous copy
                     g = torch.Generator()
                     g.manual_seed(self.seed * 1000003 + self._step)
@@ -173,11 +184,11 @@ class EncDecHybridRNNTCTCModel(nn.Module):
                     spans = self.spec_augmentation.draw(flen, self.cfg.feat_in, g)
             processed_signal, processed_signal_length = self.preprocessor(
                 input_signal=input_signal, length=input_signal_length, spec_aug=spans, dither=self.dither_enabled,
-                seed=self.seed * 7919 + self._step)
+                seed=self.seed * 7919 + self._step, seq_len=flen_dev)
         elif self.spec_augmentation is not None and self.training and self.spec_augment_enabled:
             processed_signal = self.spec_augmentation(input_spec=processed_signal, length=processed_signal_length)
         self.encoder.fast_seed = (self.seed * 31 + self._step) & 0x7FFFFFFF
-        encoded, encoded_len = self.encoder(audio_signal=processed_signal, length=processed_signal_length)
+        encoded, encoded_len = self.encoder(audio_signal=processed_signal, length=processed_signal_length, subsampled_len=sub_len)
         return encoded, encoded_len
 
     # ------------------------------------------------------------------ greedy decoding / WER
