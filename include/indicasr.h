@@ -259,12 +259,17 @@ int64_t ia_attn_bwd_unpack_scratch_elems(int B, int T, int H);
  *                     -> dG [U,B,4H] f32 = gradient w.r.t. the gate pre-activations; dW_ih = dG^T x, dW_hh = dG[1:]^T Hout[:-1],
  *                     db = sum dG, dx = dG W_ih are GEMMs/reductions by the caller.
  *   scratch: ia_lstm_scratch_bytes(B,H), 256-byte aligned, caller-owned (hand-off buffers + arrival counter; the
- *            launcher zeroes the counter words on the stream).  After completion scratch word [1] != 0 means a bounded
- *            spin gave up (results invalid) -- the kernels cannot hang.
+ *            launcher zeroes the counter words -- the first 128 bytes -- on the stream).  After completion scratch word
+ *            [1] != 0 means a bounded spin gave up (results invalid) -- the kernels cannot hang.  Word [32] is the same
+ *            flag but STICKY: the launcher never clears it, so a caller that keeps one scratch buffer per stream can
+ *            poll it once per step (the Python side turns it into RuntimeError, ops/lstm.py).  The spin bound can be
+ *            lowered through the environment variable IA_LSTM_SPIN_LIMIT (tests force a timeout with it).
+ *   ia_lstm_lds_bytes(H, backward): LDS bytes one workgroup needs (> 160 KiB => IA_UNSUPPORTED from the launchers).
  *   Limits: B <= 32 per call (split larger batches: rows are independent), H % 32 == 0, H/16 workgroups must be
  *           co-resident (H <= 4096).  One workgroup per 16 hidden units keeps its W_hh slice in LDS for the whole sequence.
  */
 size_t ia_lstm_scratch_bytes(int B, int H);
+int ia_lstm_lds_bytes(int H, int backward);
 int ia_lstm_forward(const float* Gx, const void* Whh_bf16, float* Hout, float* gates, float* Cs, int U, int B, int H,
                     void* scratch, size_t scratch_bytes, ia_stream_t stream);
 int ia_lstm_backward(const float* dHout, const float* gates, const float* Cs, const void* WhhT_bf16, float* dG, int U,
@@ -394,6 +399,13 @@ int ia_attn_keepmask(int B, int H, int T, float dropout_p, unsigned seed, void* 
  * ia_adamw_step            torch.optim.AdamW update (R/cl_baseline.py:137; lr 1e-4, betas .9/.999, eps 1e-8, wd 1e-2),
  *                          `step` counts from 1; grad is multiplied by grad_scale first (1.0, or 1/world for DP mean);
  *                          shadow_bf16 (optional, n x bf16) receives the updated weights rounded to bf16.
+ * ia_adamw_step_segmented  the same update per TENSOR, with torch.optim.AdamW's treatment of `p.grad is None`
+ *                          (optimizer.zero_grad() sets grads to None, R/cl_baseline.py:187: a tensor that received no
+ *                          gradient -- the other 21 language heads, heads of finished tasks -- gets no weight decay, no
+ *                          moment decay and keeps its own step counter).  seg_active[nseg] i32 (zero on entry, zero on
+ *                          exit), seg_step[nseg] i32 per-tensor step counters (advanced here); a tensor is live when any
+ *                          bit of its gradient is set, or always when all_active != 0 (a penalty was pre-loaded into
+ *                          every .grad: set_grads R/utils.py:316-321).  Three launches on `stream`.
  */
 int ia_cl_chunk_elems(void);
 int ia_cl_penalty(const float* theta, const float* theta_star, const float* weight, float coef, float* grad,
@@ -404,6 +416,10 @@ int ia_cl_abs_accumulate(float* omega, const float* grad, int64_t n, ia_stream_t
 int ia_adamw_step(float* theta, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int step, float grad_scale, void* shadow_bf16,
                   ia_stream_t stream);
+int ia_adamw_step_segmented(float* theta, const float* grad, float* exp_avg, float* exp_avg_sq, const int32_t* chunk_table,
+                            int nchunks, int32_t* seg_active, int32_t* seg_step, int nseg, int all_active, float lr,
+                            float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* shadow_bf16,
+                            ia_stream_t stream);
 
 #ifdef __cplusplus
 }

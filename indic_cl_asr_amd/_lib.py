@@ -72,6 +72,7 @@ SIGNATURES = {
     "ia_attn_bwd_unpack": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "ia_attn_bwd_unpack_scratch_elems": (_i64, [_i, _i, _i]),
     "ia_lstm_scratch_bytes": (_sz, [_i, _i]),
+    "ia_lstm_lds_bytes": (_i, [_i, _i]),
     "ia_lstm_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "ia_lstm_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "ia_feat_frames": (_i, [_vp, _i, _i, _i, _i, _i, _f, _f, _c.c_uint, _vp, _i, _vp]),
@@ -101,6 +102,7 @@ SIGNATURES = {
     "ia_cl_fisher_accumulate": (_i, [_vp, _vp, _vp, _i64, _vp]),
     "ia_cl_abs_accumulate": (_i, [_vp, _vp, _i64, _vp]),
     "ia_adamw_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f, _vp, _vp]),
+    "ia_adamw_step_segmented": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _f, _f, _f, _f, _f, _vp, _vp]),
 }
 
 _lib = None

@@ -31,10 +31,15 @@ def save_trainable(model, path):
 
 def load_weights(model, path_or_state, strict=False):
     """Full or trainable-only state dict (file or dict) into the model; returns torch's (missing, unexpected) report."""
+    from . import cl
+    from .ops import fast
+    cl.flush_pending_updates()   # a deferred data-parallel AdamW update must land BEFORE the new weights, not on top of them
     state = torch.load(path_or_state, map_location="cpu") if isinstance(path_or_state, (str, os.PathLike)) else path_or_state
     if isinstance(state, dict) and "state_dict" in state and not any(torch.is_tensor(v) for v in state.values()):
         state = state["state_dict"]          # Lightning-style wrapper
-    return getattr(model, "module", model).load_state_dict(state, strict=strict)
+    report = getattr(model, "module", model).load_state_dict(state, strict=strict)
+    fast.invalidate_weight_caches()          # bf16 weight images of the old values must not be served again
+    return report
 
 
 def read_nemo(path) -> Tuple[dict, Dict[str, torch.Tensor]]:

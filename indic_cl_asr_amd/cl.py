@@ -68,6 +68,9 @@ class FlatParams:
                 rows.append((o + c0, min(ch, k - c0), seg, 0))
         self.chunk_table = torch.tensor(rows, dtype=torch.int32, device=dev)
         self.seg_inv_numel = torch.tensor([1.0 / e[2] for e in self.entries], dtype=torch.float32, device=dev)
+        # True once something gave EVERY trainable tensor a gradient since the last zero_grad (a pre-loaded EWC penalty /
+        # the MAS penalty: R/utils.py:316-321, R/cl_baseline_mas.py:231-234) -- torch.optim.AdamW then updates them all
+        self.all_grads_live = False
         model._ia_flat = self
 
     # -- buffers ---------------------------------------------------------------------------------
@@ -91,6 +94,7 @@ class FlatParams:
 
     def zero_grad(self):
         self.grad.zero_()
+        self.all_grads_live = False
         self.attach_grads()
 
     @contextmanager
@@ -143,6 +147,7 @@ def set_grads(model, grad_dict):
     if isinstance(grad_dict, FlatDict) and grad_dict.flat.data_ptr() != f.grad.data_ptr():
         f.grad.copy_(grad_dict.flat)
         grad_dict = f.grads_dict()
+    f.all_grads_live = True
     for name, p in getattr(model, "module", model).named_parameters():
         p.grad = grad_dict[name] if name in grad_dict else None
 
@@ -166,6 +171,7 @@ def ewc_penalty_into_grads(flat: FlatParams, fisher: FlatDict, checkpoint: FlatD
                          _lib.ptr(flat.seg_inv_numel), _lib.ptr(seg), None, _lib.stream_ptr())
     _lib.check(st, "ia_cl_penalty")
     flat.attach_grads()
+    flat.all_grads_live = True
     return seg.mean()
 
 
@@ -211,6 +217,7 @@ def mas_penalty_add_grads(flat: FlatParams, importance: FlatDict, checkpoint: Fl
                                   2.0 * float(mas_lambda), _lib.ptr(flat.grad), 1, _lib.ptr(flat.chunk_table),
                                   flat.chunk_table.shape[0], None, None, _lib.ptr(val), _lib.stream_ptr())
     _lib.check(st, "ia_cl_penalty")
+    flat.all_grads_live = True
     return val[0]
 
 
@@ -294,10 +301,15 @@ class FusedAdamW:
         self.exp_avg = torch.zeros_like(self.flat.theta)
         self.exp_avg_sq = torch.zeros_like(self.flat.theta)
         self.step_count = 0
+        # torch.optim.AdamW keeps one step counter per parameter and skips parameters whose .grad is None: per-tensor
+        # counters + "received a gradient" flags live on the device (ia_adamw_step_segmented)
+        nseg = len(self.flat.entries)
+        self.seg_step = torch.zeros(nseg, dtype=torch.int32, device=self.flat.theta.device)
+        self.seg_active = torch.zeros(nseg, dtype=torch.int32, device=self.flat.theta.device)
         self.group = group
         if bf16_shadow is None:  # the HIP GEMM paths consume bf16 weights: let the optimizer kernel emit them (one launch)
             bf16_shadow = self.flat.theta.is_cuda
-        self.shadow = torch.zeros(self.flat.numel, dtype=torch.bfloat16, device=self.flat.theta.device) if bf16_shadow else None
+        self.shadow = self.flat.theta.to(torch.bfloat16) if bf16_shadow else None
         self.param_groups = [dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, params=self.flat.params)]
         self.defer_update = defer_update   # data parallel only: overlap the gradient all-reduce with the next forward
         self._pending, self._zero_after_flush = None, False
@@ -330,31 +342,33 @@ class FusedAdamW:
         gs = 1.0 if grad_scale is None else grad_scale
         if ws > 1 and self.defer_update:
             work = dist.all_reduce(self.flat.grad, group=self.group, async_op=True)
-            self._pending = (work, gs / ws)
+            self._pending = (work, gs / ws, self.flat.all_grads_live)
             _PENDING_OPTIMIZERS.add(self)
             return
-        self._apply(self.allreduce_grads() * gs)
+        self._apply(self.allreduce_grads() * gs, self.flat.all_grads_live)
 
     def flush(self):
         if self._pending is None:
             return
-        work, scale = self._pending
+        work, scale, live = self._pending
         self._pending = None
         _PENDING_OPTIMIZERS.discard(self)
         work.wait()
-        self._apply(scale)
+        self._apply(scale, live)
         if self._zero_after_flush:
             self._zero_after_flush = False
             self.flat.zero_grad()
 
-    def _apply(self, scale):
+    def _apply(self, scale, all_live=False):
         self.step_count += 1
         g = self.param_groups[0]
-        st = _lib.lib().ia_adamw_step(_lib.ptr(self.flat.theta), _lib.ptr(self.flat.grad), _lib.ptr(self.exp_avg),
-                                      _lib.ptr(self.exp_avg_sq), self.flat.numel, float(g["lr"]), float(g["betas"][0]),
-                                      float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), self.step_count,
-                                      float(scale), _lib.ptr(self.shadow), _lib.stream_ptr())
-        _lib.check(st, "ia_adamw_step")
+        f = self.flat
+        st = _lib.lib().ia_adamw_step_segmented(
+            _lib.ptr(f.theta), _lib.ptr(f.grad), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq), _lib.ptr(f.chunk_table),
+            f.chunk_table.shape[0], _lib.ptr(self.seg_active), _lib.ptr(self.seg_step), len(f.entries), int(bool(all_live)),
+            float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
+            float(scale), _lib.ptr(self.shadow), _lib.stream_ptr())
+        _lib.check(st, "ia_adamw_step_segmented")
         if self.flat.theta.is_cuda:
             global LAST_UPDATE_EVENT
             LAST_UPDATE_EVENT = torch.cuda.Event()

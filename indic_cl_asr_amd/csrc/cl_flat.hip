@@ -128,6 +128,88 @@ __global__ __launch_bounds__(CL_THREADS) void adamw_kernel(float* __restrict__ p
         }
 }
 
+
+// ---- per-tensor ("segment") AdamW: torch.optim.AdamW skips a parameter whose .grad is None (other languages' joint
+// heads, heads of finished tasks) -- no weight decay, no moment decay, its own step counter.  With one flat gradient
+// buffer "None" is "the segment received nothing since zero_grad": all-zero bits (or the host says every segment is
+// live because a penalty was pre-loaded into .grad: R/utils.py:316-321 gives EVERY trainable tensor a gradient then).
+__global__ __launch_bounds__(CL_THREADS) void seg_activity_kernel(const float* __restrict__ g, const int4* __restrict__ table,
+                                                                  int nchunks, int* __restrict__ seg_active) {
+    for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const int4 e = table[c];
+        const int off = e.x, cnt = e.y, n4 = cnt >> 2;
+        unsigned nz = 0;
+        for (int q = threadIdx.x; q < n4; q += CL_THREADS) {
+            const uint4 x = reinterpret_cast<const uint4*>(g + off)[q];
+            nz |= (x.x | x.y | x.z | x.w) & 0x7FFFFFFFu;   // -0.0 counts as zero
+        }
+        for (int i = (n4 << 2) + threadIdx.x; i < cnt; i += CL_THREADS) nz |= __float_as_uint(g[off + i]) & 0x7FFFFFFFu;
+        if (__any(nz != 0) && (threadIdx.x & 63) == 0) atomicOr(seg_active + e.z, 1);
+    }
+}
+
+__global__ __launch_bounds__(CL_THREADS) void adamw_seg_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                               float* __restrict__ m, float* __restrict__ v,
+                                                               const int4* __restrict__ table, int nchunks,
+                                                               const int* __restrict__ seg_active,
+                                                               const int* __restrict__ seg_step, float lr, float b1, float b2,
+                                                               float eps, float wd, float grad_scale,
+                                                               unsigned short* __restrict__ shadow_bf16) {
+    __shared__ float sh_c[2];
+    for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const int4 e = table[c];
+        if (!seg_active[e.z]) {           // workgroup-uniform: untouched tensor -- only keep its bf16 image in step
+            if (shadow_bf16)
+                for (int i = threadIdx.x; i < e.y; i += CL_THREADS) {
+                    __hip_bfloat16 a = __float2bfloat16(p[e.x + i]);
+                    shadow_bf16[e.x + i] = *reinterpret_cast<unsigned short*>(&a);
+                }
+            continue;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const double step = (double)(seg_step[e.z] + 1);
+            sh_c[0] = (float)((double)lr / (1.0 - pow((double)b1, step)));
+            sh_c[1] = (float)(1.0 / sqrt(1.0 - pow((double)b2, step)));
+        }
+        __syncthreads();
+        const float step_size = sh_c[0], inv_bc2_sqrt = sh_c[1];
+        const int off = e.x, cnt = e.y, n4 = cnt >> 2;
+        for (int q = threadIdx.x; q < n4; q += CL_THREADS) {
+            float4 P = reinterpret_cast<float4*>(p + off)[q];
+            const float4 G = reinterpret_cast<const float4*>(g + off)[q];
+            float4 M = reinterpret_cast<float4*>(m + off)[q];
+            float4 V = reinterpret_cast<float4*>(v + off)[q];
+            adamw1(P.x, G.x * grad_scale, M.x, V.x, lr, b1, b2, eps, wd, step_size, inv_bc2_sqrt);
+            adamw1(P.y, G.y * grad_scale, M.y, V.y, lr, b1, b2, eps, wd, step_size, inv_bc2_sqrt);
+            adamw1(P.z, G.z * grad_scale, M.z, V.z, lr, b1, b2, eps, wd, step_size, inv_bc2_sqrt);
+            adamw1(P.w, G.w * grad_scale, M.w, V.w, lr, b1, b2, eps, wd, step_size, inv_bc2_sqrt);
+            reinterpret_cast<float4*>(p + off)[q] = P;
+            reinterpret_cast<float4*>(m + off)[q] = M;
+            reinterpret_cast<float4*>(v + off)[q] = V;
+            if (shadow_bf16) {
+                __hip_bfloat16 a = __float2bfloat16(P.x), b = __float2bfloat16(P.y), cc = __float2bfloat16(P.z),
+                               d = __float2bfloat16(P.w);
+                ushort4 o;
+                o.x = *reinterpret_cast<unsigned short*>(&a); o.y = *reinterpret_cast<unsigned short*>(&b);
+                o.z = *reinterpret_cast<unsigned short*>(&cc); o.w = *reinterpret_cast<unsigned short*>(&d);
+                reinterpret_cast<ushort4*>(shadow_bf16 + off)[q] = o;
+            }
+        }
+        for (int i = (n4 << 2) + threadIdx.x; i < cnt; i += CL_THREADS) {
+            float P = p[off + i], M = m[off + i], V = v[off + i];
+            adamw1(P, g[off + i] * grad_scale, M, V, lr, b1, b2, eps, wd, step_size, inv_bc2_sqrt);
+            p[off + i] = P; m[off + i] = M; v[off + i] = V;
+            if (shadow_bf16) { __hip_bfloat16 a = __float2bfloat16(P); shadow_bf16[off + i] = *reinterpret_cast<unsigned short*>(&a); }
+        }
+    }
+}
+
+__global__ void seg_step_advance_kernel(int* __restrict__ seg_active, int* __restrict__ seg_step, int nseg) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < nseg) { seg_step[s] += seg_active[s] ? 1 : 0; seg_active[s] = 0; }
+}
+
 inline int cap_grid(int64_t work_items, int per_block) {
     int64_t b = (work_items + per_block - 1) / per_block;
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -181,6 +263,31 @@ extern "C" int ia_adamw_step(float* theta, const float* grad, float* exp_avg, fl
     hipLaunchKernelGGL(adamw_kernel, dim3(cap_grid(n >> 2, CL_THREADS * 4)), dim3(CL_THREADS), 0, (hipStream_t)stream, theta,
                        grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step_size, inv_bc2_sqrt,
                        grad_scale, (unsigned short*)shadow_bf16);
+    IA_RETURN_IF_LAUNCH_FAILED();
+    return IA_OK;
+}
+
+extern "C" int ia_adamw_step_segmented(float* theta, const float* grad, float* exp_avg, float* exp_avg_sq,
+                                       const int32_t* chunk_table, int nchunks, int32_t* seg_active, int32_t* seg_step, int nseg,
+                                       int all_active, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                       float grad_scale, void* shadow_bf16, ia_stream_t stream) {
+    if (!theta || !grad || !exp_avg || !exp_avg_sq || !chunk_table || !seg_active || !seg_step || nchunks <= 0 || nseg <= 0)
+        return IA_INVALID_VALUE;
+    if (!ia_is_aligned(theta, 16) || !ia_is_aligned(grad, 16) || !ia_is_aligned(exp_avg, 16) ||
+        !ia_is_aligned(exp_avg_sq, 16) || !ia_is_aligned(chunk_table, 16) || (shadow_bf16 && !ia_is_aligned(shadow_bf16, 8)))
+        return IA_INVALID_VALUE;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = nchunks < 2048 ? nchunks : 2048;
+    if (all_active) {
+        if (hipMemsetAsync(seg_active, 1, (size_t)nseg * sizeof(int32_t), st) != hipSuccess) return IA_LAUNCH_FAILED;  // 0x01010101: non-zero
+    } else {
+        hipLaunchKernelGGL(seg_activity_kernel, dim3(grid), dim3(CL_THREADS), 0, st, grad, (const int4*)chunk_table, nchunks,
+                           seg_active);
+    }
+    hipLaunchKernelGGL(adamw_seg_kernel, dim3(grid), dim3(CL_THREADS), 0, st, theta, grad, exp_avg, exp_avg_sq,
+                       (const int4*)chunk_table, nchunks, seg_active, seg_step, lr, beta1, beta2, eps, weight_decay, grad_scale,
+                       (unsigned short*)shadow_bf16);
+    hipLaunchKernelGGL(seg_step_advance_kernel, dim3((nseg + 255) / 256), dim3(256), 0, st, seg_active, seg_step, nseg);
     IA_RETURN_IF_LAUNCH_FAILED();
     return IA_OK;
 }

@@ -11,6 +11,8 @@
 // gradients of step t.  dW_ih, dW_hh, db and dx are GEMMs over the stored gate gradients, done by the caller.
 #include <hip/hip_bf16.h>
 
+#include <stdlib.h>
+
 #include "ia_common.h"
 
 namespace {
@@ -23,6 +25,7 @@ constexpr int LS_HB = 16;        // hidden units per workgroup
 constexpr int LS_THREADS = 256;
 constexpr int LS_MAXB = 32;      // batch rows per launch (2 MFMA row tiles); the host splits larger batches
 constexpr unsigned LS_SPIN_LIMIT = 1u << 22;
+constexpr int LS_STICKY_WORD = 32;  // scratch word that survives launches: set on a hand-off timeout, cleared by the host only
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
@@ -37,12 +40,16 @@ __device__ __forceinline__ void grid_arrive(unsigned* counter) {
         __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
-__device__ __forceinline__ void grid_wait(unsigned* counter, unsigned target, unsigned* status) {
+__device__ __forceinline__ void grid_wait(unsigned* counter, unsigned target, unsigned* status, unsigned spin_limit) {
     if (threadIdx.x == 0) {
         unsigned spins = 0;
         while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(2);
-            if (++spins > LS_SPIN_LIMIT) { __hip_atomic_store(status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            if (++spins > spin_limit) {   // lost hand-off: flag it (this launch + the sticky word the host polls) and go on
+                __hip_atomic_store(status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(status + LS_STICKY_WORD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -58,8 +65,8 @@ __global__ __launch_bounds__(LS_THREADS, 1) void lstm_fwd_kernel(
     float* __restrict__ gates,         // [U][B][4H]  activated i,f,g,o (NULL: inference)
     float* __restrict__ Cs,            // [U][B][H]   cell states     (NULL: inference)
     __bf16* hx,                        // [2][B][H] exchange (written by all workgroups)
-    unsigned* sync,                    // [0] arrival counter, [1] timeout flag (zeroed by the launcher)
-    int U, int B, int H) {
+    unsigned* sync,                    // [0] arrival counter, [1] timeout flag (zeroed by the launcher), [32] sticky timeout flag
+    int U, int B, int H, unsigned spin_limit) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wrow = H * 2 + 16;                        // bytes per LDS row
     unsigned char* sW = smem;                           // 64 rows: gate*16 + unit
@@ -91,7 +98,7 @@ __global__ __launch_bounds__(LS_THREADS, 1) void lstm_fwd_kernel(
 #pragma unroll
         for (int rt = 0; rt < NRT; ++rt) acc[rt] = (f4){0.f, 0.f, 0.f, 0.f};
         if (t > 0) {
-            grid_wait(sync, (unsigned)(nb * t), sync);
+            grid_wait(sync, (unsigned)(nb * t), sync, spin_limit);
             const __bf16* hsrc = hx + (size_t)((t - 1) & 1) * B * H;
             for (int i = tid; i < B * (H / 8); i += LS_THREADS) {
                 const int r = i / (H / 8), v = i - r * (H / 8);
@@ -149,7 +156,7 @@ __global__ __launch_bounds__(LS_THREADS, 1) void lstm_bwd_kernel(
     const __bf16* __restrict__ WhhT,   // [H][4H]   (W_hh transposed)
     float* __restrict__ dG,            // [U][B][4H] gradient w.r.t. the gate pre-activations (out)
     __bf16* dgx,                       // [2][B][4H] exchange
-    unsigned* sync, int U, int B, int H) {
+    unsigned* sync, int U, int B, int H, unsigned spin_limit) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int H4 = 4 * H;
     const int wrow = H4 * 2 + 16;
@@ -176,7 +183,7 @@ __global__ __launch_bounds__(LS_THREADS, 1) void lstm_bwd_kernel(
         for (int rt = 0; rt < NRT; ++rt) acc[rt] = (f4){0.f, 0.f, 0.f, 0.f};
         if (t < U - 1) {
             // d h_t (recurrent part) = dpre_{t+1} @ W_hh  restricted to this workgroup's 16 units
-            grid_wait(sync, (unsigned)(nb * phase), sync);
+            grid_wait(sync, (unsigned)(nb * phase), sync, spin_limit);
             const __bf16* src = dgx + (size_t)((phase - 1) & 1) * B * H4;
             const int k0 = wave * kper, k1 = (k0 + kper < ksteps) ? (k0 + kper) : ksteps;
             for (int ks = k0; ks < k1; ++ks) {
@@ -234,6 +241,19 @@ extern "C" size_t ia_lstm_scratch_bytes(int B, int H) {
     return 256 + ia_align_up((size_t)2 * B * 4 * H * sizeof(__bf16), 256);  // sync words + the larger exchange buffer
 }
 
+// Bound of the hand-off spins.  IA_LSTM_SPIN_LIMIT (environment, read per call) exists for the test that forces a timeout.
+static unsigned lstm_spin_limit() {
+    const char* e = getenv("IA_LSTM_SPIN_LIMIT");
+    if (e && *e) { const long v = atol(e); if (v >= 0) return (unsigned)v; }
+    return LS_SPIN_LIMIT;
+}
+
+extern "C" int ia_lstm_lds_bytes(int H, int backward) {
+    if (H <= 0) return 0;
+    return backward ? (int)((size_t)LS_HB * (4 * H * 2 + 16) + 4 * LS_MAXB * 16 * sizeof(float))
+                    : (int)((size_t)(64 + LS_MAXB) * (H * 2 + 16) + 4 * LS_MAXB * 16 * sizeof(float));
+}
+
 static int lstm_check(int U, int B, int H) {
     if (U <= 0 || B <= 0 || H <= 0) return IA_INVALID_VALUE;
     if (B > LS_MAXB || H % 32 != 0 || H % LS_HB != 0 || H / LS_HB > 256) return IA_UNSUPPORTED;
@@ -248,13 +268,13 @@ extern "C" int ia_lstm_forward(const float* Gx, const void* Whh_bf16, float* Hou
     if (scratch_bytes < ia_lstm_scratch_bytes(B, H) || !ia_is_aligned(scratch, 256) || !ia_is_aligned(Whh_bf16, 16))
         return IA_INVALID_VALUE;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(scratch, 0, 256, st) != hipSuccess) return IA_LAUNCH_FAILED;
+    if (hipMemsetAsync(scratch, 0, 128, st) != hipSuccess) return IA_LAUNCH_FAILED;   // (the sticky word at byte 128 survives)
     const size_t lds = (size_t)(64 + LS_MAXB) * (H * 2 + 16) + 4 * LS_MAXB * 16 * sizeof(float);
     if (lds > 160 * 1024) return IA_UNSUPPORTED;
     if (hipFuncSetAttribute((const void*)lstm_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return IA_LAUNCH_FAILED;
     hipLaunchKernelGGL(lstm_fwd_kernel, dim3(H / LS_HB), dim3(LS_THREADS), lds, st, Gx, (const __bf16*)Whh_bf16, Hout, gates, Cs,
-                       (__bf16*)((char*)scratch + 256), (unsigned*)scratch, U, B, H);
+                       (__bf16*)((char*)scratch + 256), (unsigned*)scratch, U, B, H, lstm_spin_limit());
     IA_RETURN_IF_LAUNCH_FAILED();
     return IA_OK;
 }
@@ -267,13 +287,13 @@ extern "C" int ia_lstm_backward(const float* dHout, const float* gates, const fl
     if (scratch_bytes < ia_lstm_scratch_bytes(B, H) || !ia_is_aligned(scratch, 256) || !ia_is_aligned(WhhT_bf16, 16))
         return IA_INVALID_VALUE;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(scratch, 0, 256, st) != hipSuccess) return IA_LAUNCH_FAILED;
+    if (hipMemsetAsync(scratch, 0, 128, st) != hipSuccess) return IA_LAUNCH_FAILED;
     const size_t lds = (size_t)LS_HB * (4 * H * 2 + 16) + 4 * LS_MAXB * 16 * sizeof(float);
     if (lds > 160 * 1024) return IA_UNSUPPORTED;
     if (hipFuncSetAttribute((const void*)lstm_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return IA_LAUNCH_FAILED;
     hipLaunchKernelGGL(lstm_bwd_kernel, dim3(H / LS_HB), dim3(LS_THREADS), lds, st, dHout, gates, Cs, (const __bf16*)WhhT_bf16, dG,
-                       (__bf16*)((char*)scratch + 256), (unsigned*)scratch, U, B, H);
+                       (__bf16*)((char*)scratch + 256), (unsigned*)scratch, U, B, H, lstm_spin_limit());
     IA_RETURN_IF_LAUNCH_FAILED();
     return IA_OK;
 }

@@ -40,9 +40,12 @@ class LSTMDropout(nn.Module):
         self.dropout = nn.Dropout(dropout) if dropout else None
         self.use_hip = False  # set by RNNTDecoder in the bf16 configuration (persistent HIP LSTM, ops/lstm.py)
 
-    def forward(self, x, h=None):
+    def forward(self, x, h=None, need_state=True):
+        """`need_state=False` (the training step: RNNTDecoder.forward discards the final state) selects the persistent HIP
+        LSTM, which only produces the output sequence; stateful callers (greedy decoding: predict() with a carried
+        (h, c)) get the library LSTM and its (h_n, c_n)."""
         from .ops import lstm as hip_lstm
-        if self.use_hip and h is None and hip_lstm.lstm_supported(x, self.lstm.hidden_size):
+        if self.use_hip and h is None and not need_state and hip_lstm.lstm_supported(x, self.lstm.hidden_size):
             x, h = hip_lstm.lstm_forward(x, self.lstm), None
         else:
             x, h = self.lstm(x, h)
@@ -64,7 +67,7 @@ class RNNTDecoder(nn.Module):
         })
         self.prediction["dec_rnn"].use_hip = (cfg.compute_dtype == "bf16")
 
-    def predict(self, y=None, state=None, add_sos=True, batch_size=None):
+    def predict(self, y=None, state=None, add_sos=True, batch_size=None, need_state=True):
         p = next(self.parameters())
         if y is not None:
             y = self.prediction["embed"](y.to(p.device))
@@ -74,13 +77,13 @@ class RNNTDecoder(nn.Module):
         if add_sos:
             B, U, H = y.shape
             y = torch.cat([torch.zeros((B, 1, H), device=y.device, dtype=y.dtype), y], dim=1).contiguous()
-        g, hid = self.prediction["dec_rnn"](y.transpose(0, 1), state)
+        g, hid = self.prediction["dec_rnn"](y.transpose(0, 1), state, need_state=need_state)
         return g.transpose(0, 1), hid
 
     def forward(self, targets, target_length, states=None):
         _flush_pending()
         y = label_collate(targets)
-        g, states = self.predict(y, state=states, add_sos=True)  # (B, U+1, H)
+        g, states = self.predict(y, state=states, add_sos=True, need_state=False)  # (B, U+1, H)
         return g.transpose(1, 2), target_length, states          # (B, H, U+1)
 
 

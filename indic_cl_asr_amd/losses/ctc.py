@@ -28,6 +28,9 @@ class _CTCHip(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gnll):
+        if ctx.saved is None:
+            raise RuntimeError("CTC loss (HIP): trying to backward through the graph a second time -- its lattice workspace "
+                               "was released by the first backward (retain_graph=True is not supported; run the forward again)")
         lp, tg, il, tl, ws, n, blank, dt = ctx.saved
         ctx.saved = None
         B, T, V = lp.shape

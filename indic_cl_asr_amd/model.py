@@ -62,7 +62,8 @@ class StepMonitor(dict):
             ev.record()
             self._pending = (tuple(keys), host, ev)
             for k in keys:
-                super().__setitem__(k, None)
+                if not k.startswith('_'):
+                    super().__setitem__(k, None)
         elif device_values is not None:
             for k, v in zip(keys, device_values.tolist()):
                 super().__setitem__(k, v)
@@ -73,6 +74,12 @@ class StepMonitor(dict):
             self._pending = None
             ev.synchronize()
             for k, v in zip(keys, host.tolist()):
+                if k == '_lstm_timeout':
+                    if v != 0:
+                        from .ops import lstm as hip_lstm
+                        hip_lstm.raise_if_timed_out()
+                        raise RuntimeError("persistent LSTM: a workgroup hand-off timed out during this step")
+                    continue
                 if super().__getitem__(k) is None:
                     super().__setitem__(k, v)
 
@@ -286,9 +293,17 @@ class EncDecHybridRNNTCTCModel(nn.Module):
                                      target_lengths=transcript_len)
         rnnt_only = loss_value
         loss_value = (1 - self.ctc_loss_weight) * loss_value + self.ctc_loss_weight * ctc_loss
-        vals = torch.stack([rnnt_only.detach().float(), ctc_loss.detach().float(), loss_value.detach().float()])
+        vals = [rnnt_only.detach().float(), ctc_loss.detach().float(), loss_value.detach().float()]
+        keys = ['train_rnnt_loss', 'train_ctc_loss', 'train_loss']
+        if signal.is_cuda:
+            # a lost hand-off of the persistent LSTM (bounded spin) travels to the host with the loss values: the monitor
+            # raises when it is read instead of training on a silently wrong prediction network (csrc/lstm.hip)
+            from .ops import lstm as hip_lstm
+            flag = hip_lstm.timeout_flags(signal.device)
+            if flag is not None:
+                vals.append(flag); keys.append('_lstm_timeout')
         monitor = StepMonitor({'training_batch_wer': torch.tensor(float('nan')), 'training_batch_wer_ctc': float('nan')},
-                              ('train_rnnt_loss', 'train_ctc_loss', 'train_loss'), vals)
+                              tuple(keys), torch.stack(vals))
         if compute_wer:
             wer, wer_ctc = self.batch_wer(encoded, encoded_len, log_probs, transcript, transcript_len, language_ids)
             monitor['training_batch_wer'], monitor['training_batch_wer_ctc'] = wer, wer_ctc

@@ -1,9 +1,16 @@
 """Python faces of the Conformer-block HIP kernels (csrc/gemm_bf16.hip, csrc/encoder_ops.hip) and the bf16 weight
 shadow cache used by the no-autograd (frozen-prefix / teacher / eval) encoder path."""
+import weakref
+
 import torch
 
 from .. import _lib
 
+# Caches below are keyed by id(parameter); every entry also holds weak references to its source parameters and is
+# (a) only served while `ref() is param` for each of them -- a new Parameter that reuses a dead one's id() / storage /
+# version can never be handed the dead model's bf16 weights -- and (b) dropped when a source parameter is collected, so
+# teacher copies and per-task reloads do not pin HBM.  Frozen weights edited through `.data` do not move `_version`:
+# call invalidate_weight_caches() after such an edit (checkpoint.load_weights does).
 _SHADOW = {}
 # Bumped whenever trainable weights change behind autograd's back (the fused AdamW kernel writes the flat buffer by
 # raw pointer, so tensor._version does not move; cl.FlatParams.weights() re-points .data).
@@ -15,17 +22,35 @@ def bump_weight_epoch():
     WEIGHT_EPOCH += 1
 
 
+def invalidate_weight_caches():
+    """Forget every cached bf16 / concatenated / re-laid-out weight image (after in-place edits through `.data`)."""
+    _SHADOW.clear(); _FLAT16.clear(); _BLOCK_PARAMS.clear()
+    bump_weight_epoch()
+
+
+def _refs(cache, key, params):
+    """Weak references to `params` whose death evicts cache[key]."""
+    def drop(_ref, cache=cache, key=key):
+        cache.pop(key, None)
+    return tuple(weakref.ref(p, drop) for p in params)
+
+
+def _same(refs, params):
+    return len(refs) == len(params) and all(r() is p for r, p in zip(refs, params))
+
+
 
 _FLAT16 = {}  # id(param) -> (weight epoch, param version, data_ptr, bf16 view written by the fused optimizer kernel)
 
 
 def register_flat_shadow(p, view16):
-    _FLAT16[id(p)] = (WEIGHT_EPOCH, p._version, p.data_ptr(), view16)
+    _FLAT16[id(p)] = (WEIGHT_EPOCH, p._version, p.data_ptr(), view16, _refs(_FLAT16, id(p), (p,)))
 
 
 def _flat_shadow(p):
     hit = _FLAT16.get(id(p))
-    if hit is not None and hit[0] == WEIGHT_EPOCH and hit[1] == p._version and hit[2] == p.data_ptr():
+    if (hit is not None and hit[0] == WEIGHT_EPOCH and hit[1] == p._version and hit[2] == p.data_ptr()
+            and _same(hit[4], (p,))):
         return hit[3]
     return None
 
@@ -37,7 +62,7 @@ def bf16_shadow(*params):
     ver = tuple(p._version for p in params) + tuple(p.data_ptr() for p in params) + \
         ((WEIGHT_EPOCH,) if any(p.requires_grad for p in params) else ())
     hit = _SHADOW.get(key)
-    if hit is not None and hit[0] == ver:
+    if hit is not None and hit[0] == ver and _same(hit[2], params):
         return hit[1]
     with torch.no_grad():
         flat16 = [_flat_shadow(p) for p in params]
@@ -47,7 +72,7 @@ def bf16_shadow(*params):
             w = torch.cat([p.detach().reshape(p.shape[0], -1) for p in params], 0) if len(params) > 1 \
                 else params[0].detach().reshape(params[0].shape[0], -1)
             w = w.to(torch.bfloat16).contiguous()
-    _SHADOW[key] = (ver, w)
+    _SHADOW[key] = (ver, w, _refs(_SHADOW, key, params))
     return w
 
 
@@ -56,11 +81,11 @@ def f32_cat(*params):
     ver = tuple(p._version for p in params) + tuple(p.data_ptr() for p in params) + \
         ((WEIGHT_EPOCH,) if any(p.requires_grad for p in params) else ())
     hit = _SHADOW.get(key)
-    if hit is not None and hit[0] == ver:
+    if hit is not None and hit[0] == ver and _same(hit[2], params):
         return hit[1]
     with torch.no_grad():
         w = torch.cat([p.detach().float().reshape(-1) for p in params], 0).contiguous()
-    _SHADOW[key] = (ver, w)
+    _SHADOW[key] = (ver, w, _refs(_SHADOW, key, params))
     return w
 
 
@@ -264,11 +289,11 @@ def _cached(key, params, make):
     ver = tuple(p._version for p in params) + tuple(p.data_ptr() for p in params) + \
         ((WEIGHT_EPOCH,) if any(p.requires_grad for p in params) else ())
     hit = _SHADOW.get(key)
-    if hit is not None and hit[0] == ver:
+    if hit is not None and hit[0] == ver and _same(hit[2], params):
         return hit[1]
     with torch.no_grad():
         val = make()
-    _SHADOW[key] = (ver, val)
+    _SHADOW[key] = (ver, val, _refs(_SHADOW, key, params))
     return val
 
 
@@ -321,7 +346,7 @@ def _block_params(layer):
         ((WEIGHT_EPOCH,) if any(p.requires_grad for p in watch) else ()) + \
         (layer.dropout.p, ff1.dropout.p, ff2.dropout.p, att.dropout_rate)
     hit = _BLOCK_PARAMS.get(id(layer))
-    if hit is not None and hit[0] == ver:
+    if hit is not None and hit[0] == ver and _same(hit[3], watch):
         return hit[1]
     d = ff1.linear1.weight.shape[1]
     keep = dict(
@@ -346,7 +371,7 @@ def _block_params(layer):
     bp.p_drop, bp.p_ff, bp.p_att = float(layer.dropout.p), float(ff1.dropout.p), float(att.dropout_rate)
     bp.fc_factor = float(layer.fc_factor)
     bp.d, bp.d_ff, bp.n_heads, bp.ksz = d, ff1.linear1.weight.shape[0], att.h, cv.depthwise_conv.weight.shape[-1]
-    _BLOCK_PARAMS[id(layer)] = (ver, bp, keep)
+    _BLOCK_PARAMS[id(layer)] = (ver, bp, keep, _refs(_BLOCK_PARAMS, id(layer), watch))
     return bp
 
 

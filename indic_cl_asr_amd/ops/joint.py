@@ -73,6 +73,10 @@ class _FusedJointRNNT(torch.autograd.Function):
     def backward(ctx, gcosts):
         from ..losses import rnnt as rl
         L = _lib.lib()
+        if ctx.saved is None:   # the gradient overwrites the saved logits in place: one backward per forward
+            raise RuntimeError("fused joint+loss: trying to backward through the graph a second time -- the saved lattice "
+                               "was overwritten in place by the first backward (the fused path does not support "
+                               "retain_graph=True; run the forward again)")
         f16, g16, Wp, logits, ws, labels, act_lens, label_lens = ctx.saved
         B, T, U1, H, V, LD, blank, p, seed, fastemit, kappa, fdt, gdt, wdt, bdt, nbytes = ctx.meta
         ctx.saved = None

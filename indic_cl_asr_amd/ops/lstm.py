@@ -11,13 +11,51 @@ from . import fast
 MAXB = 32
 
 
+_LDS_LIMIT = 160 * 1024
+
+
 def lstm_supported(x, H):
-    return x.is_cuda and H % 64 == 0 and H <= 4096
+    """Shapes the persistent kernels take (mirrors the launchers' checks, so that anything else falls back to nn.LSTM
+    instead of raising IA_UNSUPPORTED): the W_hh slices of forward and backward must fit the 160 KiB LDS."""
+    if not (x.is_cuda and H % 64 == 0 and H <= 4096):
+        return False
+    L = _lib.lib()
+    return max(L.ia_lstm_lds_bytes(H, 0), L.ia_lstm_lds_bytes(H, 1)) <= _LDS_LIMIT
 
 
-def _scratch(B, H, dev):
+_SCRATCH = {}        # (device index, stream, direction) -> persistent scratch (hand-off buffers + sync words)
+_STICKY_WORD = 32    # csrc/lstm.hip LS_STICKY_WORD: set by a kernel whose bounded spin gave up, never cleared by a launch
+
+
+def _scratch(B, H, dev, which=0):
+    """One scratch buffer per (device, stream, direction), kept alive so that its sticky timeout word can be polled
+    after the step (timeout_flags); launches on one stream are ordered, so they may share it."""
     n = _lib.lib().ia_lstm_scratch_bytes(B, H)
-    return torch.empty(n, dtype=torch.uint8, device=dev), n
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, which)
+    buf = _SCRATCH.get(key)
+    if buf is None or buf.numel() < n:
+        buf = _SCRATCH[key] = torch.zeros(n, dtype=torch.uint8, device=dev)
+    return buf, n
+
+
+def timeout_flags(dev):
+    """0-dim float tensor on `dev`: number of scratch buffers whose sticky timeout word is set (None when the persistent
+    LSTM never ran there).  model.training_step ships it to the host with the loss values; StepMonitor raises on it."""
+    words = [b.view(torch.int32)[_STICKY_WORD] for k, b in _SCRATCH.items() if k[0] == dev.index]
+    if not words:
+        return None
+    return torch.stack(words).ne(0).sum().float()
+
+
+def raise_if_timed_out(dev=None):
+    """Synchronous check (tests, end of an epoch): RuntimeError if a hand-off spin of the persistent LSTM ever gave up."""
+    for k, b in _SCRATCH.items():
+        if dev is not None and k[0] != torch.device(dev).index:
+            continue
+        if int(b.view(torch.int32)[_STICKY_WORD].item()) != 0:
+            b.view(torch.int32)[_STICKY_WORD] = 0
+            raise RuntimeError("persistent LSTM (csrc/lstm.hip): a workgroup hand-off timed out -- the prediction network's "
+                               "outputs / gradients of that launch are invalid (results of this step must be discarded)")
 
 
 class _LSTMHip(torch.autograd.Function):
@@ -45,7 +83,7 @@ class _LSTMHip(torch.autograd.Function):
             ho = Hout if whole else torch.empty(U, b1 - b0, H, dtype=torch.float32, device=dev)
             ga = gates if (whole or not need) else torch.empty(U, b1 - b0, 4 * H, dtype=torch.float32, device=dev)
             cs = Cs if (whole or not need) else torch.empty(U, b1 - b0, H, dtype=torch.float32, device=dev)
-            sc, n = _scratch(b1 - b0, H, dev)
+            sc, n = _scratch(b1 - b0, H, dev, 0)
             st = L.ia_lstm_forward(_lib.ptr(gx), _lib.ptr(whh), _lib.ptr(ho), _lib.ptr(ga), _lib.ptr(cs), U, b1 - b0, H,
                                    _lib.ptr(sc), n, _lib.stream_ptr())
             _lib.check(st, "ia_lstm_forward")
@@ -74,7 +112,7 @@ class _LSTMHip(torch.autograd.Function):
             whole = (b0 == 0 and b1 == B)
             args = [t if whole else t[:, sl].contiguous() for t in (dH, gates, Cs)]
             out = dG if whole else torch.empty(U, b1 - b0, 4 * H, dtype=torch.float32, device=dev)
-            sc, n = _scratch(b1 - b0, H, dev)
+            sc, n = _scratch(b1 - b0, H, dev, 1)
             st = L.ia_lstm_backward(_lib.ptr(args[0]), _lib.ptr(args[1]), _lib.ptr(args[2]), _lib.ptr(whhT), _lib.ptr(out), U,
                                     b1 - b0, H, _lib.ptr(sc), n, _lib.stream_ptr())
             _lib.check(st, "ia_lstm_backward")
