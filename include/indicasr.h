@@ -327,6 +327,22 @@ int ia_gemm_tn_bf16(const void* dY, int ldy, const void* X, int ldx, int M, int 
                     float* scratch, ia_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Row-resident feed-forward module of a Conformer block (csrc/ffn_fused.hip): ONE launch for
+ *     x <- [LN2]( x + alpha * dropout_res( dropout_ff(SiLU(LN(x) W1^T + b1)) W2^T + b2 ) )
+ * replacing norm_feed_forward{1,2} + ConformerFeedForward.forward + the residual update (+ norm_out after the second
+ * module) of ConformerLayer.forward, A/parts/submodules/conformer_modules.py:141-214,385-404.  The [N, d_ff] intermediate
+ * stays in LDS (64-frame tiles); the LayerNorm'd frames stay in registers as MFMA operands.
+ * x [N, d] f32 in/out (in place); W1 [d_ff, d] bf16, W2 [d, d_ff] bf16 (nn.Linear layout), biases / LayerNorm f32.
+ * Dropout masks are the ones of ia_gemm_bf16 for the same (seed, row, column): keyed (seed_ff, [N, d_ff]) after the
+ * activation and (seed_res, [N, d]) on the module output; p = 0 disables.  ln2_g/ln2_b NULL: no second LayerNorm.
+ * y_out (optional, [N, d] bf16): a bf16 copy of the result.  Limits: ia_ffn_fused_supported(d, d_ff) (d = 256,
+ * d_ff % 128 == 0); IA_UNSUPPORTED otherwise. */
+int ia_ffn_fused_supported(int d, int d_ff);
+int ia_ffn_fused(float* x, int N, int d, int d_ff, const float* ln_g, const float* ln_b, float eps, const void* W1,
+                 const float* b1, const void* W2, const float* b2, float alpha, float p_ff, unsigned seed_ff, float p_res,
+                 unsigned seed_res, const float* ln2_g, const float* ln2_b, void* y_out, ia_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Native executor of the no-autograd Conformer prefix (frozen blocks / teacher / eval): one call enqueues the 14
  * kernels of each of `n_layers` blocks (ConformerLayer.forward, conformer_modules.py:141-214) on `stream`.
  * x [B*T, d] f32 residual stream, updated in place to the last block's norm_out; pos_emb [pos_rows >= 2T-1, d] bf16;

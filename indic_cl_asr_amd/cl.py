@@ -265,10 +265,12 @@ def importance_finish(importance: FlatDict, n_batches: int, group=None) -> FlatD
 def lwf_kd_loss(loss, prob, prob_, pred_store_list, store_list, knowledge_distillation: float, kd_ctx: float):
     """R/cl_baseline_lwf.py:242-264.  Returns (total loss, rnnt_kd, ctc_kd) -- device tensors."""
     F = torch.nn.functional
-    ctc_kd_loss = F.kl_div(prob, prob_.exp(), reduction='batchmean')
+    # fp32 arithmetic whatever the stash dtype (the bf16 path stashes bf16 lattices; kl_div evaluated in bf16 rounds
+    # log(exp(i)) - j, a difference of nearly equal numbers, to 8 bits: observed 4.5 % off the fp32 value)
+    ctc_kd_loss = F.kl_div(prob.float(), prob_.float().exp(), reduction='batchmean')
     rnnt_kd = 0
     for i, j in zip(store_list, pred_store_list):
-        rnnt_kd = rnnt_kd + F.kl_div(j, i.exp(), reduction='batchmean')
+        rnnt_kd = rnnt_kd + F.kl_div(j.float(), i.float().exp(), reduction='batchmean')
     rnnt_kd = rnnt_kd / len(store_list)
     total = loss * (1 - knowledge_distillation) + knowledge_distillation * ((1 - kd_ctx) * rnnt_kd + kd_ctx * ctc_kd_loss)
     return total, rnnt_kd, ctc_kd_loss

@@ -62,16 +62,25 @@ extern "C" int ia_conformer_prefix_fwd(const ia_block_params* layers, int n_laye
          *vt = ws + w.vt;
     float *z = (float*)(ws + w.z), *sums = (float*)(ws + w.sums), *scr = (float*)(ws + w.scr);
     const int N = B * T;
+    // feed-forward modules: one row-resident launch each (csrc/ffn_fused.hip: LayerNorm, both projections, SiLU, dropouts,
+    // residual and -- for the second module -- norm_out) where the shape allows, else LayerNorm + two GEMM launches
+    const bool ffn_fused = ia_ffn_fused_supported(d, d_ff) != 0;
     // LayerNorm in front of the first block's first feed-forward; later ones are chained behind the previous norm_out
-    IA_TRY(ia_layernorm(x, d, N, d, l0.ln_ff1_g, l0.ln_ff1_b, l0.ln_eps, nullptr, 0, nullptr, nullptr, y, d, stream));
+    if (!ffn_fused)
+        IA_TRY(ia_layernorm(x, d, N, d, l0.ln_ff1_g, l0.ln_ff1_b, l0.ln_eps, nullptr, 0, nullptr, nullptr, y, d, stream));
     for (int li = 0; li < n_layers; ++li) {
         const ia_block_params& L = layers[li];
         if (L.d != d || L.d_ff != d_ff || L.n_heads != H || L.ksz != ksz) return IA_INVALID_VALUE;
         const unsigned seed = seed_base + seed_stride * (unsigned)li;
         const float p = training ? L.p_drop : 0.f, pff = training ? L.p_ff : 0.f, patt = training ? L.p_att : 0.f;
         // 1/2 feed-forward
-        IA_TRY(ia_gemm_bf16(y, d, L.w_ff1a, d, N, d_ff, d, L.b_ff1a, 1, pff, seed + 1, 1.f, nullptr, 0, nullptr, 0, h, d_ff, stream));
-        IA_TRY(ia_gemm_bf16(h, d_ff, L.w_ff1b, d_ff, N, d, d_ff, L.b_ff1b, 0, p, seed + 2, L.fc_factor, x, d, x, d, nullptr, 0, stream));
+        if (ffn_fused) {
+            IA_TRY(ia_ffn_fused(x, N, d, d_ff, L.ln_ff1_g, L.ln_ff1_b, L.ln_eps, L.w_ff1a, L.b_ff1a, L.w_ff1b, L.b_ff1b, L.fc_factor,
+                                pff, seed + 1, p, seed + 2, nullptr, nullptr, nullptr, stream));
+        } else {
+            IA_TRY(ia_gemm_bf16(y, d, L.w_ff1a, d, N, d_ff, d, L.b_ff1a, 1, pff, seed + 1, 1.f, nullptr, 0, nullptr, 0, h, d_ff, stream));
+            IA_TRY(ia_gemm_bf16(h, d_ff, L.w_ff1b, d_ff, N, d, d_ff, L.b_ff1b, 0, p, seed + 2, L.fc_factor, x, d, x, d, nullptr, 0, stream));
+        }
         // self-attention
         IA_TRY(ia_layernorm(x, d, N, d, L.ln_att_g, L.ln_att_b, L.ln_eps, nullptr, 0, nullptr, nullptr, y, d, stream));
         IA_TRY(ia_gemm_bf16(y, d, L.w_qkv, d, N, 3 * d, d, L.b_qkv, 0, 0.f, 0, 1.f, nullptr, 0, nullptr, 0, qkv, 3 * d, stream));
@@ -86,6 +95,11 @@ extern "C" int ia_conformer_prefix_fwd(const ia_block_params* layers, int n_laye
                           training ? 1 : 0, c3, stream));
         IA_TRY(ia_gemm_bf16(c3, d, L.w_pw2, d, N, d, d, L.b_pw2, 0, p, seed + 4, 1.f, x, d, x, d, nullptr, 0, stream));
         // 1/2 feed-forward
+        if (ffn_fused) {   // ... + norm_out in the same launch (the next block's module applies its own first LayerNorm)
+            IA_TRY(ia_ffn_fused(x, N, d, d_ff, L.ln_ff2_g, L.ln_ff2_b, L.ln_eps, L.w_ff2a, L.b_ff2a, L.w_ff2b, L.b_ff2b, L.fc_factor,
+                                pff, seed + 5, p, seed + 6, L.ln_out_g, L.ln_out_b, nullptr, stream));
+            continue;
+        }
         IA_TRY(ia_layernorm(x, d, N, d, L.ln_ff2_g, L.ln_ff2_b, L.ln_eps, nullptr, 0, nullptr, nullptr, y, d, stream));
         IA_TRY(ia_gemm_bf16(y, d, L.w_ff2a, d, N, d_ff, d, L.b_ff2a, 1, pff, seed + 5, 1.f, nullptr, 0, nullptr, 0, h, d_ff, stream));
         IA_TRY(ia_gemm_bf16(h, d_ff, L.w_ff2b, d_ff, N, d, d_ff, L.b_ff2b, 0, p, seed + 6, L.fc_factor, x, d, x, d, nullptr, 0, stream));

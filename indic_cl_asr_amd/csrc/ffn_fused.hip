@@ -1,0 +1,300 @@
+// Row-resident feed-forward module of a Conformer block for gfx950: ONE launch for
+//
+//     x <- [LN2] ( x + alpha * dropout( SiLU'( LN(x) W1^T + b1 ) W2^T + b2 ) )          SiLU' = dropout(SiLU(.))
+//
+// (ConformerFeedForward + the residual update of ConformerLayer.forward, A/parts/submodules/conformer_modules.py:141-214,
+// 385-404; LN = norm_feed_forward{1,2}, LN2 = norm_out for the second module of a block).  The [rows, 4d] intermediate
+// never leaves the CU: the unfused path ran LayerNorm + two 188-workgroup GEMMs and moved it through HBM twice
+// (41 us per module at 12 032 frames, d = 256; its algorithmic MFMA time is 5 us).
+//
+// Workgroup = 64 frames x all of d (= 256) x all of 4d, 8 waves = (32-frame half mi) x (quarter q).  Per chunk of 128
+// hidden units:
+//   phase A  wave (mi, q): X^T[32 units of quarter q][32 frames] = W1 rows . LN(x)^T      16 x v_mfma_f32_32x32x16_bf16
+//            (the LN'd frames live in registers as B fragments for the whole kernel, W1 rows come from LDS), then bias,
+//            SiLU, dropout, bf16 -> X[frame][unit] in LDS: the accumulator's 4 consecutive units per lane pack into one
+//            8-byte write, so the "transposed" product costs no transpose;
+//   phase B  wave (mi, q): out^T[64 channels of quarter q][32 frames] += W2 rows . X      16 MFMAs
+//            (accumulators persist across chunks: no cross-wave reduction at the end).
+// W1 / W2 chunks (64 KB each) stream L2 -> LDS with global_load_lds_dwordx4 while the other phase computes; the images
+// are unpadded rows with the 16-byte slot XOR-swizzled by (row & 15) on the SOURCE side (LDS-DMA writes lane-linearly),
+// which makes every ds_read_b128 fragment read conflict-free.  Epilogue: out^T -> LDS -> row-major pass (bias, dropout,
+// alpha, fp32 residual add, optional second LayerNorm) with 32-byte coalesced accesses.
+//
+// Roofline (d = 256, 4d = 1024): 2*2*256*1024 = 1.05 MFLOP per frame -> 12.6 GFLOP per launch at 12 032 frames (5.0 us at
+// 2.5 PF dense); each workgroup also pulls the full 1 MB of weights through its CU's L2 port, the actual bound.
+#include <hip/hip_bf16.h>
+
+#include "ia_common.h"
+#include "dropout_mask.h"
+
+namespace {
+
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+constexpr int FF_M = 64;         // frames per workgroup
+constexpr int FF_THREADS = 512;  // 8 waves
+constexpr int FF_JC = 128;       // hidden units per chunk
+
+struct FfnArgs {
+    float* x; int N;
+    const float* ln_g; const float* ln_b; float eps;
+    const __bf16* W1; const float* b1;   // [dff, D], [dff]
+    const __bf16* W2; const float* b2;   // [D, dff], [D]
+    int dff;
+    float alpha;
+    unsigned thr_ff, seed_ff; float ks_ff;     // dropout after SiLU (keep if hash byte >= thr)
+    unsigned thr_res, seed_res; float ks_res;  // dropout on the module output
+    const float* ln2_g; const float* ln2_b;    // optional LayerNorm of the updated residual (norm_out)
+    __bf16* y_out;                             // optional bf16 copy of the result (operand of the next projection)
+};
+
+__device__ __forceinline__ float half_wave_sum(float v) {   // sum over the 32 lanes of a half wave (rows are half waves)
+    v += IA_DPP_F(0.f, v, 0xB1, 0xF);    // quad_perm xor 1
+    v += IA_DPP_F(0.f, v, 0x4E, 0xF);    // quad_perm xor 2
+    v += IA_DPP_F(0.f, v, 0x141, 0xF);   // row_half_mirror
+    v += IA_DPP_F(0.f, v, 0x140, 0xF);   // row_mirror        -> every lane of a 16-lane row holds the row's sum
+    v += __shfl_xor(v, 16, 64);          // the other row of the half wave
+    return v;
+}
+
+template <int D>
+__global__ __launch_bounds__(FF_THREADS, 2) void ffn_fused_kernel(FfnArgs a) {
+    static_assert(D == 256, "wave decomposition below is written for d_model = 256");
+    constexpr int KS = D / 16;            // k-steps of phase A
+    constexpr int W1ROW = D * 2;          // bytes per W1 row in LDS (512)
+    constexpr int W2ROW = FF_JC * 2;      // bytes per W2 row / X row in LDS (256)
+    constexpr int W1BUF = FF_JC * W1ROW;  // 65536
+    constexpr int W2BUF = D * W2ROW;      // 65536
+    constexpr int EROW = D * 4 + 16;      // fp32 epilogue row (padded)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sW1 = smem;
+    unsigned char* sW2 = smem + W1BUF;
+    unsigned char* sX = smem + W1BUF + W2BUF;   // [64][128] bf16
+    unsigned char* sY = sW2;                     // prologue alias: LN(x) [64][256] bf16
+    unsigned char* sE = smem;                    // epilogue alias: out [64][EROW]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5, sw = l31 & 15;
+    const int mi = wave & 1, q = wave >> 1;
+    const int m0 = blockIdx.x * FF_M;
+    const int nchunks = a.dff / FF_JC;
+
+    // ---- weight chunk staging (LDS-DMA).  W1 chunk: 128 rows x 512 B, one instruction = 2 rows; W2 chunk: 256 rows x
+    // 256 B (columns 128c.. of the [D, dff] matrix), one instruction = 4 rows.  Wave w issues instructions 8w .. 8w+7.
+#define FF_LOAD_W1(c_)                                                                                                   \
+    do {                                                                                                                 \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                                               \
+            const int blk_ = wave * 8 + i_;                                                                              \
+            const int row_ = 2 * blk_ + hh;                                                                              \
+            const int cp_ = lane & 31;                                                                                   \
+            const int cs_ = (cp_ & 16) | ((cp_ & 15) ^ (row_ & 15));                                                     \
+            const unsigned char* src_ = reinterpret_cast<const unsigned char*>(a.W1 + (size_t)((c_) * FF_JC + row_) * D) + cs_ * 16; \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,                        \
+                                             (__attribute__((address_space(3))) void*)(sW1 + blk_ * 1024), 16, 0, 0);    \
+        }                                                                                                                \
+    } while (0)
+#define FF_LOAD_W2(c_)                                                                                                   \
+    do {                                                                                                                 \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                                               \
+            const int blk_ = wave * 8 + i_;                                                                              \
+            const int row_ = 4 * blk_ + (lane >> 4);                                                                     \
+            const int cs_ = (lane & 15) ^ (row_ & 15);                                                                   \
+            const unsigned char* src_ = reinterpret_cast<const unsigned char*>(a.W2 + (size_t)row_ * a.dff + (c_) * FF_JC) + cs_ * 16; \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,                        \
+                                             (__attribute__((address_space(3))) void*)(sW2 + blk_ * 1024), 16, 0, 0);    \
+        }                                                                                                                \
+    } while (0)
+
+    FF_LOAD_W1(0);
+
+    // ---- prologue: LayerNorm of the 64 frames, half a wave per frame (32 lanes x 8 channels), bf16 -> sY (swizzled)
+#pragma unroll
+    for (int pass = 0; pass < FF_M / 16; ++pass) {
+        const int r = pass * 16 + (tid >> 5), vec = tid & 31;
+        const int gm = (m0 + r < a.N) ? (m0 + r) : (a.N - 1);
+        const float4 x0 = *reinterpret_cast<const float4*>(a.x + (size_t)gm * D + vec * 8);
+        const float4 x1 = *reinterpret_cast<const float4*>(a.x + (size_t)gm * D + vec * 8 + 4);
+        float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[j];
+        const float mean = half_wave_sum(s) * (1.f / D);
+        float qq = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { v[j] -= mean; qq += v[j] * v[j]; }
+        const float rstd = rsqrtf(half_wave_sum(qq) * (1.f / D) + a.eps);
+        const float4 g0 = *reinterpret_cast<const float4*>(a.ln_g + vec * 8), g1 = *reinterpret_cast<const float4*>(a.ln_g + vec * 8 + 4);
+        const float4 c0 = *reinterpret_cast<const float4*>(a.ln_b + vec * 8), c1 = *reinterpret_cast<const float4*>(a.ln_b + vec * 8 + 4);
+        const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        const float bb[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        union { uint4 u; __bf16 h[8]; } o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.h[j] = (__bf16)(v[j] * rstd * gg[j] + bb[j]);
+        const int phys = (vec & 16) | ((vec & 15) ^ (r & 15));
+        *reinterpret_cast<uint4*>(sY + r * W1ROW + phys * 16) = o.u;
+    }
+    __syncthreads();
+    // this wave's 32 frames as B fragments of phase A: lane (frame l31, half hh) holds channels 16 s + 8 hh .. + 7
+    bf8 yf[KS];
+    {
+        const unsigned char* yrow = sY + (mi * 32 + l31) * W1ROW;
+        const int t16 = (hh ^ sw) * 16;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) yf[s] = *reinterpret_cast<const bf8*>(yrow + ((s & 8) * 32) + (((s & 7) * 32) ^ t16));
+    }
+    __syncthreads();   // sY (= sW2) is free; the W1(0) DMA has landed (the barrier drains the LDS-DMA queue)
+    FF_LOAD_W2(0);
+
+    f16v o[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[nt][r] = 0.f;
+
+    const int t16 = (hh ^ sw) * 16;
+    const unsigned char* w1row = sW1 + (q * 32 + l31) * W1ROW;
+    const unsigned char* xrow = sX + (mi * 32 + l31) * W2ROW;
+    const unsigned char* w2row = sW2 + (q * 64 + l31) * W2ROW;
+    const unsigned gm_drop = (unsigned)(m0 + mi * 32 + l31);
+
+    for (int c = 0; c < nchunks; ++c) {
+        // ---------------------------------------------------------------- phase A
+        f16v acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        float4 bia[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bia[g] = *reinterpret_cast<const float4*>(a.b1 + c * FF_JC + q * 32 + g * 8 + hh * 4);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const bf8 wf = *reinterpret_cast<const bf8*>(w1row + ((s & 8) * 32) + (((s & 7) * 32) ^ t16));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, yf[s], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float v[4] = {acc[4 * g] + bia[g].x, acc[4 * g + 1] + bia[g].y, acc[4 * g + 2] + bia[g].z, acc[4 * g + 3] + bia[g].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = v[i] / (1.f + __expf(-v[i]));
+            if (a.thr_ff > 0) {
+                const unsigned mk = ia_keep8(a.seed_ff, gm_drop, (unsigned)a.dff, (unsigned)(c * FF_JC + q * 32 + g * 8), a.thr_ff) >> (hh * 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = ((mk >> i) & 1u) ? v[i] * a.ks_ff : 0.f;
+            }
+            union { uint2 u; __bf16 h[4]; } pk;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pk.h[i] = (__bf16)v[i];
+            *reinterpret_cast<uint2*>(sX + (mi * 32 + l31) * W2ROW + (((q * 4 + g) ^ sw) * 16) + hh * 8) = pk.u;
+        }
+        __syncthreads();   // X complete, W2(c) landed, W1 buffer free
+        if (c + 1 < nchunks) FF_LOAD_W1(c + 1);
+        // ---------------------------------------------------------------- phase B
+#pragma unroll
+        for (int s = 0; s < FF_JC / 16; ++s) {
+            const int off = ((s * 32) ^ t16);
+            const bf8 xb = *reinterpret_cast<const bf8*>(xrow + off);
+            const bf8 w0 = *reinterpret_cast<const bf8*>(w2row + off);
+            const bf8 w1 = *reinterpret_cast<const bf8*>(w2row + 32 * W2ROW + off);
+            o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xb, o[0], 0, 0, 0);
+            o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, xb, o[1], 0, 0, 0);
+        }
+        __syncthreads();   // W2 buffer and X free, W1(c+1) landed
+        if (c + 1 < nchunks) FF_LOAD_W2(c + 1);
+    }
+
+    // ---- epilogue: out^T accumulators -> sE[frame][channel] fp32 (lane = frame, 4 consecutive channels per register group)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n0 = q * 64 + nt * 32 + g * 8 + hh * 4;
+            *reinterpret_cast<float4*>(sE + (mi * 32 + l31) * EROW + n0 * 4) =
+                make_float4(o[nt][4 * g], o[nt][4 * g + 1], o[nt][4 * g + 2], o[nt][4 * g + 3]);
+        }
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < FF_M / 16; ++pass) {
+        const int r = pass * 16 + (tid >> 5), vec = tid & 31;
+        const int gm = m0 + r;
+        const bool live = gm < a.N;
+        const int gmc = live ? gm : (a.N - 1);
+        const float4 e0 = *reinterpret_cast<const float4*>(sE + r * EROW + vec * 32);
+        const float4 e1 = *reinterpret_cast<const float4*>(sE + r * EROW + vec * 32 + 16);
+        float v[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+        const float4 b0 = *reinterpret_cast<const float4*>(a.b2 + vec * 8), b1 = *reinterpret_cast<const float4*>(a.b2 + vec * 8 + 4);
+        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+        float sc = a.alpha;
+        if (a.thr_res > 0) {
+            const unsigned mk = ia_keep8(a.seed_res, (unsigned)gmc, (unsigned)D, (unsigned)(vec * 8), a.thr_res);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (!((mk >> j) & 1u)) v[j] = 0.f;
+            sc *= a.ks_res;
+        }
+        const float4 r0 = *reinterpret_cast<const float4*>(a.x + (size_t)gmc * D + vec * 8);
+        const float4 r1 = *reinterpret_cast<const float4*>(a.x + (size_t)gmc * D + vec * 8 + 4);
+        const float rr[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = v[j] * sc + rr[j];
+        if (a.ln2_g) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[j];
+            const float mean = half_wave_sum(s) * (1.f / D);
+            float qq = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v[j] -= mean; qq += v[j] * v[j]; }
+            const float rstd = rsqrtf(half_wave_sum(qq) * (1.f / D) + a.eps);
+            const float4 g0 = *reinterpret_cast<const float4*>(a.ln2_g + vec * 8), g1 = *reinterpret_cast<const float4*>(a.ln2_g + vec * 8 + 4);
+            const float4 c0 = *reinterpret_cast<const float4*>(a.ln2_b + vec * 8), c1 = *reinterpret_cast<const float4*>(a.ln2_b + vec * 8 + 4);
+            const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            const float bb[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = v[j] * rstd * gg[j] + bb[j];
+        }
+        if (live) {
+            *reinterpret_cast<float4*>(a.x + (size_t)gm * D + vec * 8) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(a.x + (size_t)gm * D + vec * 8 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            if (a.y_out) {
+                union { uint4 u; __bf16 h[8]; } ob;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ob.h[j] = (__bf16)v[j];
+                *reinterpret_cast<uint4*>(a.y_out + (size_t)gm * D + vec * 8) = ob.u;
+            }
+        }
+    }
+#undef FF_LOAD_W1
+#undef FF_LOAD_W2
+}
+
+}  // namespace
+
+extern "C" int ia_ffn_fused_supported(int d, int d_ff) { return (d == 256 && d_ff > 0 && d_ff % FF_JC == 0) ? 1 : 0; }
+
+extern "C" int ia_ffn_fused(float* x, int N, int d, int d_ff, const float* ln_g, const float* ln_b, float eps, const void* W1,
+                            const float* b1, const void* W2, const float* b2, float alpha, float p_ff, unsigned seed_ff,
+                            float p_res, unsigned seed_res, const float* ln2_g, const float* ln2_b, void* y_out,
+                            ia_stream_t stream) {
+    if (!x || !ln_g || !ln_b || !W1 || !b1 || !W2 || !b2 || N <= 0 || (ln2_g && !ln2_b)) return IA_INVALID_VALUE;
+    if (!ia_ffn_fused_supported(d, d_ff)) return IA_UNSUPPORTED;
+    if (p_ff < 0.f || p_ff >= 1.f || p_res < 0.f || p_res >= 1.f) return IA_INVALID_VALUE;
+    if (!ia_is_aligned(x, 16) || !ia_is_aligned(W1, 16) || !ia_is_aligned(W2, 16) || !ia_is_aligned(b1, 16) ||
+        !ia_is_aligned(b2, 16) || !ia_is_aligned(ln_g, 16) || !ia_is_aligned(ln_b, 16) || (ln2_g && !ia_is_aligned(ln2_g, 16)) ||
+        (ln2_b && !ia_is_aligned(ln2_b, 16)) || (y_out && !ia_is_aligned(y_out, 16)))
+        return IA_INVALID_VALUE;
+    FfnArgs a;
+    a.x = x; a.N = N; a.ln_g = ln_g; a.ln_b = ln_b; a.eps = eps;
+    a.W1 = (const __bf16*)W1; a.b1 = b1; a.W2 = (const __bf16*)W2; a.b2 = b2; a.dff = d_ff; a.alpha = alpha;
+    a.thr_ff = (unsigned)(p_ff * 256.f + 0.5f); a.seed_ff = seed_ff;
+    a.ks_ff = a.thr_ff > 0 ? 256.f / (256.f - (float)a.thr_ff) : 1.f;
+    a.thr_res = (unsigned)(p_res * 256.f + 0.5f); a.seed_res = seed_res;
+    a.ks_res = a.thr_res > 0 ? 256.f / (256.f - (float)a.thr_res) : 1.f;
+    a.ln2_g = ln2_g; a.ln2_b = ln2_b; a.y_out = (__bf16*)y_out;
+    constexpr int LDS = FF_JC * 256 * 2 + 256 * FF_JC * 2 + FF_M * FF_JC * 2;   // 147 456 B
+    static_assert(FF_M * (256 * 4 + 16) <= 2 * FF_JC * 256 * 2, "epilogue tile aliases the weight buffers");
+    if (hipFuncSetAttribute((const void*)ffn_fused_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+        return IA_LAUNCH_FAILED;
+    hipLaunchKernelGGL((ffn_fused_kernel<256>), dim3((N + FF_M - 1) / FF_M), dim3(FF_THREADS), LDS, (hipStream_t)stream, a);
+    IA_RETURN_IF_LAUNCH_FAILED();
+    return IA_OK;
+}

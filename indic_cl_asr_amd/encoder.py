@@ -171,11 +171,18 @@ class ConformerLayer(nn.Module):
         tr = self.training
         p = self.dropout.p if tr else 0.0
         ff1, ff2, att, cv = self.feed_forward1, self.feed_forward2, self.self_attn, self.conv
+        ffn_fused = fast.ffn_fused_supported(d, ff1.linear1.weight.shape[0])
         # 1/2 FFN
-        _, h = fast.gemm(y, fast.bf16_shadow(ff1.linear1.weight), ff1.linear1.bias, act=1,
-                         dropout_p=ff1.dropout.p if tr else 0.0, seed=seed + 1)
-        fast.gemm(h, fast.bf16_shadow(ff1.linear2.weight), ff1.linear2.bias, dropout_p=p, seed=seed + 2, alpha=self.fc_factor,
-                  residual=x, out_f32=x, want_bf16=False)
+        if ffn_fused:   # LayerNorm + both projections + residual in one row-resident launch (csrc/ffn_fused.hip)
+            fast.ffn_fused(x, self.norm_feed_forward1, ff1.linear1, ff1.linear2, self.fc_factor,
+                           ff1.dropout.p if tr else 0.0, seed + 1, p, seed + 2)
+        else:
+            if y is None:
+                y = fast.layernorm(x, self.norm_feed_forward1.weight, self.norm_feed_forward1.bias, self.norm_feed_forward1.eps)
+            _, h = fast.gemm(y, fast.bf16_shadow(ff1.linear1.weight), ff1.linear1.bias, act=1,
+                             dropout_p=ff1.dropout.p if tr else 0.0, seed=seed + 1)
+            fast.gemm(h, fast.bf16_shadow(ff1.linear2.weight), ff1.linear2.bias, dropout_p=p, seed=seed + 2, alpha=self.fc_factor,
+                      residual=x, out_f32=x, want_bf16=False)
         # self-attention
         y = fast.layernorm(x, self.norm_self_att.weight, self.norm_self_att.bias, self.norm_self_att.eps)
         _, qkv = fast.gemm(y, fast.bf16_shadow(att.linear_q.weight, att.linear_k.weight, att.linear_v.weight),
@@ -200,6 +207,10 @@ class ConformerLayer(nn.Module):
         fast.gemm(c3, fast.bf16_shadow(cv.pointwise_conv2.weight), cv.pointwise_conv2.bias, dropout_p=p, seed=seed + 4,
                   residual=x, out_f32=x, want_bf16=False)
         # 1/2 FFN
+        if ffn_fused:   # ... and norm_out in the same launch
+            fast.ffn_fused(x, self.norm_feed_forward2, ff2.linear1, ff2.linear2, self.fc_factor,
+                           ff2.dropout.p if tr else 0.0, seed + 5, p, seed + 6, ln2=self.norm_out)
+            return x, None
         y = fast.layernorm(x, self.norm_feed_forward2.weight, self.norm_feed_forward2.bias, self.norm_feed_forward2.eps)
         _, h = fast.gemm(y, fast.bf16_shadow(ff2.linear1.weight), ff2.linear1.bias, act=1,
                          dropout_p=ff2.dropout.p if tr else 0.0, seed=seed + 5)
@@ -320,7 +331,7 @@ class ConformerEncoder(nn.Module):
             # native executor: one C call enqueues the 14 kernels of every block (csrc/block_exec.hip)
             fast.conformer_prefix(list(self.layers[:n_fast]), xr, pe, length, B, T, base, 16, l0.training)
             return xr.view(B, T, d), n_fast
-        y = fast.layernorm(xr, l0.norm_feed_forward1.weight, l0.norm_feed_forward1.bias, l0.norm_feed_forward1.eps)
+        y = None   # (the first module of a block applies its LayerNorm itself unless the previous block chained it)
         for l in range(n_fast):
             nxt = self.layers[l + 1].norm_feed_forward1 if l + 1 < n_fast else None
             xr, y = self.layers[l].forward_fast(xr, y, length, pe, B, T, base + 16 * l, nxt)

@@ -132,6 +132,27 @@ def layernorm(x_f32, g1, b1, eps=1e-5, out_f32=None, g2=None, b2=None, want_bf16
     return outH
 
 
+USE_FUSED_FFN = True   # tests flip this to compare the row-resident module with the LayerNorm + two-GEMM sequence
+
+
+def ffn_fused_supported(d, d_ff):
+    return USE_FUSED_FFN and bool(_lib.lib().ia_ffn_fused_supported(int(d), int(d_ff)))
+
+
+def ffn_fused(x_f32, ln, lin1, lin2, alpha, p_ff=0.0, seed_ff=0, p_res=0.0, seed_res=0, ln2=None, y_out=None):
+    """x <- [ln2](x + alpha * dropout(lin2(dropout(SiLU(lin1(ln(x))))))) in place on the fp32 residual stream [N, d]:
+    one launch of csrc/ffn_fused.hip (the [N, 4d] intermediate stays in LDS)."""
+    N, d = x_f32.shape
+    w1, w2 = bf16_shadow(lin1.weight), bf16_shadow(lin2.weight)
+    st = _lib.lib().ia_ffn_fused(_lib.ptr(x_f32), N, d, w1.shape[0], _lib.ptr(ln.weight), _lib.ptr(ln.bias), float(ln.eps),
+                                 _lib.ptr(w1), _lib.ptr(lin1.bias), _lib.ptr(w2), _lib.ptr(lin2.bias), float(alpha), float(p_ff),
+                                 int(seed_ff) & 0xFFFFFFFF, float(p_res), int(seed_res) & 0xFFFFFFFF,
+                                 _lib.ptr(ln2.weight) if ln2 is not None else None,
+                                 _lib.ptr(ln2.bias) if ln2 is not None else None, _lib.ptr(y_out), _lib.stream_ptr())
+    _lib.check(st, "ia_ffn_fused")
+    return x_f32
+
+
 def glu_dwconv_bn_silu_fast(x2_bf16, lens, B, T, d, dw_weight, dw_bias, bn, training):
     """x2 [B*T, 2d] bf16 -> [B*T, d] bf16 : GLU, pad mask, depthwise conv, BatchNorm (batch stats in training), SiLU."""
     L = _lib.lib()

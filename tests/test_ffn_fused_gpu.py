@@ -1,0 +1,66 @@
+"""csrc/ffn_fused.hip (LayerNorm -> W1 -> SiLU -> dropout -> W2 -> dropout -> residual [-> LayerNorm] in one launch)
+against (a) the fp64 restatement of the same bf16-quantised computation and (b) the unfused HIP sequence it replaces
+(ia_layernorm + two ia_gemm_bf16 launches), which shares its dropout masks bit for bit."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _modules(d=256, dff=1024, seed=0):
+    torch.manual_seed(seed)
+    ln = torch.nn.LayerNorm(d).cuda()
+    l1, l2 = torch.nn.Linear(d, dff).cuda(), torch.nn.Linear(dff, d).cuda()
+    ln2 = torch.nn.LayerNorm(d).cuda()
+    with torch.no_grad():
+        for m in (ln, ln2):
+            m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.2)
+    return ln, l1, l2, ln2
+
+
+def _reference(x, ln, l1, l2, alpha, ln2):
+    """fp64 math on the operands the kernel sees: bf16 LN output, bf16 weights, bf16 intermediate."""
+    xd = x.double()
+    y = torch.nn.functional.layer_norm(xd, (x.shape[1],), ln.weight.double(), ln.bias.double(), ln.eps).bfloat16().double()
+    h = y @ l1.weight.detach().bfloat16().double().t() + l1.bias.double()
+    h = (h * torch.sigmoid(h)).bfloat16().double()
+    o = h @ l2.weight.detach().bfloat16().double().t() + l2.bias.double()
+    r = xd + alpha * o
+    if ln2 is not None:
+        r = torch.nn.functional.layer_norm(r, (x.shape[1],), ln2.weight.double(), ln2.bias.double(), ln2.eps)
+    return r
+
+
+@pytest.mark.parametrize("N,with_ln2", [(64, False), (12032, True), (1000, True), (77, False)])
+def test_ffn_fused_matches_fp64_restatement(N, with_ln2):
+    from indic_cl_asr_amd.ops import fast
+    ln, l1, l2, ln2 = _modules()
+    g = torch.Generator().manual_seed(N)
+    x = (torch.randn(N, 256, generator=g) * 1.5).cuda()
+    ref = _reference(x, ln, l1, l2, 0.5, ln2 if with_ln2 else None)
+    y16 = torch.empty(N, 256, dtype=torch.bfloat16, device="cuda")
+    out = fast.ffn_fused(x.clone(), ln, l1, l2, 0.5, ln2=ln2 if with_ln2 else None, y_out=y16)
+    err = (out.double() - ref).abs().max().item()
+    assert err <= 3e-3 * ref.abs().max().item() + 1e-4, err   # fp32 accumulation of bf16 products, bf16 rounding ties
+    assert torch.equal(y16, out.bfloat16())
+
+
+@pytest.mark.parametrize("p_ff,p_res", [(0.0, 0.0), (0.1, 0.1), (0.5, 0.25)])
+def test_ffn_fused_matches_unfused_sequence_with_identical_dropout_masks(p_ff, p_res):
+    from indic_cl_asr_amd.ops import fast
+    ln, l1, l2, ln2 = _modules(seed=1)
+    N = 4000
+    x = (torch.randn(N, 256, generator=torch.Generator().manual_seed(5)) * 1.2).cuda()
+    # unfused: LayerNorm -> GEMM(SiLU, dropout) -> GEMM(dropout, alpha, residual) -> LayerNorm
+    xa = x.clone()
+    y = fast.layernorm(xa, ln.weight, ln.bias, ln.eps)
+    _, h = fast.gemm(y, fast.bf16_shadow(l1.weight), l1.bias, act=1, dropout_p=p_ff, seed=11)
+    fast.gemm(h, fast.bf16_shadow(l2.weight), l2.bias, dropout_p=p_res, seed=12, alpha=0.5, residual=xa, out_f32=xa, want_bf16=False)
+    fast.layernorm(xa, ln2.weight, ln2.bias, ln2.eps, out_f32=xa, want_bf16=False)
+    xb = fast.ffn_fused(x.clone(), ln, l1, l2, 0.5, p_ff, 11, p_res, 12, ln2=ln2)
+    # same masks, same bf16 operands: the two differ only by the order of fp32 sums and bf16 ties of the intermediate
+    err = (xa - xb).abs().max().item()
+    assert err <= 4e-3 * xa.abs().max().item(), err
+    if p_ff > 0:   # the masks really are applied (and differ from the p = 0 result)
+        x0 = fast.ffn_fused(x.clone(), ln, l1, l2, 0.5, ln2=ln2)
+        assert (x0 - xb).abs().max().item() > 0.05

@@ -115,14 +115,14 @@ def test_config2_medium_bf16_step_matches_oracle():
     lp, mp = m.training_step(cb, ['hi'] * 4)
     lp.backward()
     torch.cuda.synchronize()
-    _check_losses(mp, mo, 5e-3)
+    _check_losses(mp, mo, 1e-3)     # the north_star's bound, at the benchmarked dtype (observed 1e-5)
     rows = _grad_table(m, o, min_checked=3 * 30 + 8)
     print("worst gradient tensors (relative L2 vs fp32 oracle):")
     for e, n in rows[:8]:
         print(f"  {e:.3e}  {n}")
     print("median", f"{rows[len(rows) // 2][0]:.3e}")
-    assert rows[0][0] <= 0.08, rows[0]
-    assert rows[len(rows) // 2][0] <= 0.03
+    assert rows[0][0] <= 0.04, rows[0]               # observed 1.9e-2 (linear_pos of the first trainable layer)
+    assert rows[len(rows) // 2][0] <= 0.01           # observed 4.0e-3
     # encoder frame counts bit-exact, BatchNorm running stats of a frozen layer updated alike (reference quirk)
     bo, bp = o.encoder.layers[3].conv.batch_norm, m.encoder.layers[3].conv.batch_norm
     assert torch.allclose(bp.running_var.cpu(), bo.running_var, rtol=3e-2, atol=1e-4)
@@ -146,10 +146,10 @@ def test_config3_mas_importance_pass_medium_dims():
     imp_p = cl.mas_importance_loss(m, 0.3)
     imp_p.backward()
     torch.cuda.synchronize()
-    _check_losses(mp, mo, 5e-3)
+    _check_losses(mp, mo, 1e-3)
     rel = abs(imp_p.item() - imp_o.item()) / abs(imp_o.item())
     print("importance loss rel err", f"{rel:.2e}")
-    assert rel <= 1e-2
+    assert rel <= 2e-3                                # observed 3.4e-4
     om = cl.get_zero_params(m)
     cl.importance_accumulate(flat, om)
     og = dict(o.named_parameters())
@@ -160,7 +160,7 @@ def test_config3_mas_importance_pass_medium_dims():
             continue
         e = _rel_l2(om[n], og[n].grad.abs())
         worst = max(worst, e); n_checked += 1
-        assert e <= 0.10, (n, e)
+        assert e <= 0.04, (n, e)                      # observed worst 1.4e-2
     print("omega worst rel L2", f"{worst:.3e}", "tensors", n_checked)
     assert n_checked >= 90
 
