@@ -249,6 +249,19 @@ int ia_attn_bwd_unpack(const void* dQu, const void* dQv, const void* dK, const v
 int64_t ia_attn_bwd_unpack_scratch_elems(int B, int T, int H);
 
 /* ------------------------------------------------------------------------------------------------
+ * Rel-pos attention forward with a key-tile loop and online softmax (csrc/attention_flash.hip): the same function as
+ * ia_relpos_attention (RelPositionMultiHeadAttention.forward, multi_head_attention.py:197-250) without its limits:
+ * any T (30 s audio: T' = 751), head dim any multiple of 4 up to 64 (d = 144 / 4 heads = 36), no V^T scratch.
+ * qkv [B*T, 3*H*dk] bf16 (q|k|v), pos_proj [>= 2T-1, H*dk] bf16 (row r <-> relative position T-1-r), bias_u/bias_v
+ * [H*dk] f32, lens [B] i64 -> ctx [B*T, H*dk] bf16 (rows of padded queries are zero).  Attention dropout draws its
+ * own mask (one hash per (head, query, 4 keys)); it is the forward of no-autograd passes (frozen prefix, teacher,
+ * eval), so no backward has to reproduce it. */
+int ia_relpos_attention_flash_supported(int T, int dk);
+int ia_relpos_attention_flash(const void* qkv, const void* pos_proj, const float* bias_u, const float* bias_v,
+                              const int64_t* lens, int B, int T, int H, int dk, float dropout_p, unsigned seed, void* ctx,
+                              ia_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Persistent single-layer LSTM: the recurrence of the RNNT prediction network (RNNTDecoder.predict
  * A/modules/rnnt.py:683-792 -> LSTMDropout C/parts/rnn.py:151-235 -> torch.nn.LSTM, gate order i,f,g,o, zero initial
  * state) as ONE launch per direction instead of ~6 launches per time step.

@@ -66,6 +66,8 @@ SIGNATURES = {
     "ia_bn_silu": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp]),
     "ia_attn_vt_elems": (_sz, [_i, _i, _i]),
     "ia_relpos_attention": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _c.c_uint, _vp, _vp, _vp]),
+    "ia_relpos_attention_flash_supported": (_i, [_i, _i]),
+    "ia_relpos_attention_flash": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _c.c_uint, _vp, _vp]),
     "ia_relpos_attention_bwd_dims": (_i, [_i, _vp, _vp, _vp]),
     "ia_relpos_attention_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _c.c_uint, _vp, _vp, _vp, _vp, _vp,
                                      _vp, _vp, _vp]),

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "indicasr.h"
 
@@ -65,6 +66,9 @@ extern "C" int ia_conformer_prefix_fwd(const ia_block_params* layers, int n_laye
     // feed-forward modules: one row-resident launch each (csrc/ffn_fused.hip: LayerNorm, both projections, SiLU, dropouts,
     // residual and -- for the second module -- norm_out) where the shape allows, else LayerNorm + two GEMM launches
     const bool ffn_fused = ia_ffn_fused_supported(d, d_ff) != 0;
+    // attention: key-tile loop kernel (any T, head dim <= 64); IA_PREFIX_ATTN=old selects the all-keys-in-registers kernel
+    const char* attn_env = getenv("IA_PREFIX_ATTN");
+    const bool use_flash = ia_relpos_attention_flash_supported(T, dk) != 0 && !(attn_env && attn_env[0] == 'o');
     // LayerNorm in front of the first block's first feed-forward; later ones are chained behind the previous norm_out
     if (!ffn_fused)
         IA_TRY(ia_layernorm(x, d, N, d, l0.ln_ff1_g, l0.ln_ff1_b, l0.ln_eps, nullptr, 0, nullptr, nullptr, y, d, stream));
@@ -85,7 +89,10 @@ extern "C" int ia_conformer_prefix_fwd(const ia_block_params* layers, int n_laye
         IA_TRY(ia_layernorm(x, d, N, d, L.ln_att_g, L.ln_att_b, L.ln_eps, nullptr, 0, nullptr, nullptr, y, d, stream));
         IA_TRY(ia_gemm_bf16(y, d, L.w_qkv, d, N, 3 * d, d, L.b_qkv, 0, 0.f, 0, 1.f, nullptr, 0, nullptr, 0, qkv, 3 * d, stream));
         IA_TRY(ia_gemm_bf16(pos_emb, d, L.w_pos, d, pos_rows, d, d, nullptr, 0, 0.f, 0, 1.f, nullptr, 0, nullptr, 0, pl, d, stream));
-        IA_TRY(ia_relpos_attention(qkv, pl, L.pos_u, L.pos_v, lens, B, T, H, dk, patt, seed + 7, vt, ctx, stream));
+        if (use_flash)
+            IA_TRY(ia_relpos_attention_flash(qkv, pl, L.pos_u, L.pos_v, lens, B, T, H, dk, patt, seed + 7, ctx, stream));
+        else
+            IA_TRY(ia_relpos_attention(qkv, pl, L.pos_u, L.pos_v, lens, B, T, H, dk, patt, seed + 7, vt, ctx, stream));
         IA_TRY(ia_gemm_bf16(ctx, d, L.w_out, d, N, d, d, L.b_out, 0, p, seed + 3, 1.f, x, d, x, d, nullptr, 0, stream));
         // convolution module
         IA_TRY(ia_layernorm(x, d, N, d, L.ln_conv_g, L.ln_conv_b, L.ln_eps, nullptr, 0, nullptr, nullptr, y, d, stream));

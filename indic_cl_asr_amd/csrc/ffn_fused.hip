@@ -24,6 +24,8 @@
 // 2.5 PF dense); each workgroup also pulls the full 1 MB of weights through its CU's L2 port, the actual bound.
 #include <hip/hip_bf16.h>
 
+#include <stdlib.h>
+
 #include "ia_common.h"
 #include "dropout_mask.h"
 
@@ -47,6 +49,7 @@ struct FfnArgs {
     unsigned thr_res, seed_res; float ks_res;  // dropout on the module output
     const float* ln2_g; const float* ln2_b;    // optional LayerNorm of the updated residual (norm_out)
     __bf16* y_out;                             // optional bf16 copy of the result (operand of the next projection)
+    int mode;                                  // diagnostics (tools/bench_ffn.py): bit 0 = no weight loads in the loop, bit 1 = no MFMAs
 };
 
 __device__ __forceinline__ float half_wave_sum(float v) {   // sum over the 32 lanes of a half wave (rows are half waves)
@@ -58,55 +61,80 @@ __device__ __forceinline__ float half_wave_sum(float v) {   // sum over the 32 l
     return v;
 }
 
+// Weight streaming: the two projections' weights (1 MB at d = 256) pass through every workgroup's LDS once, so the kernel
+// is paced by the CU's L2 -> LDS rate; what that rate needs is bytes IN FLIGHT all the time (the first version issued
+// one 64 KB chunk per phase behind a draining barrier and reached 23 GB/s per CU: 44 us per launch, no better than the
+// three launches it replaced).  The weights therefore stream through a ring of four 32 KB slots, per 128-unit chunk c:
+//   slot 0  W1[128c .. +127][k   0..127]      slot 1  W1[128c .. +127][k 128..255]        (phase A, k halves)
+//   slot 2  W2[:, 128c     .. +63]            slot 3  W2[:, 128c + 64 .. +127]            (phase B, j halves)
+// All eight waves consume one slot between two raw s_barriers; at each barrier the slot three ahead is requested into
+// the space just freed, so two to three slots (64-96 KB) are always on their way, and a wave waits with a COUNTED
+// vmcnt for exactly the slot it is about to read (never vmcnt(0), never __syncthreads() inside the loop: both would
+// drain the queue).  b1 sits in LDS and is read through inline asm: hipcc waits vmcnt(0) in front of an ordinary vector load
+// and of a compiler-visible LDS read while LDS-DMA is in flight.
 template <int D>
 __global__ __launch_bounds__(FF_THREADS, 2) void ffn_fused_kernel(FfnArgs a) {
     static_assert(D == 256, "wave decomposition below is written for d_model = 256");
-    constexpr int KS = D / 16;            // k-steps of phase A
-    constexpr int W1ROW = D * 2;          // bytes per W1 row in LDS (512)
-    constexpr int W2ROW = FF_JC * 2;      // bytes per W2 row / X row in LDS (256)
-    constexpr int W1BUF = FF_JC * W1ROW;  // 65536
-    constexpr int W2BUF = D * W2ROW;      // 65536
+    constexpr int SLOT = 32768;
+    constexpr int YROW = D * 2;           // bytes per LN(x) row in the prologue staging (512)
+    constexpr int XROW = FF_JC * 2;       // bytes per X row (256)
     constexpr int EROW = D * 4 + 16;      // fp32 epilogue row (padded)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* sW1 = smem;
-    unsigned char* sW2 = smem + W1BUF;
-    unsigned char* sX = smem + W1BUF + W2BUF;   // [64][128] bf16
-    unsigned char* sY = sW2;                     // prologue alias: LN(x) [64][256] bf16
-    unsigned char* sE = smem;                    // epilogue alias: out [64][EROW]
+    unsigned char* sRing = smem;                    // 4 x 32 KB
+    unsigned char* sX = smem + 4 * SLOT;            // [64][128] bf16
+    float* sB1 = reinterpret_cast<float*>(smem + 4 * SLOT + FF_M * XROW);   // [dff] (read through inline asm in the loop)
+    unsigned char* sY = smem + 3 * SLOT;            // prologue alias (ring slot 3): LN(x) [64][256] bf16
+    unsigned char* sE = smem;                       // epilogue alias: out [64][EROW]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hh = lane >> 5, sw = l31 & 15;
     const int mi = wave & 1, q = wave >> 1;
     const int m0 = blockIdx.x * FF_M;
     const int nchunks = a.dff / FF_JC;
+    const int total = nchunks * 4;
 
-    // ---- weight chunk staging (LDS-DMA).  W1 chunk: 128 rows x 512 B, one instruction = 2 rows; W2 chunk: 256 rows x
-    // 256 B (columns 128c.. of the [D, dff] matrix), one instruction = 4 rows.  Wave w issues instructions 8w .. 8w+7.
-#define FF_LOAD_W1(c_)                                                                                                   \
-    do {                                                                                                                 \
-        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                                               \
-            const int blk_ = wave * 8 + i_;                                                                              \
-            const int row_ = 2 * blk_ + hh;                                                                              \
-            const int cp_ = lane & 31;                                                                                   \
-            const int cs_ = (cp_ & 16) | ((cp_ & 15) ^ (row_ & 15));                                                     \
-            const unsigned char* src_ = reinterpret_cast<const unsigned char*>(a.W1 + (size_t)((c_) * FF_JC + row_) * D) + cs_ * 16; \
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,                        \
-                                             (__attribute__((address_space(3))) void*)(sW1 + blk_ * 1024), 16, 0, 0);    \
-        }                                                                                                                \
-    } while (0)
-#define FF_LOAD_W2(c_)                                                                                                   \
-    do {                                                                                                                 \
-        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                                               \
-            const int blk_ = wave * 8 + i_;                                                                              \
-            const int row_ = 4 * blk_ + (lane >> 4);                                                                     \
-            const int cs_ = (lane & 15) ^ (row_ & 15);                                                                   \
-            const unsigned char* src_ = reinterpret_cast<const unsigned char*>(a.W2 + (size_t)row_ * a.dff + (c_) * FF_JC) + cs_ * 16; \
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,                        \
-                                             (__attribute__((address_space(3))) void*)(sW2 + blk_ * 1024), 16, 0, 0);    \
-        }                                                                                                                \
-    } while (0)
+    // slot g = 4 c + p.  One LDS-DMA instruction moves 1 KB (lane l -> 16 bytes at position l): W1 half-rows are 256 B
+    // (4 rows per instruction, 16-byte slot XOR row & 15), W2 half-rows 128 B (8 rows per instruction, slot XOR (row >> 1) & 7:
+    // two rows share a 256-byte bank window).  Wave w issues instructions 4 w .. 4 w + 3 of a slot's 32.
+    auto issue_slot = [&](int g) {
+        const int c = g >> 2, p = g & 3;
+        unsigned char* dst = sRing + p * SLOT;
+        if (p < 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int blk = wave * 4 + i;
+                const int row = 4 * blk + (lane >> 4);
+                const int cs = (lane & 15) ^ (row & 15);
+                const unsigned char* src = reinterpret_cast<const unsigned char*>(a.W1 + (size_t)(c * FF_JC + row) * D + p * 128) + cs * 16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(dst + blk * 1024), 16, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int blk = wave * 4 + i;
+                const int row = 8 * blk + (lane >> 3);
+                const int cs = (lane & 7) ^ ((row >> 1) & 7);
+                const unsigned char* src = reinterpret_cast<const unsigned char*>(a.W2 + (size_t)row * a.dff + c * FF_JC + (p - 2) * 64) + cs * 16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(dst + blk * 1024), 16, 0, 0);
+            }
+        }
+    };
+    // rendezvous in front of slot g: this wave's share of slot g has landed (later slots stay in flight), everybody is done
+    // with slot g - 1, whose space then takes slot g + 3
+    auto step_sync = [&](int g) {
+        const int rem = total - 1 - g;
+        if (rem >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (g + 3 < total && !(a.mode & 1)) issue_slot(g + 3);
+    };
 
-    FF_LOAD_W1(0);
+    issue_slot(0); issue_slot(1); issue_slot(2);
+    for (int i = tid; i < a.dff; i += FF_THREADS) sB1[i] = a.b1[i];
 
     // ---- prologue: LayerNorm of the 64 frames, half a wave per frame (32 lanes x 8 channels), bf16 -> sY (swizzled)
 #pragma unroll
@@ -132,19 +160,18 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ffn_fused_kernel(FfnArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) o.h[j] = (__bf16)(v[j] * rstd * gg[j] + bb[j]);
         const int phys = (vec & 16) | ((vec & 15) ^ (r & 15));
-        *reinterpret_cast<uint4*>(sY + r * W1ROW + phys * 16) = o.u;
+        *reinterpret_cast<uint4*>(sY + r * YROW + phys * 16) = o.u;
     }
     __syncthreads();
     // this wave's 32 frames as B fragments of phase A: lane (frame l31, half hh) holds channels 16 s + 8 hh .. + 7
+    constexpr int KS = D / 16;
     bf8 yf[KS];
+    const int t16 = (hh ^ sw) * 16;
     {
-        const unsigned char* yrow = sY + (mi * 32 + l31) * W1ROW;
-        const int t16 = (hh ^ sw) * 16;
+        const unsigned char* yrow = sY + (mi * 32 + l31) * YROW;
 #pragma unroll
         for (int s = 0; s < KS; ++s) yf[s] = *reinterpret_cast<const bf8*>(yrow + ((s & 8) * 32) + (((s & 7) * 32) ^ t16));
     }
-    __syncthreads();   // sY (= sW2) is free; the W1(0) DMA has landed (the barrier drains the LDS-DMA queue)
-    FF_LOAD_W2(0);
 
     f16v o[2];
 #pragma unroll
@@ -152,28 +179,42 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ffn_fused_kernel(FfnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[nt][r] = 0.f;
 
-    const int t16 = (hh ^ sw) * 16;
-    const unsigned char* w1row = sW1 + (q * 32 + l31) * W1ROW;
-    const unsigned char* xrow = sX + (mi * 32 + l31) * W2ROW;
-    const unsigned char* w2row = sW2 + (q * 64 + l31) * W2ROW;
+    const unsigned char* w1row = sRing + (q * 32 + l31) * 256;                    // + slot base, rows of 256 B
+    const int w2sw = (((q * 64 + l31) >> 1) & 7);                                  // (row >> 1) & 7, same for row + 32
+    const unsigned char* w2row = sRing + 2 * SLOT + (q * 64 + l31) * 128;          // rows of 128 B
+    const unsigned char* xrow = sX + (mi * 32 + l31) * XROW;
     const unsigned gm_drop = (unsigned)(m0 + mi * 32 + l31);
+    const bool do_mfma = !(a.mode & 2);
 
     for (int c = 0; c < nchunks; ++c) {
-        // ---------------------------------------------------------------- phase A
+        // ---------------------------------------------------------------- phase A: two k halves
         f16v acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        float4 bia[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) bia[g] = *reinterpret_cast<const float4*>(a.b1 + c * FF_JC + q * 32 + g * 8 + hh * 4);
+        for (int p = 0; p < 2; ++p) {
+            step_sync(4 * c + p);
+            if (do_mfma) {
+                bf8 wf[8];   // all fragments of the slot are requested before the first MFMA (one LDS latency per slot, not per pair)
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const bf8 wf = *reinterpret_cast<const bf8*>(w1row + ((s & 8) * 32) + (((s & 7) * 32) ^ t16));
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, yf[s], acc, 0, 0, 0);
+                for (int s = 0; s < 8; ++s) wf[s] = *reinterpret_cast<const bf8*>(w1row + p * SLOT + ((s * 32) ^ t16));
+#pragma unroll
+                for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s], yf[p * 8 + s], acc, 0, 0, 0);
+            }
+        }
+        // b1 from LDS through inline asm: a compiler-visible LDS read here makes hipcc drain vmcnt(0) (it assumes the read may
+        // alias the LDS-DMA destinations) and stalls the weight stream; lane (hh) needs units 32 q + 8 g + 4 hh .. + 3
+        float4 bias4[4];
+        {
+            const unsigned baddr = (unsigned)(4 * SLOT + FF_M * XROW) + (unsigned)((c * FF_JC + q * 32 + hh * 4) * 4);
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:32\n\tds_read_b128 %2, %4 offset:64\n\t"
+                         "ds_read_b128 %3, %4 offset:96\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(bias4[0]), "=&v"(bias4[1]), "=&v"(bias4[2]), "=&v"(bias4[3]) : "v"(baddr) : "memory");
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            float v[4] = {acc[4 * g] + bia[g].x, acc[4 * g + 1] + bia[g].y, acc[4 * g + 2] + bia[g].z, acc[4 * g + 3] + bia[g].w};
+            const float4 bia = bias4[g];
+            float v[4] = {acc[4 * g] + bia.x, acc[4 * g + 1] + bia.y, acc[4 * g + 2] + bia.z, acc[4 * g + 3] + bia.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = v[i] / (1.f + __expf(-v[i]));
             if (a.thr_ff > 0) {
@@ -184,23 +225,33 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ffn_fused_kernel(FfnArgs a) {
             union { uint2 u; __bf16 h[4]; } pk;
 #pragma unroll
             for (int i = 0; i < 4; ++i) pk.h[i] = (__bf16)v[i];
-            *reinterpret_cast<uint2*>(sX + (mi * 32 + l31) * W2ROW + (((q * 4 + g) ^ sw) * 16) + hh * 8) = pk.u;
+            {   // X store through inline asm as well (a compiler-visible LDS store draws the same vmcnt(0))
+                const unsigned xaddr = (unsigned)(4 * SLOT) + (unsigned)((mi * 32 + l31) * XROW + (((q * 4 + g) ^ sw) * 16) + hh * 8);
+                asm volatile("ds_write_b64 %0, %1" :: "v"(xaddr), "v"(pk.u) : "memory");
+            }
         }
-        __syncthreads();   // X complete, W2(c) landed, W1 buffer free
-        if (c + 1 < nchunks) FF_LOAD_W1(c + 1);
-        // ---------------------------------------------------------------- phase B
+        // ---------------------------------------------------------------- phase B: two j halves
 #pragma unroll
-        for (int s = 0; s < FF_JC / 16; ++s) {
-            const int off = ((s * 32) ^ t16);
-            const bf8 xb = *reinterpret_cast<const bf8*>(xrow + off);
-            const bf8 w0 = *reinterpret_cast<const bf8*>(w2row + off);
-            const bf8 w1 = *reinterpret_cast<const bf8*>(w2row + 32 * W2ROW + off);
-            o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xb, o[0], 0, 0, 0);
-            o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, xb, o[1], 0, 0, 0);
+        for (int p = 0; p < 2; ++p) {
+            step_sync(4 * c + 2 + p);
+            if (do_mfma) {
+                bf8 xb[4], w0[4], w1[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int woff = p * SLOT + (((s * 2 + hh) ^ w2sw) * 16);
+                    xb[s] = *reinterpret_cast<const bf8*>(xrow + (((p * 8 + s * 2 + hh) ^ sw) * 16));
+                    w0[s] = *reinterpret_cast<const bf8*>(w2row + woff);
+                    w1[s] = *reinterpret_cast<const bf8*>(w2row + 32 * 128 + woff);
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0[s], xb[s], o[0], 0, 0, 0);
+                    o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[s], xb[s], o[1], 0, 0, 0);
+                }
+            }
         }
-        __syncthreads();   // W2 buffer and X free, W1(c+1) landed
-        if (c + 1 < nchunks) FF_LOAD_W2(c + 1);
     }
+    __syncthreads();   // every wave is done with the ring and X; nothing is in flight
 
     // ---- epilogue: out^T accumulators -> sE[frame][channel] fp32 (lane = frame, 4 consecutive channels per register group)
 #pragma unroll
@@ -263,13 +314,11 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ffn_fused_kernel(FfnArgs a) {
             }
         }
     }
-#undef FF_LOAD_W1
-#undef FF_LOAD_W2
 }
 
 }  // namespace
 
-extern "C" int ia_ffn_fused_supported(int d, int d_ff) { return (d == 256 && d_ff > 0 && d_ff % FF_JC == 0) ? 1 : 0; }
+extern "C" int ia_ffn_fused_supported(int d, int d_ff) { return (d == 256 && d_ff > 0 && d_ff % FF_JC == 0 && d_ff <= 2048) ? 1 : 0; }
 
 extern "C" int ia_ffn_fused(float* x, int N, int d, int d_ff, const float* ln_g, const float* ln_b, float eps, const void* W1,
                             const float* b1, const void* W2, const float* b2, float alpha, float p_ff, unsigned seed_ff,
@@ -290,8 +339,10 @@ extern "C" int ia_ffn_fused(float* x, int N, int d, int d_ff, const float* ln_g,
     a.thr_res = (unsigned)(p_res * 256.f + 0.5f); a.seed_res = seed_res;
     a.ks_res = a.thr_res > 0 ? 256.f / (256.f - (float)a.thr_res) : 1.f;
     a.ln2_g = ln2_g; a.ln2_b = ln2_b; a.y_out = (__bf16*)y_out;
-    constexpr int LDS = FF_JC * 256 * 2 + 256 * FF_JC * 2 + FF_M * FF_JC * 2;   // 147 456 B
-    static_assert(FF_M * (256 * 4 + 16) <= 2 * FF_JC * 256 * 2, "epilogue tile aliases the weight buffers");
+    if (d_ff > 2048) return IA_UNSUPPORTED;                    // b1 is kept in LDS
+    const int LDS = 4 * 32768 + FF_M * FF_JC * 2 + d_ff * 4;   // ring + X + b1 = 151 552 B at d_ff = 1024
+    static_assert(FF_M * (256 * 4 + 16) <= 4 * 32768, "epilogue tile aliases the ring");
+    { const char* e = getenv("IA_FFN_MODE"); a.mode = (e && *e) ? atoi(e) : 0; }   // diagnostics only
     if (hipFuncSetAttribute((const void*)ffn_fused_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
         return IA_LAUNCH_FAILED;
     hipLaunchKernelGGL((ffn_fused_kernel<256>), dim3((N + FF_M - 1) / FF_M), dim3(FF_THREADS), LDS, (hipStream_t)stream, a);

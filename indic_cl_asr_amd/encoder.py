@@ -188,7 +188,10 @@ class ConformerLayer(nn.Module):
         _, qkv = fast.gemm(y, fast.bf16_shadow(att.linear_q.weight, att.linear_k.weight, att.linear_v.weight),
                            fast.f32_cat(att.linear_q.bias, att.linear_k.bias, att.linear_v.bias))
         _, pl = fast.gemm(pos_emb, fast.bf16_shadow(att.linear_pos.weight))
-        if fast.attention_supported(T, att.d_k):
+        if fast.attention_flash_supported(T, att.d_k):
+            ctx = fast.relpos_attention_flash(qkv, pl, att.pos_bias_u, att.pos_bias_v, lens, B, T, att.h, att.d_k,
+                                              att.dropout_rate if tr else 0.0, seed + 7)
+        elif fast.attention_supported(T, att.d_k):
             ctx = fast.relpos_attention(qkv, pl, att.pos_bias_u, att.pos_bias_v, lens, B, T, att.h, att.d_k,
                                         att.dropout_rate if tr else 0.0, seed + 7)
         else:  # long inputs (T' > 384) / other head sizes: ATen composition
@@ -327,7 +330,7 @@ class ConformerEncoder(nn.Module):
         l0 = self.layers[0]
         bn_ok = all(l.conv.batch_norm.track_running_stats for l in self.layers[:n_fast])
         same_mode = all(l.training == l0.training for l in self.layers[:n_fast])
-        if fast.attention_supported(T, l0.self_attn.d_k) and bn_ok and same_mode:
+        if (fast.attention_flash_supported(T, l0.self_attn.d_k) or fast.attention_supported(T, l0.self_attn.d_k)) and bn_ok and same_mode:
             # native executor: one C call enqueues the 14 kernels of every block (csrc/block_exec.hip)
             fast.conformer_prefix(list(self.layers[:n_fast]), xr, pe, length, B, T, base, 16, l0.training)
             return xr.view(B, T, d), n_fast

@@ -175,7 +175,26 @@ def glu_dwconv_bn_silu_fast(x2_bf16, lens, B, T, d, dw_weight, dw_bias, bn, trai
 
 
 def attention_supported(T, dk):
+    """The all-keys-in-registers kernel pair (forward + backward row pass) of the trainable blocks."""
     return dk == 64 and T <= 384
+
+
+USE_FLASH_ATTN = True   # tests flip this to compare the two forward kernels
+
+
+def attention_flash_supported(T, dk):
+    return USE_FLASH_ATTN and bool(_lib.lib().ia_relpos_attention_flash_supported(int(T), int(dk)))
+
+
+def relpos_attention_flash(qkv_bf16, pos_proj_bf16, bias_u, bias_v, lens, B, T, H, dk, dropout_p=0.0, seed=0):
+    """qkv [B*T, 3*H*dk] bf16, pos_proj [>= 2T-1, H*dk] bf16 -> ctx [B*T, H*dk] bf16: key-tile loop with online softmax
+    (csrc/attention_flash.hip), any T, head dim <= 64.  No-autograd passes only (its dropout mask has no backward)."""
+    ctx = torch.empty(B * T, H * dk, dtype=torch.bfloat16, device=qkv_bf16.device)
+    st = _lib.lib().ia_relpos_attention_flash(_lib.ptr(qkv_bf16), _lib.ptr(pos_proj_bf16), _lib.ptr(bias_u), _lib.ptr(bias_v),
+                                              _lib.ptr(lens), B, T, H, dk, float(dropout_p), int(seed) & 0xFFFFFFFF,
+                                              _lib.ptr(ctx), _lib.stream_ptr())
+    _lib.check(st, "ia_relpos_attention_flash")
+    return ctx
 
 
 _VT = {}

@@ -63,6 +63,10 @@ def test_adamw_skips_tensors_without_gradient_across_a_language_switch():
     assert torch.equal(po["joint.joint_net.2.hi.weight"], hi3)                         # reference: frozen after the switch
     torch.cuda.synchronize()
     for n in flat.names:
+        # (structurally zero gradients -- a bias in front of train-mode BatchNorm, the key bias -- are rounding noise on
+        #  both sides, and Adam normalises noise to full-size steps: not comparable)
+        if n.endswith("depthwise_conv.bias") or n.endswith("self_attn.linear_k.bias"):
+            continue
         a, b = flat.params_dict()[n].cpu().double(), po[n].detach().double()
         assert torch.allclose(a, b, rtol=2e-4, atol=5e-5), (n, (a - b).abs().max().item())
     assert torch.allclose(flat.params_dict()["joint.joint_net.2.hi.weight"].cpu(), hi3, rtol=2e-4, atol=5e-5)
