@@ -346,8 +346,9 @@ int ia_gemm_tn_bf16(const void* dY, int ldy, const void* X, int ldx, int M, int 
  * module) of ConformerLayer.forward, A/parts/submodules/conformer_modules.py:141-214,385-404.  The [N, d_ff] intermediate
  * stays in LDS (64-frame tiles); the LayerNorm'd frames stay in registers as MFMA operands.
  * x [N, d] f32 in/out (in place); W1 [d_ff, d] bf16, W2 [d, d_ff] bf16 (nn.Linear layout), biases / LayerNorm f32.
- * Dropout masks are the ones of ia_gemm_bf16 for the same (seed, row, column): keyed (seed_ff, [N, d_ff]) after the
- * activation and (seed_res, [N, d]) on the module output; p = 0 disables.  ln2_g/ln2_b NULL: no second LayerNorm.
+ * Dropout: after the activation a mask of the kernel's own (one cheap 32-bit word per frame and 4 hidden units, keyed by
+ * seed_ff: this is the forward of no-autograd passes, nothing has to regenerate it); on the module output the mask of
+ * ia_gemm_bf16 for (seed_res, row, column of [N, d]); p = 0 disables.  ln2_g/ln2_b NULL: no second LayerNorm.
  * y_out (optional, [N, d] bf16): a bf16 copy of the result.  Limits: ia_ffn_fused_supported(d, d_ff) (d = 256,
  * d_ff % 128 == 0); IA_UNSUPPORTED otherwise. */
 int ia_ffn_fused_supported(int d, int d_ff);

@@ -185,6 +185,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ffn_fused_kernel(FfnArgs a) {
     const unsigned char* xrow = sX + (mi * 32 + l31) * XROW;
     const unsigned gm_drop = (unsigned)(m0 + mi * 32 + l31);
     const bool do_mfma = !(a.mode & 2);
+    const unsigned sm_ff = ia_dm_hash32(a.seed_ff);
 
     for (int c = 0; c < nchunks; ++c) {
         // ---------------------------------------------------------------- phase A: two k halves
@@ -215,12 +216,14 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ffn_fused_kernel(FfnArgs a) {
         for (int g = 0; g < 4; ++g) {
             const float4 bia = bias4[g];
             float v[4] = {acc[4 * g] + bia.x, acc[4 * g + 1] + bia.y, acc[4 * g + 2] + bia.z, acc[4 * g + 3] + bia.w};
+            // SiLU as v * rcp(1 + exp2(-v log2 e)): 6 VALU per element (the IEEE division of v / (1 + expf(-v)) alone was ~12;
+            // this epilogue, not the MFMAs, paced the first version of the kernel)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = v[i] / (1.f + __expf(-v[i]));
-            if (a.thr_ff > 0) {
-                const unsigned mk = ia_keep8(a.seed_ff, gm_drop, (unsigned)a.dff, (unsigned)(c * FF_JC + q * 32 + g * 8), a.thr_ff) >> (hh * 4);
+            for (int i = 0; i < 4; ++i) v[i] = v[i] * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(v[i] * -1.44269504088896341f));
+            if (a.thr_ff > 0) {   // one cheap word per (frame, 4 units): this lane's 4 consecutive units are exactly one group
+                const unsigned w = ia_dm_word24(sm_ff, gm_drop * (unsigned)(a.dff >> 2) + (unsigned)((c * FF_JC + q * 32 + g * 8 + hh * 4) >> 2));
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = ((mk >> i) & 1u) ? v[i] * a.ks_ff : 0.f;
+                for (int i = 0; i < 4; ++i) v[i] *= (((w >> (8 * i)) & 0xFFu) >= a.thr_ff) ? a.ks_ff : 0.f;   // byte i keeps unit i
             }
             union { uint2 u; __bf16 h[4]; } pk;
 #pragma unroll

@@ -45,22 +45,44 @@ def test_ffn_fused_matches_fp64_restatement(N, with_ln2):
     assert torch.equal(y16, out.bfloat16())
 
 
-@pytest.mark.parametrize("p_ff,p_res", [(0.0, 0.0), (0.1, 0.1), (0.5, 0.25)])
-def test_ffn_fused_matches_unfused_sequence_with_identical_dropout_masks(p_ff, p_res):
+@pytest.mark.parametrize("p_res", [0.0, 0.1, 0.25])
+def test_ffn_fused_matches_unfused_sequence_with_identical_output_dropout_mask(p_res):
+    """The module-output dropout uses ia_gemm_bf16's mask for the same (seed, row, column): with it on (and the inner
+    dropout off) the fused launch and the LayerNorm + two-GEMM sequence agree element by element."""
     from indic_cl_asr_amd.ops import fast
     ln, l1, l2, ln2 = _modules(seed=1)
     N = 4000
     x = (torch.randn(N, 256, generator=torch.Generator().manual_seed(5)) * 1.2).cuda()
-    # unfused: LayerNorm -> GEMM(SiLU, dropout) -> GEMM(dropout, alpha, residual) -> LayerNorm
     xa = x.clone()
     y = fast.layernorm(xa, ln.weight, ln.bias, ln.eps)
-    _, h = fast.gemm(y, fast.bf16_shadow(l1.weight), l1.bias, act=1, dropout_p=p_ff, seed=11)
+    _, h = fast.gemm(y, fast.bf16_shadow(l1.weight), l1.bias, act=1)
     fast.gemm(h, fast.bf16_shadow(l2.weight), l2.bias, dropout_p=p_res, seed=12, alpha=0.5, residual=xa, out_f32=xa, want_bf16=False)
     fast.layernorm(xa, ln2.weight, ln2.bias, ln2.eps, out_f32=xa, want_bf16=False)
-    xb = fast.ffn_fused(x.clone(), ln, l1, l2, 0.5, p_ff, 11, p_res, 12, ln2=ln2)
-    # same masks, same bf16 operands: the two differ only by the order of fp32 sums and bf16 ties of the intermediate
+    xb = fast.ffn_fused(x.clone(), ln, l1, l2, 0.5, 0.0, 11, p_res, 12, ln2=ln2)
     err = (xa - xb).abs().max().item()
     assert err <= 4e-3 * xa.abs().max().item(), err
-    if p_ff > 0:   # the masks really are applied (and differ from the p = 0 result)
-        x0 = fast.ffn_fused(x.clone(), ln, l1, l2, 0.5, ln2=ln2)
-        assert (x0 - xb).abs().max().item() > 0.05
+
+
+def test_ffn_fused_inner_dropout_is_unbiased_and_deterministic():
+    """The dropout behind the activation draws the kernel's own cheap mask (one word per frame and 4 hidden units):
+    deterministic in the seed, different across seeds, and -- inverted dropout -- unbiased: the mean over many seeds
+    returns to the undropped result."""
+    from indic_cl_asr_amd.ops import fast
+    ln, l1, l2, _ = _modules(seed=2)
+    N = 1024
+    x = (torch.randn(N, 256, generator=torch.Generator().manual_seed(6)) * 1.2).cuda()
+    base = fast.ffn_fused(x.clone(), ln, l1, l2, 1.0) - x
+    d1 = fast.ffn_fused(x.clone(), ln, l1, l2, 1.0, 0.25, 21) - x
+    d2 = fast.ffn_fused(x.clone(), ln, l1, l2, 1.0, 0.25, 21) - x
+    d3 = fast.ffn_fused(x.clone(), ln, l1, l2, 1.0, 0.25, 22) - x
+    assert torch.equal(d1, d2) and not torch.equal(d1, d3)
+    single = ((d1 - base).norm() / base.norm()).item()
+    assert single > 0.05
+    acc = torch.zeros_like(base)
+    n = 32
+    for s in range(n):
+        acc += fast.ffn_fused(x.clone(), ln, l1, l2, 1.0, 0.25, 100 + s) - x
+    rel = ((acc / n - base).norm() / base.norm()).item()
+    assert rel < 0.3 * single, (rel, single)       # ~ 1/sqrt(32) of one draw's deviation
+    # keep rate: with W2 = I-like probe the fraction of zeroed hidden units is p; cheap proxy: E|d1| / E|base| ~ 1 within noise
+    assert 0.8 < (d1.abs().mean() / base.abs().mean()).item() < 1.3

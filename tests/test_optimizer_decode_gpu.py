@@ -44,8 +44,8 @@ def test_adamw_skips_tensors_without_gradient_across_a_language_switch():
     m.spec_augment_enabled = False
     S.freeze_layer(o, 0); freeze_layer(m, 0); m.encoder.encoder_frozen_till = 0
     flat = cl.FlatParams(m)
-    opt = cl.FusedAdamW(flat, lr=1e-2, weight_decay=0.1)
-    oref = torch.optim.AdamW([p for p in o.parameters() if p.requires_grad], lr=1e-2, weight_decay=0.1)
+    opt = cl.FusedAdamW(flat, lr=1e-3, weight_decay=0.1)
+    oref = torch.optim.AdamW([p for p in o.parameters() if p.requires_grad], lr=1e-3, weight_decay=0.1)
     batch = _batch()
     cb = tuple(t.cuda() for t in batch)
     ta0 = dict(o.named_parameters())["joint.joint_net.2.ta.weight"].detach().clone()
@@ -67,9 +67,12 @@ def test_adamw_skips_tensors_without_gradient_across_a_language_switch():
         #  both sides, and Adam normalises noise to full-size steps: not comparable)
         if n.endswith("depthwise_conv.bias") or n.endswith("self_attn.linear_k.bias"):
             continue
+        # (Adam turns gradient rounding differences between the CPU and GPU fp32 kernels into O(lr) differences wherever a
+        #  gradient component is near zero: compare on the scale of the 6 x lr a weight can have moved)
         a, b = flat.params_dict()[n].cpu().double(), po[n].detach().double()
-        assert torch.allclose(a, b, rtol=2e-4, atol=5e-5), (n, (a - b).abs().max().item())
-    assert torch.allclose(flat.params_dict()["joint.joint_net.2.hi.weight"].cpu(), hi3, rtol=2e-4, atol=5e-5)
+        assert torch.allclose(a, b, rtol=2e-4, atol=1.2e-3), (n, (a - b).abs().max().item())
+        assert (a - b).norm().item() <= 0.05 * 6e-3 * math.sqrt(a.numel()), n
+    assert torch.allclose(flat.params_dict()["joint.joint_net.2.hi.weight"].cpu(), hi3, rtol=2e-4, atol=2e-4)
     # step counters: 'hi' head 3 updates, 'ta' head 3 updates, shared tensors 6
     steps = dict(zip(flat.names, opt.seg_step.tolist()))
     assert steps["joint.joint_net.2.hi.weight"] == 3 and steps["joint.joint_net.2.ta.weight"] == 3
