@@ -380,6 +380,53 @@ int ia_conformer_prefix_fwd(const ia_block_params* layers, int n_layers, float* 
                             void* workspace, size_t workspace_bytes, ia_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Native executors of ONE TRAINABLE Conformer block (csrc/block_train.hip): ConformerLayer.forward
+ * (conformer_modules.py:141-214) keeping what its backward needs, and that backward as two calls around the attention
+ * core's backward (ia_relpos_attention_bwd + the caller's contractions).  Replaces the per-op Python autograd node:
+ * one C call enqueues the ~25 (forward) / ~35 + ~25 (backward) kernels of a block on `stream`.
+ *   ia_block_saved  activations kept from forward to backward (caller-owned; bf16 unless noted): y1,y2,y3,y4 [N,d] =
+ *                   LayerNorm outputs; h1p,h1,h4p,h4 [N,d_ff] = feed-forward pre-activation / dropout(SiLU(.));
+ *                   x1..x4 [N,d] f32 = residual stream after each module; qkv [N,3d]; pl [pos_rows,d]; ctxv [N,d];
+ *                   c2 [N,2d] (pointwise_conv1 output); z [N,d] f32 (depthwise conv output); sums [2,d] f32 (BatchNorm
+ *                   sum / sum of squares); c3 [N,d].
+ *   ia_block_grads  where the parameter gradients are WRITTEN (f32, caller-owned; the q|k|v weight / bias gradients are
+ *                   one [3d,d] / [3d] block in that order).
+ *   forward   x0 [N,d] f32 -> out [N,d] f32 (= norm_out(...)); train-mode BatchNorm (running statistics updated); dropout
+ *             sites seed + {1..7} as in ia_conformer_prefix_fwd; vt_scratch = ia_attn_vt_elems bf16, dw_scratch =
+ *             ia_dwconv_scratch_elems f32.  Limits: ia_conformer_block_supported (head dim 64, T <= 384, taps <= 31).
+ *   bwd_a     dout [N,d] f32 -> gradients of norm_out, feed_forward2, conv module, linear_out; *dx2_out (f32 [N,d]) and
+ *             *dctx_out (bf16 [N,d]) point INTO the workspace: d(residual in front of the attention branch), d(ctx).
+ *   bwd_b     dqkv [N,3d], dpl [pos_rows,d] (bf16, from the attention backward) -> remaining gradients, dx0 [N,d] f32,
+ *             then one launch adds the parameter gradients to their .grad buffers: add_table = n_add rows
+ *             {float* dst, const float* src, int64 n} in device memory (NULL: skip).
+ *   The workspace (ia_conformer_block_bwd_ws_bytes) must stay untouched between bwd_a and bwd_b. */
+typedef struct ia_block_saved {
+    void *y1, *h1p, *h1; float* x1;
+    void *y2, *qkv, *pl, *ctxv; float* x2;
+    void *y3, *c2; float *z, *sums; void* c3; float* x3;
+    void *y4, *h4p, *h4; float* x4;
+} ia_block_saved;
+typedef struct ia_block_grads {
+    float *w_ff1a, *b_ff1a, *w_ff1b, *b_ff1b, *w_qkv, *b_qkv, *w_pos, *w_out, *b_out, *w_pw1, *b_pw1, *w_pw2, *b_pw2;
+    float *w_ff2a, *b_ff2a, *w_ff2b, *b_ff2b;
+    float *ln_ff1_g, *ln_ff1_b, *ln_att_g, *ln_att_b, *ln_conv_g, *ln_conv_b, *ln_ff2_g, *ln_ff2_b, *ln_out_g, *ln_out_b;
+    float *dw_w, *dw_b, *bn_g, *bn_b;
+} ia_block_grads;
+struct ia_block_params;
+int ia_conformer_block_supported(int d, int d_ff, int H, int ksz, int T);
+size_t ia_conformer_block_bwd_ws_bytes(int B, int T, int d, int d_ff, int ksz);
+int ia_conformer_block_fwd(const struct ia_block_params* layer, const float* x0, const void* pos_emb, int pos_rows,
+                           const int64_t* lens, int B, int T, unsigned seed, const ia_block_saved* saved, float* out,
+                           void* vt_scratch, float* dw_scratch, ia_stream_t stream);
+int ia_conformer_block_bwd_a(const struct ia_block_params* layer, const ia_block_saved* saved, const ia_block_grads* grads,
+                             const float* dout, const int64_t* lens, int B, int T, unsigned seed, void* workspace,
+                             size_t workspace_bytes, float** dx2_out, void** dctx_out, ia_stream_t stream);
+int ia_conformer_block_bwd_b(const struct ia_block_params* layer, const ia_block_saved* saved, const ia_block_grads* grads,
+                             const float* x0, const void* pos_emb, int pos_rows, const void* dqkv, const void* dpl, int B,
+                             int T, unsigned seed, void* workspace, size_t workspace_bytes, float* dx0,
+                             const void* add_table, int n_add, ia_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Backward-side kernels of the trainable Conformer blocks (autograd of ConformerLayer.forward,
  * A/parts/submodules/conformer_modules.py:141-214); the dense contractions in between are bf16 GEMMs.
  *   ia_layernorm_bwd      dx_out = (dx_in or 0) + dLN/dx; dgamma/dbeta written (block partials in `scratch`, f32 x

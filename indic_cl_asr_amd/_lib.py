@@ -30,6 +30,21 @@ class BlockParams(_c.Structure):
         + [(n, _c.c_int) for n in ("d", "d_ff", "n_heads", "ksz")])
 
 
+class BlockSaved(_c.Structure):
+    """ia_block_saved of include/indicasr.h (activations a trainable block keeps from forward to backward)."""
+    _fields_ = [(n, _c.c_void_p) for n in ("y1", "h1p", "h1", "x1", "y2", "qkv", "pl", "ctxv", "x2", "y3", "c2", "z", "sums",
+                                           "c3", "x3", "y4", "h4p", "h4", "x4")]
+
+
+class BlockGrads(_c.Structure):
+    """ia_block_grads of include/indicasr.h (where a trainable block's parameter gradients are written)."""
+    _fields_ = [(n, _c.c_void_p) for n in (
+        "w_ff1a", "b_ff1a", "w_ff1b", "b_ff1b", "w_qkv", "b_qkv", "w_pos", "w_out", "b_out", "w_pw1", "b_pw1", "w_pw2", "b_pw2",
+        "w_ff2a", "b_ff2a", "w_ff2b", "b_ff2b",
+        "ln_ff1_g", "ln_ff1_b", "ln_att_g", "ln_att_b", "ln_conv_g", "ln_conv_b", "ln_ff2_g", "ln_ff2_b", "ln_out_g", "ln_out_b",
+        "dw_w", "dw_b", "bn_g", "bn_b")]
+
+
 SIGNATURES = {
     "ia_version": (_c.c_char_p, []),
     "ia_rnnt_workspace_bytes": (_sz, [_i, _i, _i]),
@@ -91,6 +106,11 @@ SIGNATURES = {
     "ia_ffn_fused": (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _f, _f, _c.c_uint, _f, _c.c_uint, _vp, _vp, _vp, _vp]),
     "ia_conformer_prefix_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "ia_conformer_prefix_fwd": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _c.c_uint, _c.c_uint, _i, _vp, _sz, _vp]),
+    "ia_conformer_block_supported": (_i, [_i, _i, _i, _i, _i]),
+    "ia_conformer_block_bwd_ws_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "ia_conformer_block_fwd": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _c.c_uint, _vp, _vp, _vp, _vp, _vp]),
+    "ia_conformer_block_bwd_a": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _c.c_uint, _vp, _sz, _vp, _vp, _vp]),
+    "ia_conformer_block_bwd_b": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _c.c_uint, _vp, _sz, _vp, _vp, _i, _vp]),
     "ia_layernorm_bwd": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _f, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "ia_layernorm_bwd_scratch_elems": (_i64, [_i, _i]),
     "ia_silu_dropout": (_i, [_vp, _i64, _i, _f, _c.c_uint, _vp, _vp]),

@@ -1,0 +1,241 @@
+// Native executors of ONE TRAINABLE Conformer block (ConformerLayer.forward, A/parts/submodules/conformer_modules.py
+// :141-214, and its autograd): forward = one C call, backward = two C calls around the attention core's backward.
+// The Python autograd node these replace (ops/block.py) issued ~40 + ~70 launches per block through ctypes at ~17 us of
+// host time each -- 4.5 ms of the 12 ms a training step spends on the host -- and allocated every intermediate with
+// torch.empty.  Here the activations the backward needs live in ONE caller-owned arena (ia_block_saved), the backward's
+// temporaries in ONE workspace, parameter gradients are written into ONE arena (ia_block_grads) and added to the
+// parameters' .grad buffers by ONE multi-tensor launch, and the data-gradient contractions dX = dY W run on the bf16
+// MFMA GEMM against transposed weight images made here (no library GEMM left in the block outside the attention core).
+// Host code + two small kernels (bf16 transpose, multi-tensor add); everything else sequences the extern "C" kernels.
+#include <hip/hip_bf16.h>
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "ia_common.h"
+
+namespace {
+
+inline size_t up256(size_t x) { return (x + 255) / 256 * 256; }
+
+#define IA_TRY(call)                  \
+    do {                              \
+        const int rc_ = (call);       \
+        if (rc_ != IA_OK) return rc_; \
+    } while (0)
+
+// out[c][r] = in[r][c] (bf16), 64 x 64 tiles through LDS
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const unsigned short* __restrict__ in, int rows, int cols,
+                                                             unsigned short* __restrict__ out) {
+    __shared__ unsigned short tile[64][66];
+    const int tiles_c = (cols + 63) / 64;
+    const int tr = blockIdx.x / tiles_c, tc = blockIdx.x - tr * tiles_c;
+    const int r0 = tr * 64, c0 = tc * 64;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        tile[r][c] = (r0 + r < rows && c0 + c < cols) ? in[(size_t)(r0 + r) * cols + c0 + c] : (unsigned short)0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int c = i >> 6, r = i & 63;
+        if (r0 + r < rows && c0 + c < cols) out[(size_t)(c0 + c) * rows + r0 + r] = tile[r][c];
+    }
+}
+
+int transpose_bf16(const void* in, int rows, int cols, void* out, hipStream_t st) {
+    const int grid = ((rows + 63) / 64) * ((cols + 63) / 64);
+    hipLaunchKernelGGL(transpose_bf16_kernel, dim3(grid), dim3(256), 0, st, (const unsigned short*)in, rows, cols, (unsigned short*)out);
+    IA_RETURN_IF_LAUNCH_FAILED();
+    return IA_OK;
+}
+
+// dst[k][i] += src[k][i]: one launch for all parameter gradients of a block (table rows: dst, src, n)
+struct AddRow { float* dst; const float* src; int64_t n; };
+__global__ __launch_bounds__(256) void multi_add_kernel(const AddRow* __restrict__ table, int rows) {
+    for (int k = blockIdx.y; k < rows; k += gridDim.y) {
+        const AddRow r = table[k];
+        const int64_t n4 = ((reinterpret_cast<uintptr_t>(r.dst) | reinterpret_cast<uintptr_t>(r.src)) & 15) ? 0 : (r.n >> 2);
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+            float4 a = reinterpret_cast<float4*>(r.dst)[i];
+            const float4 b = reinterpret_cast<const float4*>(r.src)[i];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            reinterpret_cast<float4*>(r.dst)[i] = a;
+        }
+        for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < r.n; i += (int64_t)gridDim.x * 256) r.dst[i] += r.src[i];
+    }
+}
+
+struct BwdWs {   // workspace of the two backward calls (offsets in bytes)
+    size_t dxa, dxb, dB, dh, dhp, dy, dc3, dz, dG, Gm, dc2, dctx, wt, scr, total;
+};
+
+size_t max3(size_t a, size_t b, size_t c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
+
+BwdWs bwd_ws(int B, int T, int d, int d_ff, int ksz) {
+    const size_t N = (size_t)B * T;
+    BwdWs w;
+    size_t o = 0;
+    w.dxa = o;  o = up256(o + N * d * 4);          // residual-stream gradients ping-pong
+    w.dxb = o;  o = up256(o + N * d * 4);
+    w.dB = o;   o = up256(o + N * d * 2);          // gradient entering a branch (bf16)
+    w.dh = o;   o = up256(o + N * d_ff * 2);
+    w.dhp = o;  o = up256(o + N * d_ff * 2);
+    w.dy = o;   o = up256(o + N * d * 2);
+    w.dc3 = o;  o = up256(o + N * d * 2);
+    w.dz = o;   o = up256(o + N * d * 4);
+    w.dG = o;   o = up256(o + N * d * 4);
+    w.Gm = o;   o = up256(o + N * d * 4);
+    w.dc2 = o;  o = up256(o + N * 2 * d * 2);
+    w.dctx = o; o = up256(o + N * d * 2);
+    w.wt = o;   o = up256(o + (size_t)d_ff * d * 2);                                   // one transposed weight image at a time
+    size_t scr = (size_t)ia_layernorm_bwd_scratch_elems((int)N, d);
+    const int shapes[5][2] = {{d, d_ff}, {d_ff, d}, {d, d}, {2 * d, d}, {3 * d, d}};   // (n, k) of every weight gradient
+    for (int i = 0; i < 5; ++i) {
+        const size_t e = (size_t)ia_gemm_tn_scratch_elems((int)N, shapes[i][0], shapes[i][1]);
+        scr = e > scr ? e : scr;
+    }
+    scr = max3(scr, (size_t)ia_bn_silu_bwd_scratch_elems((int64_t)N, d), (size_t)ia_dwconv_scratch_elems(B, T, d, ksz));
+    w.scr = o;  o = up256(o + scr * 4);
+    w.total = o;
+    return w;
+}
+
+// dY [M,n] bf16, X [M,k] bf16, W [n,k] bf16 -> dX [M,k] bf16 (optional: dX == nullptr skips it), dW [n,k] | db [n] f32
+int linear_bwd(const void* dY, const void* X, const void* W, int M, int n, int k, void* dX, float* dW, float* db, void* wt,
+               float* scr, ia_stream_t stream) {
+    if (dX) {   // dX = dY W = dY (W^T)^T : the NT bf16 GEMM against the transposed image
+        IA_TRY(transpose_bf16(W, n, k, wt, (hipStream_t)stream));
+        IA_TRY(ia_gemm_bf16(dY, n, wt, n, M, k, n, nullptr, 0, 0.f, 0, 1.f, nullptr, 0, nullptr, 0, dX, k, stream));
+    }
+    return ia_gemm_tn_bf16(dY, n, X, k, M, n, k, dW, db, scr, stream);
+}
+
+}  // namespace
+
+extern "C" size_t ia_conformer_block_bwd_ws_bytes(int B, int T, int d, int d_ff, int ksz) {
+    if (B <= 0 || T <= 0 || d <= 0 || d_ff <= 0 || ksz <= 0) return 0;
+    return bwd_ws(B, T, d, d_ff, ksz).total;
+}
+
+extern "C" int ia_conformer_block_supported(int d, int d_ff, int H, int ksz, int T) {
+    if (d <= 0 || H <= 0 || d % H != 0) return 0;
+    return (d % 64 == 0 && d <= 1024 && 256 % (d / 4) == 0 && d_ff % 64 == 0 && ksz <= 31 && d / H == 64 && T <= 384) ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+extern "C" int ia_conformer_block_fwd(const ia_block_params* Lp, const float* x0, const void* pos_emb, int pos_rows,
+                                      const int64_t* lens, int B, int T, unsigned seed, const ia_block_saved* Sp, float* out,
+                                      void* vt_scratch, float* dw_scratch, ia_stream_t stream) {
+    if (!Lp || !x0 || !pos_emb || !lens || !Sp || !out || !vt_scratch || !dw_scratch || B <= 0 || T <= 0) return IA_INVALID_VALUE;
+    const ia_block_params& L = *Lp;
+    const ia_block_saved& S = *Sp;
+    const int d = L.d, d_ff = L.d_ff, H = L.n_heads, dk = d / (H > 0 ? H : 1), ksz = L.ksz, N = B * T;
+    if (!ia_conformer_block_supported(d, d_ff, H, ksz, T) || pos_rows < 2 * T - 1) return IA_UNSUPPORTED;
+    const float p = L.p_drop, pff = L.p_ff, patt = L.p_att;
+    // 1/2 feed-forward (pre-activation kept for the backward)
+    IA_TRY(ia_layernorm(x0, d, N, d, L.ln_ff1_g, L.ln_ff1_b, L.ln_eps, nullptr, 0, nullptr, nullptr, S.y1, d, stream));
+    IA_TRY(ia_gemm_bf16(S.y1, d, L.w_ff1a, d, N, d_ff, d, L.b_ff1a, 0, 0.f, 0, 1.f, nullptr, 0, nullptr, 0, S.h1p, d_ff, stream));
+    IA_TRY(ia_silu_dropout(S.h1p, N, d_ff, pff, seed + 1, S.h1, stream));
+    IA_TRY(ia_gemm_bf16(S.h1, d_ff, L.w_ff1b, d_ff, N, d, d_ff, L.b_ff1b, 0, p, seed + 2, L.fc_factor, x0, d, S.x1, d, nullptr, 0, stream));
+    // self-attention
+    IA_TRY(ia_layernorm(S.x1, d, N, d, L.ln_att_g, L.ln_att_b, L.ln_eps, nullptr, 0, nullptr, nullptr, S.y2, d, stream));
+    IA_TRY(ia_gemm_bf16(S.y2, d, L.w_qkv, d, N, 3 * d, d, L.b_qkv, 0, 0.f, 0, 1.f, nullptr, 0, nullptr, 0, S.qkv, 3 * d, stream));
+    IA_TRY(ia_gemm_bf16(pos_emb, d, L.w_pos, d, pos_rows, d, d, nullptr, 0, 0.f, 0, 1.f, nullptr, 0, nullptr, 0, S.pl, d, stream));
+    IA_TRY(ia_relpos_attention(S.qkv, S.pl, L.pos_u, L.pos_v, lens, B, T, H, dk, patt, seed + 7, vt_scratch, S.ctxv, stream));
+    IA_TRY(ia_gemm_bf16(S.ctxv, d, L.w_out, d, N, d, d, L.b_out, 0, p, seed + 3, 1.f, S.x1, d, S.x2, d, nullptr, 0, stream));
+    // convolution module (train-mode BatchNorm: batch statistics, running statistics updated)
+    IA_TRY(ia_layernorm(S.x2, d, N, d, L.ln_conv_g, L.ln_conv_b, L.ln_eps, nullptr, 0, nullptr, nullptr, S.y3, d, stream));
+    IA_TRY(ia_gemm_bf16(S.y3, d, L.w_pw1, d, N, 2 * d, d, L.b_pw1, 0, 0.f, 0, 1.f, nullptr, 0, nullptr, 0, S.c2, 2 * d, stream));
+    IA_TRY(ia_glu_dwconv(S.c2, lens, B, T, d, ksz, L.dw_w, L.dw_b, S.z, S.sums, S.sums + d, dw_scratch, stream));
+    IA_TRY(ia_bn_silu(S.z, N, d, S.sums, S.sums + d, L.bn_g, L.bn_b, L.bn_rm, L.bn_rv, L.bn_nbt, L.bn_momentum, L.bn_eps, 1, S.c3, stream));
+    IA_TRY(ia_gemm_bf16(S.c3, d, L.w_pw2, d, N, d, d, L.b_pw2, 0, p, seed + 4, 1.f, S.x2, d, S.x3, d, nullptr, 0, stream));
+    // 1/2 feed-forward
+    IA_TRY(ia_layernorm(S.x3, d, N, d, L.ln_ff2_g, L.ln_ff2_b, L.ln_eps, nullptr, 0, nullptr, nullptr, S.y4, d, stream));
+    IA_TRY(ia_gemm_bf16(S.y4, d, L.w_ff2a, d, N, d_ff, d, L.b_ff2a, 0, 0.f, 0, 1.f, nullptr, 0, nullptr, 0, S.h4p, d_ff, stream));
+    IA_TRY(ia_silu_dropout(S.h4p, N, d_ff, pff, seed + 5, S.h4, stream));
+    IA_TRY(ia_gemm_bf16(S.h4, d_ff, L.w_ff2b, d_ff, N, d, d_ff, L.b_ff2b, 0, p, seed + 6, L.fc_factor, S.x3, d, S.x4, d, nullptr, 0, stream));
+    return ia_layernorm(S.x4, d, N, d, L.ln_out_g, L.ln_out_b, L.ln_eps, out, d, nullptr, nullptr, nullptr, 0, stream);
+}
+
+// ------------------------------------------------------------------------------------------------ backward, part 1
+// dout [N,d] f32 -> gradients of norm_out, feed_forward2, the convolution module and linear_out; leaves d x2 (the
+// residual-stream gradient in front of the attention branch) and d ctx (gradient of the attention core's output) in the
+// workspace for the caller's attention backward: *dx2_out / *dctx_out point into the workspace.
+extern "C" int ia_conformer_block_bwd_a(const ia_block_params* Lp, const ia_block_saved* Sp, const ia_block_grads* Gp,
+                                        const float* dout, const int64_t* lens, int B, int T, unsigned seed, void* workspace,
+                                        size_t workspace_bytes, float** dx2_out, void** dctx_out, ia_stream_t stream) {
+    if (!Lp || !Sp || !Gp || !dout || !lens || !workspace || !dx2_out || !dctx_out || B <= 0 || T <= 0) return IA_INVALID_VALUE;
+    const ia_block_params& L = *Lp;
+    const ia_block_saved& S = *Sp;
+    const ia_block_grads& G = *Gp;
+    const int d = L.d, d_ff = L.d_ff, ksz = L.ksz, N = B * T;
+    const BwdWs w = bwd_ws(B, T, d, d_ff, ksz);
+    if (workspace_bytes < w.total) return IA_WORKSPACE_TOO_SMALL;
+    char* ws = (char*)workspace;
+    float *dxa = (float*)(ws + w.dxa), *dxb = (float*)(ws + w.dxb), *dz = (float*)(ws + w.dz), *dG = (float*)(ws + w.dG),
+          *Gm = (float*)(ws + w.Gm), *scr = (float*)(ws + w.scr);
+    void *dB = ws + w.dB, *dh = ws + w.dh, *dhp = ws + w.dhp, *dy = ws + w.dy, *dc3 = ws + w.dc3, *dc2 = ws + w.dc2,
+         *dctx = ws + w.dctx, *wt = ws + w.wt;
+    const float p = L.p_drop, pff = L.p_ff;
+    // norm_out: d x4 -> dxa
+    IA_TRY(ia_layernorm_bwd(S.x4, d, dout, nullptr, d, N, d, L.ln_out_g, L.ln_eps, nullptr, dxa, d, G.ln_out_g, G.ln_out_b, scr, stream));
+    // feed_forward2
+    IA_TRY(ia_scale_dropout_bf16(dxa, N, d, L.fc_factor, p, seed + 6, dB, stream));
+    IA_TRY(linear_bwd(dB, S.h4, L.w_ff2b, N, d, d_ff, dh, G.w_ff2b, G.b_ff2b, wt, scr, stream));
+    IA_TRY(ia_silu_dropout_bwd(S.h4p, dh, N, d_ff, pff, seed + 5, dhp, stream));
+    IA_TRY(linear_bwd(dhp, S.y4, L.w_ff2a, N, d_ff, d, dy, G.w_ff2a, G.b_ff2a, wt, scr, stream));
+    IA_TRY(ia_layernorm_bwd(S.x3, d, nullptr, dy, d, N, d, L.ln_ff2_g, L.ln_eps, dxa, dxb, d, G.ln_ff2_g, G.ln_ff2_b, scr, stream));   // d x3 -> dxb
+    // convolution module
+    IA_TRY(ia_scale_dropout_bf16(dxb, N, d, 1.f, p, seed + 4, dB, stream));
+    IA_TRY(linear_bwd(dB, S.c3, L.w_pw2, N, d, d, dc3, G.w_pw2, G.b_pw2, wt, scr, stream));
+    IA_TRY(ia_bn_silu_bwd(S.z, dc3, N, d, S.sums, S.sums + d, L.bn_g, L.bn_b, L.bn_eps, G.bn_b, G.bn_g, dz, scr, stream));
+    IA_TRY(ia_dwconv_time(dz, B, T, d, ksz, L.dw_w, nullptr, 1, dG, stream));
+    IA_TRY(ia_glu_mask(S.c2, lens, B, T, d, Gm, stream));
+    IA_TRY(ia_dwconv_time_wgrad(Gm, dz, B, T, d, ksz, G.dw_w, G.dw_b, scr, stream));
+    IA_TRY(ia_glu_bwd(S.c2, dG, lens, B, T, d, dc2, stream));
+    IA_TRY(linear_bwd(dc2, S.y3, L.w_pw1, N, 2 * d, d, dy, G.w_pw1, G.b_pw1, wt, scr, stream));
+    IA_TRY(ia_layernorm_bwd(S.x2, d, nullptr, dy, d, N, d, L.ln_conv_g, L.ln_eps, dxb, dxa, d, G.ln_conv_g, G.ln_conv_b, scr, stream));  // d x2 -> dxa
+    // linear_out
+    IA_TRY(ia_scale_dropout_bf16(dxa, N, d, 1.f, p, seed + 3, dB, stream));
+    IA_TRY(linear_bwd(dB, S.ctxv, L.w_out, N, d, d, dctx, G.w_out, G.b_out, wt, scr, stream));
+    *dx2_out = dxa;
+    *dctx_out = dctx;
+    return IA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ backward, part 2
+// dqkv [N,3d] bf16 and dpl [pos_rows,d] bf16 (from the attention core's backward) + the workspace of part 1 -> gradients
+// of the q|k|v and position projections, norm_self_att, feed_forward1, norm_feed_forward1 and d x0 [N,d] f32; then ONE
+// launch adds every parameter gradient of the block to its .grad buffer (add_table: n_add rows {dst, src, n} on the device).
+extern "C" int ia_conformer_block_bwd_b(const ia_block_params* Lp, const ia_block_saved* Sp, const ia_block_grads* Gp,
+                                        const float* x0, const void* pos_emb, int pos_rows, const void* dqkv, const void* dpl,
+                                        int B, int T, unsigned seed, void* workspace, size_t workspace_bytes, float* dx0,
+                                        const void* add_table, int n_add, ia_stream_t stream) {
+    if (!Lp || !Sp || !Gp || !x0 || !pos_emb || !dqkv || !dpl || !workspace || !dx0 || B <= 0 || T <= 0) return IA_INVALID_VALUE;
+    const ia_block_params& L = *Lp;
+    const ia_block_saved& S = *Sp;
+    const ia_block_grads& G = *Gp;
+    const int d = L.d, d_ff = L.d_ff, ksz = L.ksz, N = B * T;
+    const BwdWs w = bwd_ws(B, T, d, d_ff, ksz);
+    if (workspace_bytes < w.total) return IA_WORKSPACE_TOO_SMALL;
+    char* ws = (char*)workspace;
+    float *dxa = (float*)(ws + w.dxa), *dxb = (float*)(ws + w.dxb), *scr = (float*)(ws + w.scr);
+    void *dB = ws + w.dB, *dh = ws + w.dh, *dhp = ws + w.dhp, *dy = ws + w.dy, *wt = ws + w.wt;
+    const float p = L.p_drop, pff = L.p_ff;
+    // q|k|v projection (dW rows q, k, v contiguous; bias likewise) and the bias-free position projection
+    IA_TRY(linear_bwd(dqkv, S.y2, L.w_qkv, N, 3 * d, d, dy, G.w_qkv, G.b_qkv, wt, scr, stream));
+    IA_TRY(ia_gemm_tn_bf16(dpl, d, pos_emb, d, pos_rows, d, d, G.w_pos, nullptr, scr, stream));
+    IA_TRY(ia_layernorm_bwd(S.x1, d, nullptr, dy, d, N, d, L.ln_att_g, L.ln_eps, dxa, dxb, d, G.ln_att_g, G.ln_att_b, scr, stream));   // d x1 -> dxb
+    // feed_forward1
+    IA_TRY(ia_scale_dropout_bf16(dxb, N, d, L.fc_factor, p, seed + 2, dB, stream));
+    IA_TRY(linear_bwd(dB, S.h1, L.w_ff1b, N, d, d_ff, dh, G.w_ff1b, G.b_ff1b, wt, scr, stream));
+    IA_TRY(ia_silu_dropout_bwd(S.h1p, dh, N, d_ff, pff, seed + 1, dhp, stream));
+    IA_TRY(linear_bwd(dhp, S.y1, L.w_ff1a, N, d_ff, d, dy, G.w_ff1a, G.b_ff1a, wt, scr, stream));
+    IA_TRY(ia_layernorm_bwd(x0, d, nullptr, dy, d, N, d, L.ln_ff1_g, L.ln_eps, dxb, dx0, d, G.ln_ff1_g, G.ln_ff1_b, scr, stream));
+    if (add_table && n_add > 0) {
+        hipLaunchKernelGGL(multi_add_kernel, dim3(64, n_add < 64 ? n_add : 64), dim3(256), 0, (hipStream_t)stream,
+                           (const AddRow*)add_table, n_add);
+        IA_RETURN_IF_LAUNCH_FAILED();
+    }
+    return IA_OK;
+}

@@ -252,4 +252,197 @@ def pad_pos_emb(pos_emb, d):
 def conformer_block(x2d, layer, lens, pe_bf16, B, T, seed):
     """x2d [B*T, d] f32 residual stream -> [B*T, d] f32 (autograd-connected to x2d and the block's parameters).
     pe_bf16: pad_pos_emb(pos_emb) (>= 2T-1 rows)."""
+    if USE_NATIVE_BLOCKS and layer.training:
+        return conformer_block_native(x2d, layer, lens, pe_bf16, B, T, seed)
     return _ConformerBlockFn.apply(x2d, layer, lens, pe_bf16, B, T, seed, *list(layer.parameters()))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Native executor (csrc/block_train.hip): the same block as ONE C call forward and TWO C calls backward around the
+# attention core's backward.  The node above issued ~40 + ~70 launches per block through ctypes (~17 us of host time
+# each: 4.5 ms of a 12 ms step on the host); here Python only carves two arenas and calls three functions.
+USE_NATIVE_BLOCKS = True
+
+_SAVED_FIELDS = ("y1", "h1p", "h1", "x1", "y2", "qkv", "pl", "ctxv", "x2", "y3", "c2", "z", "sums", "c3", "x3", "y4", "h4p", "h4", "x4")
+
+
+def _saved_layout(N, d, dff, pos_rows):
+    """(field -> (byte offset, bytes)), total bytes: every buffer 256-byte aligned."""
+    sizes = dict(y1=N * d * 2, h1p=N * dff * 2, h1=N * dff * 2, x1=N * d * 4, y2=N * d * 2, qkv=N * 3 * d * 2, pl=pos_rows * d * 2,
+                 ctxv=N * d * 2, x2=N * d * 4, y3=N * d * 2, c2=N * 2 * d * 2, z=N * d * 4, sums=2 * d * 4, c3=N * d * 2,
+                 x3=N * d * 4, y4=N * d * 2, h4p=N * dff * 2, h4=N * dff * 2, x4=N * d * 4)
+    lay, o = {}, 0
+    for f in _SAVED_FIELDS:
+        lay[f] = (o, sizes[f])
+        o = (o + sizes[f] + 255) // 256 * 256
+    return lay, o
+
+
+class _BlockRuntime:
+    """Per-layer persistent state of the native path: gradient arena (f32), the ia_block_grads struct pointing into it and
+    the device table {dst .grad pointer, src arena pointer, n} of the one multi-tensor add that ends the backward."""
+
+    def __init__(self, layer, dev):
+        import ctypes
+        d = layer.norm_out.weight.shape[0]
+        dff = layer.feed_forward1.linear1.weight.shape[0]
+        ksz = layer.conv.depthwise_conv.weight.shape[-1]
+        self.d, self.dff, self.ksz = d, dff, ksz
+        # arena layout: weight | bias pairs contiguous (one finishing pass of the split-K weight-gradient kernel)
+        blocks = [("w_ff1a", dff * d), ("b_ff1a", dff), ("w_ff1b", d * dff), ("b_ff1b", d), ("w_qkv", 3 * d * d), ("b_qkv", 3 * d),
+                  ("w_pos", d * d), ("w_out", d * d), ("b_out", d), ("w_pw1", 2 * d * d), ("b_pw1", 2 * d), ("w_pw2", d * d), ("b_pw2", d),
+                  ("w_ff2a", dff * d), ("b_ff2a", dff), ("w_ff2b", d * dff), ("b_ff2b", d)]
+        for nm in ("ln_ff1", "ln_att", "ln_conv", "ln_ff2", "ln_out"):
+            blocks += [(nm + "_g", d), (nm + "_b", d)]
+        blocks += [("dw_w", d * ksz), ("dw_b", d), ("bn_g", d), ("bn_b", d), ("pos_u", d), ("pos_v", d)]
+        off, o = {}, 0
+        for nm, n in blocks:
+            off[nm] = (o, n)
+            o += (n + 3) // 4 * 4       # keep every block 16-byte aligned
+        self.arena = torch.zeros(o, dtype=torch.float32, device=dev)
+        self.off = off
+        base = self.arena.data_ptr()
+        self.grads = _lib.BlockGrads()
+        for nm, _ in _lib.BlockGrads._fields_:
+            setattr(self.grads, nm, base + 4 * off[nm][0])
+        self.pos_u = self.arena[off["pos_u"][0]:off["pos_u"][0] + d]
+        self.pos_v = self.arena[off["pos_v"][0]:off["pos_v"][0] + d]
+        att, cv, ff1, ff2 = layer.self_attn, layer.conv, layer.feed_forward1, layer.feed_forward2
+        self.param_src = [   # (parameter, arena block, element offset inside the block)
+            (ff1.linear1.weight, "w_ff1a", 0), (ff1.linear1.bias, "b_ff1a", 0), (ff1.linear2.weight, "w_ff1b", 0), (ff1.linear2.bias, "b_ff1b", 0),
+            (att.linear_q.weight, "w_qkv", 0), (att.linear_k.weight, "w_qkv", d * d), (att.linear_v.weight, "w_qkv", 2 * d * d),
+            (att.linear_q.bias, "b_qkv", 0), (att.linear_k.bias, "b_qkv", d), (att.linear_v.bias, "b_qkv", 2 * d),
+            (att.linear_pos.weight, "w_pos", 0), (att.linear_out.weight, "w_out", 0), (att.linear_out.bias, "b_out", 0),
+            (att.pos_bias_u, "pos_u", 0), (att.pos_bias_v, "pos_v", 0),
+            (cv.pointwise_conv1.weight, "w_pw1", 0), (cv.pointwise_conv1.bias, "b_pw1", 0), (cv.pointwise_conv2.weight, "w_pw2", 0),
+            (cv.pointwise_conv2.bias, "b_pw2", 0), (cv.depthwise_conv.weight, "dw_w", 0), (cv.depthwise_conv.bias, "dw_b", 0),
+            (cv.batch_norm.weight, "bn_g", 0), (cv.batch_norm.bias, "bn_b", 0),
+            (ff2.linear1.weight, "w_ff2a", 0), (ff2.linear1.bias, "b_ff2a", 0), (ff2.linear2.weight, "w_ff2b", 0), (ff2.linear2.bias, "b_ff2b", 0),
+            (layer.norm_feed_forward1.weight, "ln_ff1_g", 0), (layer.norm_feed_forward1.bias, "ln_ff1_b", 0),
+            (layer.norm_self_att.weight, "ln_att_g", 0), (layer.norm_self_att.bias, "ln_att_b", 0),
+            (layer.norm_conv.weight, "ln_conv_g", 0), (layer.norm_conv.bias, "ln_conv_b", 0),
+            (layer.norm_feed_forward2.weight, "ln_ff2_g", 0), (layer.norm_feed_forward2.bias, "ln_ff2_b", 0),
+            (layer.norm_out.weight, "ln_out_g", 0), (layer.norm_out.bias, "ln_out_b", 0)]
+        self._table_key, self._table = None, None
+
+    def add_table(self):
+        """Device table of the final multi-tensor add; rebuilt only when a .grad buffer moves."""
+        key = tuple((q.grad.data_ptr() if (q.requires_grad and q.grad is not None) else 0) for q, _, _ in self.param_src)
+        if key != self._table_key:
+            rows = []
+            base = self.arena.data_ptr()
+            for (q, blk, sub), gp in zip(self.param_src, key):
+                if gp:
+                    rows.append((gp, base + 4 * (self.off[blk][0] + sub), q.numel()))
+            self._table = torch.tensor(rows, dtype=torch.int64).to(self.arena.device) if rows else None
+            self._table_key = key
+            self._n_rows = len(rows)
+        return self._table, (self._n_rows if self._table is not None else 0)
+
+
+_RUNTIMES = {}
+_BWD_WS = {}
+
+
+def _runtime(layer, dev):
+    rt = _RUNTIMES.get(id(layer))
+    if rt is None or rt.arena.device != dev:
+        import weakref
+        rt = _RUNTIMES[id(layer)] = _BlockRuntime(layer, dev)
+        weakref.finalize(layer, _RUNTIMES.pop, id(layer), None)
+    return rt
+
+
+class _ConformerBlockNativeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, layer, lens, pe, B, T, seed, *params):
+        import ctypes
+        L = _lib.lib()
+        N, d = x.shape
+        dev = x.device
+        rt = _runtime(layer, dev)
+        tr = layer.training
+        if not tr:
+            raise RuntimeError("trainable fused block expects train-mode BatchNorm (batch statistics)")
+        bp = fast._block_params(layer)
+        x0 = x.contiguous()
+        lay, nbytes = _saved_layout(N, d, rt.dff, pe.shape[0])
+        arena = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        saved = _lib.BlockSaved()
+        base = arena.data_ptr()
+        for f in _SAVED_FIELDS:
+            setattr(saved, f, base + lay[f][0])
+        out = torch.empty(N, d, dtype=torch.float32, device=dev)
+        att = layer.self_attn
+        nvt = L.ia_attn_vt_elems(B, T, att.h)
+        vt = fast._VT.get((dev.index, nvt))
+        if vt is None:
+            vt = fast._VT[(dev.index, nvt)] = torch.empty(nvt, dtype=torch.bfloat16, device=dev)
+        dw_scr = fast.scratch(dev, L.ia_dwconv_scratch_elems(B, T, d, rt.ksz))
+        st = L.ia_conformer_block_fwd(ctypes.addressof(bp), _ptr(x0), _ptr(pe), pe.shape[0], _ptr(lens), B, T, int(seed) & 0xFFFFFFFF,
+                                      ctypes.addressof(saved), _ptr(out), _ptr(vt), _ptr(dw_scr), _lib.stream_ptr())
+        _lib.check(st, "ia_conformer_block_fwd")
+        ctx.keep = (x0, arena, saved, lay, pe, lens, bp)
+        ctx.meta = (layer, B, T, seed, [q.requires_grad for q in params], params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        import ctypes
+        if ctx.keep is None:
+            raise RuntimeError("fused Conformer block: trying to backward through the graph a second time (its saved "
+                               "activations were released by the first backward)")
+        L = _lib.lib()
+        x0, arena, saved, lay, pe, lens, bp = ctx.keep
+        ctx.keep = None
+        layer, B, T, seed, req, params = ctx.meta
+        N, d = x0.shape
+        dev = x0.device
+        rt = _runtime(layer, dev)
+        att = layer.self_attn
+        n_ws = L.ia_conformer_block_bwd_ws_bytes(B, T, d, rt.dff, rt.ksz)
+        key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+        ws = _BWD_WS.get(key)
+        if ws is None or ws.numel() < n_ws:
+            ws = _BWD_WS[key] = torch.empty(n_ws, dtype=torch.uint8, device=dev)
+        dout = dout.float().contiguous()
+        dx2_p, dctx_p = ctypes.c_void_p(), ctypes.c_void_p()
+        sp = _lib.stream_ptr()
+        st = L.ia_conformer_block_bwd_a(ctypes.addressof(bp), ctypes.addressof(saved), ctypes.addressof(rt.grads), _ptr(dout), _ptr(lens), B, T,
+                                        int(seed) & 0xFFFFFFFF, _ptr(ws), n_ws, ctypes.addressof(dx2_p), ctypes.addressof(dctx_p), sp)
+        _lib.check(st, "ia_conformer_block_bwd_a")
+        # attention core: row pass + batched contractions (ops/fast.relpos_attention_bwd) on views of the saved arena / workspace
+        def view(buf, off, shape, dtype):
+            n = 1
+            for s_ in shape:
+                n *= s_
+            return buf[off:off + n * torch.empty(0, dtype=dtype).element_size()].view(dtype).view(*shape)
+        qkv = view(arena, lay["qkv"][0], (N, 3 * d), torch.bfloat16)
+        pl = view(arena, lay["pl"][0], (pe.shape[0], d), torch.bfloat16)
+        ctxv = view(arena, lay["ctxv"][0], (N, d), torch.bfloat16)
+        dctx = view(ws, dctx_p.value - ws.data_ptr(), (N, d), torch.bfloat16)
+        patt = float(att.dropout_rate)
+        dqkv, dpl, du, dv = fast.relpos_attention_bwd(qkv, pl, att.pos_bias_u, att.pos_bias_v, lens, ctxv, dctx, B, T, att.h, att.d_k,
+                                                      patt, seed + 7, dub_out=(rt.pos_u, rt.pos_v))
+        dx0 = torch.empty(N, d, dtype=torch.float32, device=dev)
+        table, n_rows = rt.add_table() if DIRECT_ACCUMULATE else (None, 0)
+        st = L.ia_conformer_block_bwd_b(ctypes.addressof(bp), ctypes.addressof(saved), ctypes.addressof(rt.grads), _ptr(x0), _ptr(pe), pe.shape[0],
+                                        _ptr(dqkv), _ptr(dpl), B, T, int(seed) & 0xFFFFFFFF, _ptr(ws), n_ws, _ptr(dx0), _ptr(table),
+                                        n_rows, sp)
+        _lib.check(st, "ia_conformer_block_bwd_b")
+        outs = []
+        by_id = {id(q): (blk, sub) for q, blk, sub in rt.param_src}
+        for r, q in zip(req, params):
+            if not r:
+                outs.append(None)
+            elif DIRECT_ACCUMULATE and q.grad is not None and q.grad.dtype == torch.float32:
+                outs.append(None)            # added to .grad by the multi-tensor launch of bwd_b
+            else:
+                blk, sub = by_id[id(q)]
+                o = rt.off[blk][0] + sub
+                outs.append(rt.arena[o:o + q.numel()].view(q.shape).clone())
+        return (dx0, None, None, None, None, None, None) + tuple(outs)
+
+
+def conformer_block_native(x2d, layer, lens, pe_bf16, B, T, seed):
+    return _ConformerBlockNativeFn.apply(x2d, layer, lens, pe_bf16, B, T, seed, *list(layer.parameters()))

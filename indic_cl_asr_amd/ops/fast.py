@@ -224,7 +224,7 @@ def attention_bwd_dims(T):
     return ts.value, rs.value, p0.value
 
 
-def relpos_attention_bwd(qkv, pl, bias_u, bias_v, lens, ctx, dctx, B, T, H, dk, dropout_p=0.0, seed=0):
+def relpos_attention_bwd(qkv, pl, bias_u, bias_v, lens, ctx, dctx, B, T, H, dk, dropout_p=0.0, seed=0, dub_out=None):
     """Backward of relpos_attention.  qkv [B*T,3d], pl [>=2T-1, d], ctx/dctx [B*T, d] (bf16) ->
     (dqkv [B*T,3d] bf16, dpl [pl rows, d] bf16, dbias_u [H,dk] f32, dbias_v [H,dk] f32).
     csrc/attention.hip writes dropout(P), dS and the band-skewed dS; the five contractions are batched GEMMs on them."""
@@ -254,7 +254,7 @@ def relpos_attention_bwd(qkv, pl, bias_u, bias_v, lens, ctx, dctx, B, T, H, dk, 
     dQv = torch.bmm(dBand, posB)                                                               # [H,B*T,dk]
     dposB = torch.bmm(dBand.transpose(1, 2), Qv)                                               # [H,Rs,dk]
     dqkv = torch.empty(B * T, 3 * d, dtype=bf, device=dev)
-    dub = torch.empty(2, H, dk, dtype=torch.float32, device=dev)
+    dub = dub_out if dub_out is not None else torch.empty(2, H, dk, dtype=torch.float32, device=dev)   # (dbias_u, dbias_v) destinations
     st = L.ia_attn_bwd_unpack(_lib.ptr(dQu), _lib.ptr(dQv), _lib.ptr(dK), _lib.ptr(dV), _lib.ptr(dqkv), _lib.ptr(dub[0]),
                               _lib.ptr(dub[1]), B, T, H, dk, _lib.ptr(scratch(dev, L.ia_attn_bwd_unpack_scratch_elems(B, T, H))),
                               _lib.stream_ptr())

@@ -1,0 +1,65 @@
+"""csrc/block_train.hip (one trainable Conformer block as one C call forward + two C calls backward) against the per-op
+Python autograd node it replaces (ops/block.py::_ConformerBlockFn): same kernels and dropout masks in the forward (equal
+outputs), bf16 MFMA data-gradient GEMMs on transposed weight images instead of library GEMMs in the backward."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("d,heads,B,T,p", [(128, 2, 4, 96, 0.0), (256, 4, 3, 200, 0.1), (128, 2, 2, 33, 0.5)])
+def test_native_block_matches_python_node(d, heads, B, T, p):
+    from indic_cl_asr_amd.encoder import ConformerLayer
+    from indic_cl_asr_amd.ops import block
+    torch.manual_seed(d + T)
+    layer = ConformerLayer(d, 4 * d, heads, 31, p, p).cuda().train()
+    with torch.no_grad():
+        layer.self_attn.pos_bias_u.normal_(0, 0.2); layer.self_attn.pos_bias_v.normal_(0, 0.2)
+        layer.conv.batch_norm.weight.uniform_(0.5, 1.5); layer.conv.batch_norm.bias.normal_(0, 0.2)
+    lens = torch.tensor([T] + [max(1, T - 7 * (i + 1)) for i in range(B - 1)], device="cuda")
+    x = torch.randn(B * T, d, device="cuda")
+    pe = block.pad_pos_emb(torch.randn(1, 2 * T - 1, d, device="cuda") * 0.5, d)
+    R = torch.randn(B * T, d, device="cuda")
+    res = []
+    for native in (True, False):
+        block.USE_NATIVE_BLOCKS = native
+        try:
+            for q in layer.parameters():
+                q.grad = torch.full_like(q, 0.25)          # the backward ADDS into existing .grad buffers
+            bn = layer.conv.batch_norm
+            rm, rv, nb = bn.running_mean.clone(), bn.running_var.clone(), bn.num_batches_tracked.clone()
+            xg = x.clone().requires_grad_(True)
+            out = block.conformer_block(xg, layer, lens, pe, B, T, 4321)
+            (out * R).sum().backward()
+            res.append((out.detach().clone(), xg.grad.clone(), {n: q.grad.clone() for n, q in layer.named_parameters()},
+                        bn.running_var.clone()))
+            bn.running_mean.copy_(rm); bn.running_var.copy_(rv); bn.num_batches_tracked.copy_(nb)
+        finally:
+            block.USE_NATIVE_BLOCKS = True
+    (o1, dx1, g1, rv1), (o2, dx2, g2, rv2) = res
+    assert (o1 - o2).abs().max().item() <= 1e-5 * max(1.0, o2.abs().max().item())        # same kernels, same masks
+    assert torch.allclose(rv1, rv2, rtol=1e-4, atol=1e-6)
+    def rel(a, b):
+        return ((a - b).norm() / (b.norm() + 1e-12)).item()
+    assert rel(dx1, dx2) < 2e-2, rel(dx1, dx2)
+    for n in g1:
+        a, b = g1[n] - 0.25, g2[n] - 0.25
+        if n.endswith("depthwise_conv.bias") or n.endswith("linear_k.bias"):          # structurally zero gradients: noise
+            assert a.abs().max().item() < 5e-2 * (1 + R.abs().max().item()), n
+            continue
+        assert rel(a, b) < 3e-2, (n, rel(a, b))
+
+
+def test_native_block_refuses_a_second_backward():
+    from indic_cl_asr_amd.encoder import ConformerLayer
+    from indic_cl_asr_amd.ops import block
+    torch.manual_seed(0)
+    layer = ConformerLayer(128, 512, 2, 31, 0.0, 0.0).cuda().train()
+    B, T = 2, 40
+    lens = torch.tensor([40, 30], device="cuda")
+    x = torch.randn(B * T, 128, device="cuda", requires_grad=True)
+    pe = block.pad_pos_emb(torch.randn(1, 2 * T - 1, 128, device="cuda"), 128)
+    out = block.conformer_block(x, layer, lens, pe, B, T, 1).sum()
+    out.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="second time"):
+        out.backward()

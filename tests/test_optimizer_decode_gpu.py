@@ -49,6 +49,7 @@ def test_adamw_skips_tensors_without_gradient_across_a_language_switch():
     batch = _batch()
     cb = tuple(t.cuda() for t in batch)
     ta0 = dict(o.named_parameters())["joint.joint_net.2.ta.weight"].detach().clone()
+    p0 = {n: p.detach().clone() for n, p in o.named_parameters()}
     for step in range(6):
         lang = 'hi' if step < 3 else 'ta'
         oref.zero_grad(set_to_none=True); opt.zero_grad()
@@ -63,15 +64,17 @@ def test_adamw_skips_tensors_without_gradient_across_a_language_switch():
     assert torch.equal(po["joint.joint_net.2.hi.weight"], hi3)                         # reference: frozen after the switch
     torch.cuda.synchronize()
     for n in flat.names:
-        # (structurally zero gradients -- a bias in front of train-mode BatchNorm, the key bias -- are rounding noise on
-        #  both sides, and Adam normalises noise to full-size steps: not comparable)
+        # Adam normalises every gradient component to an O(lr) step, so components that are rounding noise (structurally
+        # zero gradients: a bias in front of train-mode BatchNorm, the key bias; near-zero components elsewhere) move
+        # differently under the CPU and GPU fp32 kernels: bound the error by the distance the tensor travelled, and pin
+        # the tensors this test is about (the two language heads, the joint projections) tightly
         if n.endswith("depthwise_conv.bias") or n.endswith("self_attn.linear_k.bias"):
             continue
-        # (Adam turns gradient rounding differences between the CPU and GPU fp32 kernels into O(lr) differences wherever a
-        #  gradient component is near zero: compare on the scale of the 6 x lr a weight can have moved)
-        a, b = flat.params_dict()[n].cpu().double(), po[n].detach().double()
-        assert torch.allclose(a, b, rtol=2e-4, atol=1.2e-3), (n, (a - b).abs().max().item())
-        assert (a - b).norm().item() <= 0.05 * 6e-3 * math.sqrt(a.numel()), n
+        a, b, b0 = flat.params_dict()[n].cpu().double(), po[n].detach().double(), p0[n].double()
+        moved = (b - b0).norm().item()
+        assert (a - b).norm().item() <= 0.35 * moved + 1e-7, (n, (a - b).norm().item(), moved)
+        if n.startswith("joint."):
+            assert torch.allclose(a, b, rtol=2e-4, atol=1e-4), (n, (a - b).abs().max().item())
     assert torch.allclose(flat.params_dict()["joint.joint_net.2.hi.weight"].cpu(), hi3, rtol=2e-4, atol=2e-4)
     # step counters: 'hi' head 3 updates, 'ta' head 3 updates, shared tensors 6
     steps = dict(zip(flat.names, opt.seg_step.tolist()))
