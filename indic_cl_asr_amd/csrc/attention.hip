@@ -538,8 +538,7 @@ extern "C" int ia_relpos_attention(const void* qkv, const void* pos_proj, const 
     const unsigned thr = (unsigned)(dropout_p * 256.f + 0.5f);
     const float keep_scale = thr > 0 ? 256.f / (256.f - (float)thr) : 1.f;
     const size_t lds = 4 * (size_t)AT_WAVE_LDS;
-    if (hipFuncSetAttribute((const void*)relpos_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return IA_LAUNCH_FAILED;
+    IA_SET_MAX_LDS_ONCE((relpos_attn_kernel), (int)lds);
     const int nqt = (T + 63) / 64;
     hipLaunchKernelGGL(relpos_attn_kernel, dim3(8 * ((B * H + 7) / 8) * nqt), dim3(AT_THREADS), lds, st, (const __bf16*)qkv,
                        (const __bf16*)pos_proj, (const __bf16*)vt_scratch, bias_u, bias_v, lens, (__bf16*)ctx, B, T, H, Tp,
@@ -574,8 +573,7 @@ extern "C" int ia_relpos_attention_bwd(const void* qkv, const void* pos_proj, co
     const unsigned thr = (unsigned)(dropout_p * 256.f + 0.5f);
     const float keep_scale = thr > 0 ? 256.f / (256.f - (float)thr) : 1.f;
     const size_t lds = 4 * (size_t)(16 * AT_LDR + 80) * sizeof(float);
-    if (hipFuncSetAttribute((const void*)relpos_attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return IA_LAUNCH_FAILED;
+    IA_SET_MAX_LDS_ONCE((relpos_attn_bwd_kernel), (int)lds);
     const int nqt = (T + 63) / 64;
     hipLaunchKernelGGL(relpos_attn_bwd_kernel, dim3(B * H * nqt), dim3(AT_THREADS), lds, (hipStream_t)stream, (const __bf16*)qkv,
                        (const __bf16*)pos_proj, bias_u, bias_v, lens, (const __bf16*)ctx, (const __bf16*)dctx, (__bf16*)Pd,

@@ -294,12 +294,10 @@ extern "C" int ia_relpos_attention_flash(const void* qkv, const void* pos_proj, 
     const int grid = 8 * ((B * H + 7) / 8) * nqt;
     hipStream_t st = (hipStream_t)stream;
     if (dk == 64 && (H * dk) % 8 == 0) {
-        if (hipFuncSetAttribute((const void*)relpos_flash_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FA_LDS) != hipSuccess)
-            return IA_LAUNCH_FAILED;
+        IA_SET_MAX_LDS_ONCE((relpos_flash_fwd_kernel<true>), FA_LDS);
         hipLaunchKernelGGL((relpos_flash_fwd_kernel<true>), dim3(grid), dim3(FA_THREADS), FA_LDS, st, a);
     } else {
-        if (hipFuncSetAttribute((const void*)relpos_flash_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FA_LDS) != hipSuccess)
-            return IA_LAUNCH_FAILED;
+        IA_SET_MAX_LDS_ONCE((relpos_flash_fwd_kernel<false>), FA_LDS);
         hipLaunchKernelGGL((relpos_flash_fwd_kernel<false>), dim3(grid), dim3(FA_THREADS), FA_LDS, st, a);
     }
     IA_RETURN_IF_LAUNCH_FAILED();

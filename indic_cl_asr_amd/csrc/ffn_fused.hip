@@ -92,6 +92,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ffn_fused_kernel(FfnArgs a) {
     const int m0 = blockIdx.x * FF_M;
     const int nchunks = a.dff / FF_JC;
     const int total = nchunks * 4;
+    if ((a.mode & 4) && (blockIdx.x & 1)) return;   // diagnostics: half of the workgroups (is the weight stream a per-CU or a chip limit?)
 
     // slot g = 4 c + p.  One LDS-DMA instruction moves 1 KB (lane l -> 16 bytes at position l): W1 half-rows are 256 B
     // (4 rows per instruction, 16-byte slot XOR row & 15), W2 half-rows 128 B (8 rows per instruction, slot XOR (row >> 1) & 7:
@@ -346,8 +347,7 @@ extern "C" int ia_ffn_fused(float* x, int N, int d, int d_ff, const float* ln_g,
     const int LDS = 4 * 32768 + FF_M * FF_JC * 2 + d_ff * 4;   // ring + X + b1 = 151 552 B at d_ff = 1024
     static_assert(FF_M * (256 * 4 + 16) <= 4 * 32768, "epilogue tile aliases the ring");
     { const char* e = getenv("IA_FFN_MODE"); a.mode = (e && *e) ? atoi(e) : 0; }   // diagnostics only
-    if (hipFuncSetAttribute((const void*)ffn_fused_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
-        return IA_LAUNCH_FAILED;
+    IA_SET_MAX_LDS_ONCE((ffn_fused_kernel<256>), LDS);
     hipLaunchKernelGGL((ffn_fused_kernel<256>), dim3((N + FF_M - 1) / FF_M), dim3(FF_THREADS), LDS, (hipStream_t)stream, a);
     IA_RETURN_IF_LAUNCH_FAILED();
     return IA_OK;

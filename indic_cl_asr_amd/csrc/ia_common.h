@@ -16,6 +16,18 @@
         if (hipGetLastError() != hipSuccess) return IA_LAUNCH_FAILED; \
     } while (0)
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) costs several microseconds of host time: issue it once per kernel (and
+// again only if a larger size is ever requested) instead of in front of every launch.  One device per process.
+#define IA_SET_MAX_LDS_ONCE(kernel, bytes)                                                                  \
+    do {                                                                                                    \
+        static int ia_granted_ = -1;                                                                        \
+        if ((int)(bytes) > ia_granted_) {                                                                   \
+            if (hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)) != hipSuccess) \
+                return IA_LAUNCH_FAILED;                                                                    \
+            ia_granted_ = (int)(bytes);                                                                     \
+        }                                                                                                   \
+    } while (0)
+
 static inline size_t ia_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline int ia_is_aligned(const void* p, size_t a) { return ((uintptr_t)p % a) == 0; }
 

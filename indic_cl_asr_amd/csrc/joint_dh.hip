@@ -323,12 +323,10 @@ extern "C" int ia_joint_dh_fused(const void* G, const void* Wt, const void* f, c
     const dim3 grid((unsigned)(B * ntt * a.nh)), blk(256);
     hipStream_t st = (hipStream_t)stream;
     if (a.thr > 0) {
-        if (hipFuncSetAttribute((const void*)joint_dh_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return IA_LAUNCH_FAILED;
+        IA_SET_MAX_LDS_ONCE((joint_dh_fused_kernel<true>), (int)lds);
         hipLaunchKernelGGL((joint_dh_fused_kernel<true>), grid, blk, lds, st, a);
     } else {
-        if (hipFuncSetAttribute((const void*)joint_dh_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return IA_LAUNCH_FAILED;
+        IA_SET_MAX_LDS_ONCE((joint_dh_fused_kernel<false>), (int)lds);
         hipLaunchKernelGGL((joint_dh_fused_kernel<false>), grid, blk, lds, st, a);
     }
     IA_RETURN_IF_LAUNCH_FAILED();

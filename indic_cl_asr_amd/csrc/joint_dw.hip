@@ -360,12 +360,10 @@ extern "C" int ia_joint_dw_fused(const void* G, const void* f, const void* g, in
     const dim3 grid(8 * ((Seff + 7) / 8) * a.ntiles), blk(DW_THREADS);
     const int lds = 2 * DW_STAGE + DW_MAX_U1 * DW_XROW;
     if (a.thr > 0) {
-        if (hipFuncSetAttribute((const void*)joint_dw_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return IA_LAUNCH_FAILED;
+        IA_SET_MAX_LDS_ONCE((joint_dw_fused_kernel<true>), lds);
         hipLaunchKernelGGL((joint_dw_fused_kernel<true>), grid, blk, lds, st, a);
     } else {
-        if (hipFuncSetAttribute((const void*)joint_dw_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return IA_LAUNCH_FAILED;
+        IA_SET_MAX_LDS_ONCE((joint_dw_fused_kernel<false>), lds);
         hipLaunchKernelGGL((joint_dw_fused_kernel<false>), grid, blk, lds, st, a);
     }
     IA_RETURN_IF_LAUNCH_FAILED();

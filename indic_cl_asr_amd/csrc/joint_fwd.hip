@@ -264,10 +264,10 @@ extern "C" int ia_joint_fwd(const void* f, const void* g, const void* W, const f
     const dim3 grid((unsigned)((int64_t)B * ntt * nut)), blk(J_THREADS);
     hipStream_t st = (hipStream_t)stream;
     if (a.thr > 0) {
-        if (hipFuncSetAttribute((const void*)joint_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return IA_LAUNCH_FAILED;
+        IA_SET_MAX_LDS_ONCE((joint_fwd_kernel<true>), (int)lds);
         hipLaunchKernelGGL((joint_fwd_kernel<true>), grid, blk, lds, st, a);
     } else {
-        if (hipFuncSetAttribute((const void*)joint_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return IA_LAUNCH_FAILED;
+        IA_SET_MAX_LDS_ONCE((joint_fwd_kernel<false>), (int)lds);
         hipLaunchKernelGGL((joint_fwd_kernel<false>), grid, blk, lds, st, a);
     }
     IA_RETURN_IF_LAUNCH_FAILED();

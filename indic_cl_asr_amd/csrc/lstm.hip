@@ -271,8 +271,7 @@ extern "C" int ia_lstm_forward(const float* Gx, const void* Whh_bf16, float* Hou
     if (hipMemsetAsync(scratch, 0, 128, st) != hipSuccess) return IA_LAUNCH_FAILED;   // (the sticky word at byte 128 survives)
     const size_t lds = (size_t)(64 + LS_MAXB) * (H * 2 + 16) + 4 * LS_MAXB * 16 * sizeof(float);
     if (lds > 160 * 1024) return IA_UNSUPPORTED;
-    if (hipFuncSetAttribute((const void*)lstm_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return IA_LAUNCH_FAILED;
+    IA_SET_MAX_LDS_ONCE((lstm_fwd_kernel), (int)lds);
     hipLaunchKernelGGL(lstm_fwd_kernel, dim3(H / LS_HB), dim3(LS_THREADS), lds, st, Gx, (const __bf16*)Whh_bf16, Hout, gates, Cs,
                        (__bf16*)((char*)scratch + 256), (unsigned*)scratch, U, B, H, lstm_spin_limit());
     IA_RETURN_IF_LAUNCH_FAILED();
@@ -290,8 +289,7 @@ extern "C" int ia_lstm_backward(const float* dHout, const float* gates, const fl
     if (hipMemsetAsync(scratch, 0, 128, st) != hipSuccess) return IA_LAUNCH_FAILED;
     const size_t lds = (size_t)LS_HB * (4 * H * 2 + 16) + 4 * LS_MAXB * 16 * sizeof(float);
     if (lds > 160 * 1024) return IA_UNSUPPORTED;
-    if (hipFuncSetAttribute((const void*)lstm_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return IA_LAUNCH_FAILED;
+    IA_SET_MAX_LDS_ONCE((lstm_bwd_kernel), (int)lds);
     hipLaunchKernelGGL(lstm_bwd_kernel, dim3(H / LS_HB), dim3(LS_THREADS), lds, st, dHout, gates, Cs, (const __bf16*)WhhT_bf16, dG,
                        (__bf16*)((char*)scratch + 256), (unsigned*)scratch, U, B, H, lstm_spin_limit());
     IA_RETURN_IF_LAUNCH_FAILED();
