@@ -373,6 +373,8 @@ typedef struct ia_block_params {
     int64_t* bn_nbt;
     float ln_eps, bn_eps, bn_momentum, p_drop, p_ff, p_att, fc_factor;
     int d, d_ff, n_heads, ksz;
+    const void* pl_cached;   /* optional: linear_pos(pos_emb) [pos_rows, d] bf16 computed earlier (frozen weights: it only
+                                depends on T) -- the executor then skips that GEMM; NULL: computed per call */
 } ia_block_params;
 size_t ia_conformer_prefix_ws_bytes(int B, int T, int d, int d_ff, int H, int ksz, int pos_rows);
 int ia_conformer_prefix_fwd(const ia_block_params* layers, int n_layers, float* x, const void* pos_emb, int pos_rows,

@@ -27,7 +27,8 @@ class BlockParams(_c.Structure):
         "ln_ff1_g", "ln_ff1_b", "ln_att_g", "ln_att_b", "ln_conv_g", "ln_conv_b", "ln_ff2_g", "ln_ff2_b", "ln_out_g", "ln_out_b",
         "pos_u", "pos_v", "dw_w", "dw_b", "bn_g", "bn_b", "bn_rm", "bn_rv", "bn_nbt")]
         + [(n, _c.c_float) for n in ("ln_eps", "bn_eps", "bn_momentum", "p_drop", "p_ff", "p_att", "fc_factor")]
-        + [(n, _c.c_int) for n in ("d", "d_ff", "n_heads", "ksz")])
+        + [(n, _c.c_int) for n in ("d", "d_ff", "n_heads", "ksz")]
+        + [("pl_cached", _c.c_void_p)])
 
 
 class BlockSaved(_c.Structure):

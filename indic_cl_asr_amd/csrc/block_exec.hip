@@ -88,11 +88,15 @@ extern "C" int ia_conformer_prefix_fwd(const ia_block_params* layers, int n_laye
         // self-attention
         IA_TRY(ia_layernorm(x, d, N, d, L.ln_att_g, L.ln_att_b, L.ln_eps, nullptr, 0, nullptr, nullptr, y, d, stream));
         IA_TRY(ia_gemm_bf16(y, d, L.w_qkv, d, N, 3 * d, d, L.b_qkv, 0, 0.f, 0, 1.f, nullptr, 0, nullptr, 0, qkv, 3 * d, stream));
-        IA_TRY(ia_gemm_bf16(pos_emb, d, L.w_pos, d, pos_rows, d, d, nullptr, 0, 0.f, 0, 1.f, nullptr, 0, nullptr, 0, pl, d, stream));
+        const void* plu = L.pl_cached;   // frozen position projection: computed once per (layer, T) by the caller
+        if (!plu) {
+            IA_TRY(ia_gemm_bf16(pos_emb, d, L.w_pos, d, pos_rows, d, d, nullptr, 0, 0.f, 0, 1.f, nullptr, 0, nullptr, 0, pl, d, stream));
+            plu = pl;
+        }
         if (use_flash)
-            IA_TRY(ia_relpos_attention_flash(qkv, pl, L.pos_u, L.pos_v, lens, B, T, H, dk, patt, seed + 7, ctx, stream));
+            IA_TRY(ia_relpos_attention_flash(qkv, plu, L.pos_u, L.pos_v, lens, B, T, H, dk, patt, seed + 7, ctx, stream));
         else
-            IA_TRY(ia_relpos_attention(qkv, pl, L.pos_u, L.pos_v, lens, B, T, H, dk, patt, seed + 7, vt, ctx, stream));
+            IA_TRY(ia_relpos_attention(qkv, plu, L.pos_u, L.pos_v, lens, B, T, H, dk, patt, seed + 7, vt, ctx, stream));
         IA_TRY(ia_gemm_bf16(ctx, d, L.w_out, d, N, d, d, L.b_out, 0, p, seed + 3, 1.f, x, d, x, d, nullptr, 0, stream));
         // convolution module
         IA_TRY(ia_layernorm(x, d, N, d, L.ln_conv_g, L.ln_conv_b, L.ln_eps, nullptr, 0, nullptr, nullptr, y, d, stream));

@@ -24,7 +24,7 @@ def bump_weight_epoch():
 
 def invalidate_weight_caches():
     """Forget every cached bf16 / concatenated / re-laid-out weight image (after in-place edits through `.data`)."""
-    _SHADOW.clear(); _FLAT16.clear(); _BLOCK_PARAMS.clear()
+    _SHADOW.clear(); _FLAT16.clear(); _BLOCK_PARAMS.clear(); _POS_PROJ.clear()
     bump_weight_epoch()
 
 
@@ -416,12 +416,38 @@ def _block_params(layer):
 
 
 _PREFIX_WS = {}
+_POS_PROJ = {}   # id(layer) -> (weight version key, {pos rows: (pos_emb data_ptr, pl)}, weakrefs)
+
+
+def pos_proj_cached(layer, pos_emb_bf16, max_entries=8):
+    """linear_pos(pos_emb) of a layer whose position projection is frozen: pos_emb is a pure function of T (a centred
+    slice of the sin/cos table), so the projection is computed once per (layer, T) and reused by every later step.
+    None for trainable weights (recomputed per call by the executor)."""
+    w = layer.self_attn.linear_pos.weight
+    if w.requires_grad:
+        return None
+    ver = (w._version, w.data_ptr())
+    hit = _POS_PROJ.get(id(layer))
+    if hit is None or hit[0] != ver or not _same(hit[2], (w,)):
+        hit = _POS_PROJ[id(layer)] = (ver, {}, _refs(_POS_PROJ, id(layer), (w,)))
+    rows = pos_emb_bf16.shape[0]
+    ent = hit[1].get(rows)
+    if ent is None:
+        if len(hit[1]) >= max_entries:
+            hit[1].pop(next(iter(hit[1])))
+        with torch.no_grad():
+            _, pl = gemm(pos_emb_bf16, bf16_shadow(w))
+        ent = hit[1][rows] = pl
+    return ent
 
 
 def conformer_prefix(layers, xr, pos_emb_bf16, lens, B, T, seed_base, seed_stride, training):
     """Run `layers` (ConformerLayer list) over the fp32 residual stream xr [B*T, d] in place with ONE native call."""
     L = _lib.lib()
     arr = (_lib.BlockParams * len(layers))(*[_block_params(l) for l in layers])
+    for i, l in enumerate(layers):   # frozen position projections depend on T only: one GEMM per (layer, T), not per step
+        pl = pos_proj_cached(l, pos_emb_bf16)
+        arr[i].pl_cached = pl.data_ptr() if pl is not None else None
     p0 = arr[0]
     n = L.ia_conformer_prefix_ws_bytes(B, T, p0.d, p0.d_ff, p0.n_heads, p0.ksz, pos_emb_bf16.shape[0])
     key = (xr.device.index, torch.cuda.current_stream(xr.device).cuda_stream)
