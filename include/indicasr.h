@@ -349,12 +349,14 @@ int ia_gemm_tn_bf16(const void* dY, int ldy, const void* X, int ldx, int M, int 
  * Dropout: after the activation a mask of the kernel's own (one cheap 32-bit word per frame and 4 hidden units, keyed by
  * seed_ff: this is the forward of no-autograd passes, nothing has to regenerate it); on the module output the mask of
  * ia_gemm_bf16 for (seed_res, row, column of [N, d]); p = 0 disables.  ln2_g/ln2_b NULL: no second LayerNorm.
- * y_out (optional, [N, d] bf16): a bf16 copy of the result.  Limits: ia_ffn_fused_supported(d, d_ff) (d = 256,
+ * y_out (optional, [N, d] bf16): a bf16 copy of the result.  ln2_to_y_only != 0: x receives the un-normalised residual and
+ * LN2 goes to y_out only (the LayerNorm in front of the NEXT module, e.g. norm_self_att after the first feed-forward).  Limits: ia_ffn_fused_supported(d, d_ff) (d = 256,
  * d_ff % 128 == 0); IA_UNSUPPORTED otherwise. */
 int ia_ffn_fused_supported(int d, int d_ff);
 int ia_ffn_fused(float* x, int N, int d, int d_ff, const float* ln_g, const float* ln_b, float eps, const void* W1,
                  const float* b1, const void* W2, const float* b2, float alpha, float p_ff, unsigned seed_ff, float p_res,
-                 unsigned seed_res, const float* ln2_g, const float* ln2_b, void* y_out, ia_stream_t stream);
+                 unsigned seed_res, const float* ln2_g, const float* ln2_b, void* y_out, int ln2_to_y_only,
+                 ia_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Native executor of the no-autograd Conformer prefix (frozen blocks / teacher / eval): one call enqueues the 14

@@ -79,14 +79,16 @@ extern "C" int ia_conformer_prefix_fwd(const ia_block_params* layers, int n_laye
         const float p = training ? L.p_drop : 0.f, pff = training ? L.p_ff : 0.f, patt = training ? L.p_att : 0.f;
         // 1/2 feed-forward
         if (ffn_fused) {
+            // (... and norm_self_att of the updated residual straight into y: no separate LayerNorm launch)
             IA_TRY(ia_ffn_fused(x, N, d, d_ff, L.ln_ff1_g, L.ln_ff1_b, L.ln_eps, L.w_ff1a, L.b_ff1a, L.w_ff1b, L.b_ff1b, L.fc_factor,
-                                pff, seed + 1, p, seed + 2, nullptr, nullptr, nullptr, stream));
+                                pff, seed + 1, p, seed + 2, L.ln_att_g, L.ln_att_b, y, 1, stream));
         } else {
             IA_TRY(ia_gemm_bf16(y, d, L.w_ff1a, d, N, d_ff, d, L.b_ff1a, 1, pff, seed + 1, 1.f, nullptr, 0, nullptr, 0, h, d_ff, stream));
             IA_TRY(ia_gemm_bf16(h, d_ff, L.w_ff1b, d_ff, N, d, d_ff, L.b_ff1b, 0, p, seed + 2, L.fc_factor, x, d, x, d, nullptr, 0, stream));
         }
         // self-attention
-        IA_TRY(ia_layernorm(x, d, N, d, L.ln_att_g, L.ln_att_b, L.ln_eps, nullptr, 0, nullptr, nullptr, y, d, stream));
+        if (!ffn_fused)
+            IA_TRY(ia_layernorm(x, d, N, d, L.ln_att_g, L.ln_att_b, L.ln_eps, nullptr, 0, nullptr, nullptr, y, d, stream));
         IA_TRY(ia_gemm_bf16(y, d, L.w_qkv, d, N, 3 * d, d, L.b_qkv, 0, 0.f, 0, 1.f, nullptr, 0, nullptr, 0, qkv, 3 * d, stream));
         const void* plu = L.pl_cached;   // frozen position projection: computed once per (layer, T) by the caller
         if (!plu) {
@@ -108,7 +110,7 @@ extern "C" int ia_conformer_prefix_fwd(const ia_block_params* layers, int n_laye
         // 1/2 feed-forward
         if (ffn_fused) {   // ... + norm_out in the same launch (the next block's module applies its own first LayerNorm)
             IA_TRY(ia_ffn_fused(x, N, d, d_ff, L.ln_ff2_g, L.ln_ff2_b, L.ln_eps, L.w_ff2a, L.b_ff2a, L.w_ff2b, L.b_ff2b, L.fc_factor,
-                                pff, seed + 5, p, seed + 6, L.ln_out_g, L.ln_out_b, nullptr, stream));
+                                pff, seed + 5, p, seed + 6, L.ln_out_g, L.ln_out_b, nullptr, 0, stream));
             continue;
         }
         IA_TRY(ia_layernorm(x, d, N, d, L.ln_ff2_g, L.ln_ff2_b, L.ln_eps, nullptr, 0, nullptr, nullptr, y, d, stream));

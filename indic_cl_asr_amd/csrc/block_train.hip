@@ -24,25 +24,33 @@ inline size_t up256(size_t x) { return (x + 255) / 256 * 256; }
         if (rc_ != IA_OK) return rc_; \
     } while (0)
 
-// out[c][r] = in[r][c] (bf16), 64 x 64 tiles through LDS
+// out[c][r] = in[r][c] (bf16), 64 x 64 tiles through LDS, 16-byte global accesses both ways (rows, cols multiples of 8)
 __global__ __launch_bounds__(256) void transpose_bf16_kernel(const unsigned short* __restrict__ in, int rows, int cols,
                                                              unsigned short* __restrict__ out) {
-    __shared__ unsigned short tile[64][66];
+    __shared__ unsigned short tile[64][72];   // 144-byte rows: 16-byte aligned vectors, staggered banks
     const int tiles_c = (cols + 63) / 64;
     const int tr = blockIdx.x / tiles_c, tc = blockIdx.x - tr * tiles_c;
     const int r0 = tr * 64, c0 = tc * 64;
-    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
-        const int r = i >> 6, c = i & 63;
-        tile[r][c] = (r0 + r < rows && c0 + c < cols) ? in[(size_t)(r0 + r) * cols + c0 + c] : (unsigned short)0;
+    for (int i = threadIdx.x; i < 64 * 8; i += 256) {          // 8 vectors of 8 elements per tile row
+        const int r = i >> 3, v = i & 7;
+        uint4 x = make_uint4(0, 0, 0, 0);
+        if (r0 + r < rows && c0 + v * 8 < cols) x = *reinterpret_cast<const uint4*>(in + (size_t)(r0 + r) * cols + c0 + v * 8);
+        *reinterpret_cast<uint4*>(&tile[r][v * 8]) = x;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
-        const int c = i >> 6, r = i & 63;
-        if (r0 + r < rows && c0 + c < cols) out[(size_t)(c0 + c) * rows + r0 + r] = tile[r][c];
+    for (int i = threadIdx.x; i < 64 * 8; i += 256) {          // output row c (a column of the tile), 8 consecutive r
+        const int c = i >> 3, v = i & 7;
+        if (c0 + c < cols && r0 + v * 8 < rows) {
+            union { uint4 u; unsigned short h[8]; } o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o.h[j] = tile[v * 8 + j][c];
+            *reinterpret_cast<uint4*>(out + (size_t)(c0 + c) * rows + r0 + v * 8) = o.u;
+        }
     }
 }
 
 int transpose_bf16(const void* in, int rows, int cols, void* out, hipStream_t st) {
+    if (rows % 8 != 0 || cols % 8 != 0) return IA_UNSUPPORTED;
     const int grid = ((rows + 63) / 64) * ((cols + 63) / 64);
     hipLaunchKernelGGL(transpose_bf16_kernel, dim3(grid), dim3(256), 0, st, (const unsigned short*)in, rows, cols, (unsigned short*)out);
     IA_RETURN_IF_LAUNCH_FAILED();

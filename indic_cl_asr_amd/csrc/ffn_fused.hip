@@ -49,6 +49,7 @@ struct FfnArgs {
     unsigned thr_res, seed_res; float ks_res;  // dropout on the module output
     const float* ln2_g; const float* ln2_b;    // optional LayerNorm of the updated residual (norm_out)
     __bf16* y_out;                             // optional bf16 copy of the result (operand of the next projection)
+    int ln2_y_only;                            // 1: x keeps the un-normalised residual, LN2 goes to y_out only (next module's LayerNorm)
     int mode;                                  // diagnostics (tools/bench_ffn.py): bit 0 = no weight loads in the loop, bit 1 = no MFMAs
 };
 
@@ -308,8 +309,10 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ffn_fused_kernel(FfnArgs a) {
             for (int j = 0; j < 8; ++j) v[j] = v[j] * rstd * gg[j] + bb[j];
         }
         if (live) {
-            *reinterpret_cast<float4*>(a.x + (size_t)gm * D + vec * 8) = make_float4(v[0], v[1], v[2], v[3]);
-            *reinterpret_cast<float4*>(a.x + (size_t)gm * D + vec * 8 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            if (!a.ln2_y_only) {
+                *reinterpret_cast<float4*>(a.x + (size_t)gm * D + vec * 8) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(a.x + (size_t)gm * D + vec * 8 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            }
             if (a.y_out) {
                 union { uint4 u; __bf16 h[8]; } ob;
 #pragma unroll
@@ -327,7 +330,7 @@ extern "C" int ia_ffn_fused_supported(int d, int d_ff) { return (d == 256 && d_f
 extern "C" int ia_ffn_fused(float* x, int N, int d, int d_ff, const float* ln_g, const float* ln_b, float eps, const void* W1,
                             const float* b1, const void* W2, const float* b2, float alpha, float p_ff, unsigned seed_ff,
                             float p_res, unsigned seed_res, const float* ln2_g, const float* ln2_b, void* y_out,
-                            ia_stream_t stream) {
+                            int ln2_to_y_only, ia_stream_t stream) {
     if (!x || !ln_g || !ln_b || !W1 || !b1 || !W2 || !b2 || N <= 0 || (ln2_g && !ln2_b)) return IA_INVALID_VALUE;
     if (!ia_ffn_fused_supported(d, d_ff)) return IA_UNSUPPORTED;
     if (p_ff < 0.f || p_ff >= 1.f || p_res < 0.f || p_res >= 1.f) return IA_INVALID_VALUE;
@@ -342,7 +345,8 @@ extern "C" int ia_ffn_fused(float* x, int N, int d, int d_ff, const float* ln_g,
     a.ks_ff = a.thr_ff > 0 ? 256.f / (256.f - (float)a.thr_ff) : 1.f;
     a.thr_res = (unsigned)(p_res * 256.f + 0.5f); a.seed_res = seed_res;
     a.ks_res = a.thr_res > 0 ? 256.f / (256.f - (float)a.thr_res) : 1.f;
-    a.ln2_g = ln2_g; a.ln2_b = ln2_b; a.y_out = (__bf16*)y_out;
+    if (ln2_to_y_only && (!ln2_g || !y_out)) return IA_INVALID_VALUE;
+    a.ln2_g = ln2_g; a.ln2_b = ln2_b; a.y_out = (__bf16*)y_out; a.ln2_y_only = ln2_to_y_only ? 1 : 0;
     if (d_ff > 2048) return IA_UNSUPPORTED;                    // b1 is kept in LDS
     const int LDS = 4 * 32768 + FF_M * FF_JC * 2 + d_ff * 4;   // ring + X + b1 = 151 552 B at d_ff = 1024
     static_assert(FF_M * (256 * 4 + 16) <= 4 * 32768, "epilogue tile aliases the ring");

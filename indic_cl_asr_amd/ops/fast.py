@@ -139,7 +139,7 @@ def ffn_fused_supported(d, d_ff):
     return USE_FUSED_FFN and bool(_lib.lib().ia_ffn_fused_supported(int(d), int(d_ff)))
 
 
-def ffn_fused(x_f32, ln, lin1, lin2, alpha, p_ff=0.0, seed_ff=0, p_res=0.0, seed_res=0, ln2=None, y_out=None):
+def ffn_fused(x_f32, ln, lin1, lin2, alpha, p_ff=0.0, seed_ff=0, p_res=0.0, seed_res=0, ln2=None, y_out=None, ln2_to_y_only=False):
     """x <- [ln2](x + alpha * dropout(lin2(dropout(SiLU(lin1(ln(x))))))) in place on the fp32 residual stream [N, d]:
     one launch of csrc/ffn_fused.hip (the [N, 4d] intermediate stays in LDS)."""
     N, d = x_f32.shape
@@ -148,7 +148,8 @@ def ffn_fused(x_f32, ln, lin1, lin2, alpha, p_ff=0.0, seed_ff=0, p_res=0.0, seed
                                  _lib.ptr(w1), _lib.ptr(lin1.bias), _lib.ptr(w2), _lib.ptr(lin2.bias), float(alpha), float(p_ff),
                                  int(seed_ff) & 0xFFFFFFFF, float(p_res), int(seed_res) & 0xFFFFFFFF,
                                  _lib.ptr(ln2.weight) if ln2 is not None else None,
-                                 _lib.ptr(ln2.bias) if ln2 is not None else None, _lib.ptr(y_out), _lib.stream_ptr())
+                                 _lib.ptr(ln2.bias) if ln2 is not None else None, _lib.ptr(y_out), int(bool(ln2_to_y_only)),
+                                 _lib.stream_ptr())
     _lib.check(st, "ia_ffn_fused")
     return x_f32
 
