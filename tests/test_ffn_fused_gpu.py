@@ -86,3 +86,18 @@ def test_ffn_fused_inner_dropout_is_unbiased_and_deterministic():
     assert rel < 0.3 * single, (rel, single)       # ~ 1/sqrt(32) of one draw's deviation
     # keep rate: with W2 = I-like probe the fraction of zeroed hidden units is p; cheap proxy: E|d1| / E|base| ~ 1 within noise
     assert 0.8 < (d1.abs().mean() / base.abs().mean()).item() < 1.3
+
+
+def test_ffn_fused_can_emit_the_next_modules_layernorm_without_touching_the_residual():
+    """ln2_to_y_only: x receives the un-normalised residual, y_out = LN2(x) in bf16 (norm_self_att behind the first
+    feed-forward module of a block: saves that LayerNorm launch)."""
+    from indic_cl_asr_amd.ops import fast
+    ln, l1, l2, ln2 = _modules(seed=3)
+    N = 777
+    x = (torch.randn(N, 256, generator=torch.Generator().manual_seed(8)) * 1.1).cuda()
+    ref_x = fast.ffn_fused(x.clone(), ln, l1, l2, 0.5)
+    ref_y = fast.layernorm(ref_x, ln2.weight, ln2.bias, ln2.eps)
+    y = torch.empty(N, 256, dtype=torch.bfloat16, device="cuda")
+    out_x = fast.ffn_fused(x.clone(), ln, l1, l2, 0.5, ln2=ln2, y_out=y, ln2_to_y_only=True)
+    assert torch.equal(out_x, ref_x)
+    assert (y.float() - ref_y.float()).abs().max().item() <= 2e-2 * ref_y.float().abs().max().item()
