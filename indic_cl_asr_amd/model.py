@@ -18,6 +18,7 @@ from .encoder import ConformerEncoder, subsampled_length
 from .features import AudioToMelSpectrogramPreprocessor, SpectrogramAugmentation, mel_frame_count
 from .losses.ctc import CTCLoss
 from .losses.rnnt import RNNTLoss
+from .transcribe import TranscriptionMixin, lookup_host_lengths
 
 
 @dataclass
@@ -40,6 +41,8 @@ class TranscribeConfig:  # :114-127
     augmentor: Optional[dict] = None
     verbose: bool = True
     partial_hypothesis: Optional[List] = None
+    logprobs: bool = False                  # fields of the reference's fork (R/cl_baseline.py:162-170 passes both)
+    language_id: Optional[str] = None
     _internal: Optional[InternalTranscribeConfig] = None
 
 
@@ -113,7 +116,7 @@ class _WerStub(nn.Module):
         self.log_prediction = False
 
 
-class EncDecHybridRNNTCTCModel(nn.Module):
+class EncDecHybridRNNTCTCModel(TranscriptionMixin, nn.Module):
     def __init__(self, cfg: Optional[ModelConfig] = None, **kw):
         super().__init__()
         self.cfg = cfg = cfg or model_config(**kw)
@@ -231,6 +234,13 @@ class EncDecHybridRNNTCTCModel(nn.Module):
         carries NaN otherwise (token-level rates unless `self.detokenize` is set, decoding.py)."""
         signal, signal_len, transcript, transcript_len = batch
         language_ids = lang_ids
+        if host_lengths is None:
+            # batches from model._transcribe_input_processing (the loader the CL scripts use) carry their host-side lengths
+            # in a registry keyed by the device tensors: the reference's own call -- training_step(batch, lang_ids) -- then
+            # runs without a device->host read (which would wait for everything already queued: the previous step)
+            h_sig, h_tgt = lookup_host_lengths(signal_len), lookup_host_lengths(transcript_len)
+            if h_sig is not None and h_tgt is not None and len(h_sig) == signal.shape[0]:
+                host_lengths = (h_sig, h_tgt)
         if host_lengths is None:
             both = torch.stack([signal_len.long(), transcript_len.long()]).tolist()  # one D2H read
             host_lengths = (both[0], both[1])

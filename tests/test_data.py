@@ -10,25 +10,7 @@ import torch
 from indic_cl_asr_amd import data as D
 
 
-def _tone(n, f, sr=16000):
-    return (0.3 * np.sin(2 * np.pi * f * np.arange(n) / sr)).astype(np.float32)
-
-
-@pytest.fixture(scope="module")
-def corpus(tmp_path_factory):
-    import sentencepiece as spm
-    root = tmp_path_factory.mktemp("data")
-    texts = ["namaste duniya", "yah ek pariksha hai", "duniya gol hai", "ek do teen char", "pariksha safal"] * 8
-    (root / "corpus.txt").write_text("\n".join(texts))
-    spm.SentencePieceTrainer.Train(input=str(root / "corpus.txt"), model_prefix=str(root / "hi"), vocab_size=40,
-                                   model_type="unigram", hard_vocab_limit=False, minloglevel=2)
-    files, durs = [], []
-    os.makedirs(root / "train" / "hindi")
-    for i, n in enumerate((16000, 8000, 24000, 12000, 4000)):
-        f = root / "train" / "hindi" / f"u{i}.wav"
-        D.save_wav(str(f), _tone(n, 200 + 50 * i))
-        files.append(str(f)); durs.append(n / 16000)
-    return root, files, texts[:5], durs
+from conftest import _tone  # noqa: E402  (the `corpus` fixture lives in conftest.py: shared with the boundary tests)
 
 
 def test_manifest_and_pkl_formats(corpus, tmp_path):
