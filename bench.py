@@ -158,6 +158,8 @@ def main():
     if args.freeze >= 0:
         freeze_layer(model, args.freeze)
         model.encoder.encoder_frozen_till = args.freeze
+    if world > 1:   # the reference's DDP recipe (R/cl_baseline.py:133): BatchNorm statistics over the global batch
+        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
     model.train()
     flat = cl.FlatParams(model)
     opt = cl.FusedAdamW(flat, lr=1e-4)

@@ -457,6 +457,21 @@ int ia_bn_silu_bwd(const float* z, const void* dc3, int64_t n_rows, int d, const
                    const float* gamma, const float* beta, float eps, float* S1, float* S2, float* dz, float* scratch,
                    ia_stream_t stream);
 int64_t ia_bn_silu_bwd_scratch_elems(int64_t n_rows, int d);
+/* SyncBatchNorm (torch.nn.SyncBatchNorm.convert_sync_batchnorm, R/cl_baseline.py:133; conformer_modules.py:322): the
+ * per-channel sums of ia_glu_dwconv, extended by the rank's row count ([sum(d) | sumsq(d) | count]), are all-reduced by the
+ * caller (torch.distributed / RCCL); ia_bn_sync_finish then updates the running statistics from the GLOBAL batch and
+ * rescales the sums by n_local / count so that ia_bn_silu / ia_bn_silu_bwd (which form mean and rstd as sums / n_local)
+ * see the global statistics.  The backward is split at its own exchange: ia_bn_silu_bwd_reduce leaves the LOCAL S1 | S2
+ * (= d beta | d gamma of this rank), the caller all-reduces a copy and rescales it by n_local / n_global,
+ * ia_bn_silu_bwd_apply forms dz from it.  (ia_bn_silu_bwd = reduce + apply on one rank.) */
+int ia_bn_sync_finish(float* sums_and_count, int d, int64_t n_local_rows, float* running_mean, float* running_var,
+                      int64_t* num_batches_tracked, float momentum, ia_stream_t stream);
+int ia_bn_silu_bwd_reduce(const float* z, const void* dc3, int64_t n_rows, int d, const float* bn_sum, const float* bn_sumsq,
+                          const float* gamma, const float* beta, float eps, float* S1, float* S2, float* scratch,
+                          ia_stream_t stream);
+int ia_bn_silu_bwd_apply(const float* z, const void* dc3, int64_t n_rows, int d, const float* bn_sum, const float* bn_sumsq,
+                         const float* gamma, const float* beta, float eps, const float* S1, const float* S2, float* dz,
+                         ia_stream_t stream);
 int ia_glu_mask(const void* c2, const int64_t* lens, int B, int T, int d, float* G, ia_stream_t stream);
 int ia_glu_bwd(const void* c2, const float* dG, const int64_t* lens, int B, int T, int d, void* dc2, ia_stream_t stream);
 int ia_attn_keepmask(int B, int H, int T, float dropout_p, unsigned seed, void* mask_bf16, ia_stream_t stream);

@@ -119,6 +119,9 @@ SIGNATURES = {
     "ia_scale_dropout_bf16": (_i, [_vp, _i64, _i, _f, _f, _c.c_uint, _vp, _vp]),
     "ia_bn_silu_bwd": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
     "ia_bn_silu_bwd_scratch_elems": (_i64, [_i64, _i]),
+    "ia_bn_sync_finish": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _f, _vp]),
+    "ia_bn_silu_bwd_reduce": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
+    "ia_bn_silu_bwd_apply": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     "ia_glu_mask": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "ia_glu_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "ia_attn_keepmask": (_i, [_i, _i, _i, _f, _c.c_uint, _vp, _vp]),

@@ -377,6 +377,37 @@ extern "C" int ia_bn_silu_bwd(const float* z, const void* dc3, int64_t n_rows, i
     return IA_OK;
 }
 
+// The two halves of ia_bn_silu_bwd as separate entry points (SyncBatchNorm: the per-channel sums S1 | S2 are all-reduced
+// over the ranks -- and rescaled by n_local / n_global -- between them; S1 / S2 of `reduce` are the LOCAL sums = the
+// rank's d beta / d gamma).
+extern "C" int ia_bn_silu_bwd_reduce(const float* z, const void* dc3, int64_t n_rows, int d, const float* bn_sum,
+                                     const float* bn_sumsq, const float* gamma, const float* beta, float eps, float* S1, float* S2,
+                                     float* scratch, ia_stream_t stream) {
+    if (!z || !dc3 || !bn_sum || !bn_sumsq || !gamma || !beta || !S1 || !S2 || !scratch || n_rows <= 1 || d <= 0)
+        return IA_INVALID_VALUE;
+    if (d % 4 != 0 || 256 % (d / 4) != 0) return IA_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int rpb = bnb_rows_per_block(n_rows);
+    const int G = (int)((n_rows + rpb - 1) / rpb);
+    hipLaunchKernelGGL(bn_silu_bwd_reduce_kernel, dim3((unsigned)G), dim3(256), 0, st, z, (const __bf16*)dc3, n_rows, d, bn_sum,
+                       bn_sumsq, gamma, beta, eps, scratch, rpb);
+    IA_RETURN_IF_LAUNCH_FAILED();
+    ia_partials_finish(scratch, G, 2 * d, d, S1, S2, st);
+    IA_RETURN_IF_LAUNCH_FAILED();
+    return IA_OK;
+}
+
+extern "C" int ia_bn_silu_bwd_apply(const float* z, const void* dc3, int64_t n_rows, int d, const float* bn_sum,
+                                    const float* bn_sumsq, const float* gamma, const float* beta, float eps, const float* S1,
+                                    const float* S2, float* dz, ia_stream_t stream) {
+    if (!z || !dc3 || !bn_sum || !bn_sumsq || !gamma || !beta || !S1 || !S2 || !dz || n_rows <= 1 || d <= 0) return IA_INVALID_VALUE;
+    if (d % 4 != 0) return IA_UNSUPPORTED;
+    hipLaunchKernelGGL(bn_silu_bwd_apply_kernel, dim3(ew_grid(n_rows * d / 4)), dim3(256), 0, (hipStream_t)stream, z,
+                       (const __bf16*)dc3, n_rows, d, bn_sum, bn_sumsq, gamma, beta, eps, S1, S2, dz);
+    IA_RETURN_IF_LAUNCH_FAILED();
+    return IA_OK;
+}
+
 extern "C" int ia_glu_mask(const void* c2, const int64_t* lens, int B, int T, int d, float* G, ia_stream_t stream) {
     if (!c2 || !lens || !G || B <= 0 || T <= 0 || d <= 0) return IA_INVALID_VALUE;
     hipLaunchKernelGGL((glu_kernel<0>), dim3(ew_grid((int64_t)B * T * d)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)c2,

@@ -144,6 +144,28 @@ __global__ void bn_running_update_kernel(const float* __restrict__ bn_sum, const
     if (c == 0 && num_batches) num_batches[0] += 1;
 }
 
+// SyncBatchNorm (torch.nn.SyncBatchNorm semantics, R/cl_baseline.py:133): `sums` = [sum(d) | sumsq(d) | count] already
+// all-reduced over the ranks.  Updates the running statistics from the GLOBAL batch (unbiased variance with the global
+// count) and rescales the sums by n_local / count, so that every kernel that derives mean / rstd as sums / n_local
+// (ia_bn_silu, ia_bn_silu_bwd) sees the global statistics without knowing about the other ranks.
+__global__ __launch_bounds__(256) void bn_sync_finish_kernel(float* __restrict__ sums, int d, float n_local,
+                                                             float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                             int64_t* __restrict__ num_batches, float momentum) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const float cnt = sums[2 * d];
+    if (c < d) {
+        const float s1 = sums[c], s2 = sums[d + c];
+        const float mean = s1 / cnt, var = fmaxf(s2 / cnt - mean * mean, 0.f);
+        if (running_mean && running_var) {
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * (cnt / (cnt - 1.f));
+        }
+        const float k = n_local / cnt;
+        sums[c] = s1 * k; sums[d + c] = s2 * k;
+    }
+    if (c == 0 && num_batches) num_batches[0] += 1;
+}
+
 // Column sums of a bf16 [M,N] matrix into fp32 (bias gradients): thread = 8 columns (16-byte loads) x one of 8 row
 // lanes; workgroup = 256 columns x 256 rows; partial sums meet in LDS, one f32 atomic per column per workgroup.
 __global__ __launch_bounds__(256) void colsum_bf16_kernel(const __bf16* __restrict__ x, int M, int N, int ld,
@@ -227,3 +249,12 @@ extern "C" int ia_bn_silu(const float* z, int64_t n_rows, int d, const float* bn
     return IA_OK;
 }
 
+
+extern "C" int ia_bn_sync_finish(float* sums_and_count, int d, int64_t n_local_rows, float* running_mean, float* running_var,
+                                 int64_t* num_batches_tracked, float momentum, ia_stream_t stream) {
+    if (!sums_and_count || d <= 0 || n_local_rows <= 0) return IA_INVALID_VALUE;
+    hipLaunchKernelGGL(bn_sync_finish_kernel, dim3((d + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums_and_count, d,
+                       (float)n_local_rows, running_mean, running_var, num_batches_tracked, momentum);
+    IA_RETURN_IF_LAUNCH_FAILED();
+    return IA_OK;
+}

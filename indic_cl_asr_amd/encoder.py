@@ -159,8 +159,7 @@ class ConformerLayer(nn.Module):
         d = x.shape[-1]
         bn = self.conv.batch_norm
         return (x.is_cuda and not torch.is_grad_enabled() and fast.gemm_supported(d, d) and d % 64 == 0 and d <= 1024
-                and isinstance(bn, nn.BatchNorm1d) and type(bn) is nn.BatchNorm1d
-                and self.conv.depthwise_conv.weight.shape[-1] <= 31)
+                and fast.bn_module_ok(bn) and self.conv.depthwise_conv.weight.shape[-1] <= 31)
 
     def forward_fast(self, x, y, lens, pos_emb, B, T, seed, next_ln=None):
         """x: fp32 residual stream [B*T, d] (updated in place), y: bf16 LN_ff1(x) [B*T, d].  Returns (x_out fp32,
@@ -330,7 +329,11 @@ class ConformerEncoder(nn.Module):
         l0 = self.layers[0]
         bn_ok = all(l.conv.batch_norm.track_running_stats for l in self.layers[:n_fast])
         same_mode = all(l.training == l0.training for l in self.layers[:n_fast])
-        if (fast.attention_flash_supported(T, l0.self_attn.d_k) or fast.attention_supported(T, l0.self_attn.d_k)) and bn_ok and same_mode:
+        # (SyncBatchNorm across more than one rank exchanges the BatchNorm sums between two launches of every block: the
+        #  per-op path below does that; one rank, or plain BatchNorm: the native executor)
+        sync = any(fast.bn_sync_group(l.conv.batch_norm) is not None for l in self.layers[:n_fast])
+        if ((fast.attention_flash_supported(T, l0.self_attn.d_k) or fast.attention_supported(T, l0.self_attn.d_k)) and bn_ok
+                and same_mode and not sync):
             # native executor: one C call enqueues the 14 kernels of every block (csrc/block_exec.hip)
             fast.conformer_prefix(list(self.layers[:n_fast]), xr, pe, length, B, T, base, 16, l0.training)
             return xr.view(B, T, d), n_fast

@@ -81,7 +81,7 @@ DIRECT_ACCUMULATE = True
 def block_supported(layer, x2d, T):
     d = x2d.shape[-1]
     bn = layer.conv.batch_norm
-    return (x2d.is_cuda and d % 64 == 0 and d <= 1024 and type(bn) is torch.nn.BatchNorm1d and 256 % (d // 4) == 0
+    return (x2d.is_cuda and d % 64 == 0 and d <= 1024 and fast.bn_module_ok(bn) and 256 % (d // 4) == 0
             and layer.conv.depthwise_conv.weight.shape[-1] <= 31 and fast.attention_supported(T, layer.self_attn.d_k))
 
 
@@ -121,17 +121,9 @@ class _ConformerBlockFn(torch.autograd.Function):
         y3 = fast.layernorm(x2, layer.norm_conv.weight, layer.norm_conv.bias, layer.norm_conv.eps)
         _, c2 = fast.gemm(y3, W["wp1"], cv.pointwise_conv1.bias)
         bn = cv.batch_norm
-        z = torch.empty(N, d, dtype=torch.float32, device=dev)
-        sums = torch.empty(2, d, dtype=torch.float32, device=dev)
-        ksz = cv.depthwise_conv.weight.shape[-1]
-        dw_scr = fast.scratch(dev, L.ia_dwconv_scratch_elems(B, T, d, ksz))
-        _lib.check(L.ia_glu_dwconv(_ptr(c2), _ptr(lens), B, T, d, ksz, _ptr(cv.depthwise_conv.weight), _ptr(cv.depthwise_conv.bias),
-                                   _ptr(z), _ptr(sums[0]), _ptr(sums[1]), _ptr(dw_scr), _lib.stream_ptr()), "ia_glu_dwconv")
-        c3 = torch.empty(N, d, dtype=torch.bfloat16, device=dev)
         use_batch = bool(tr or not bn.track_running_stats)
-        _lib.check(L.ia_bn_silu(_ptr(z), N, d, _ptr(sums[0]), _ptr(sums[1]), _ptr(bn.weight), _ptr(bn.bias), _ptr(bn.running_mean),
-                                _ptr(bn.running_var), _ptr(bn.num_batches_tracked), float(bn.momentum or 0.1), float(bn.eps),
-                                int(use_batch), _ptr(c3), _lib.stream_ptr()), "ia_bn_silu")
+        c3, z, sums = fast.glu_dwconv_bn_silu_fast(c2, lens, B, T, d, cv.depthwise_conv.weight, cv.depthwise_conv.bias, bn, tr,
+                                                   keep=True)   # (SyncBatchNorm: sums all-reduced inside)
         x3, _ = fast.gemm(c3, W["wp2"], cv.pointwise_conv2.bias, dropout_p=p, seed=seed + 4, residual=x2, out_f32=new(),
                           want_bf16=False)
         # 1/2 FFN
@@ -180,10 +172,26 @@ class _ConformerBlockFn(torch.autograd.Function):
         bn = cv.batch_norm
         S12 = torch.empty(2, d, dtype=torch.float32, device=dev)
         dz = torch.empty(N, d, dtype=torch.float32, device=dev)
-        _lib.check(L.ia_bn_silu_bwd(_ptr(S["z"]), _ptr(dc3), N, d, _ptr(S["sums"][0]), _ptr(S["sums"][1]), _ptr(bn.weight),
-                                    _ptr(bn.bias), float(bn.eps), _ptr(S12[0]), _ptr(S12[1]), _ptr(dz),
-                                    _ptr(fast.scratch(dev, L.ia_bn_silu_bwd_scratch_elems(N, d))), _lib.stream_ptr()),
-                   "ia_bn_silu_bwd")
+        sums = S["sums"]
+        group = fast.bn_sync_group(bn)
+        bn_scr = _ptr(fast.scratch(dev, L.ia_bn_silu_bwd_scratch_elems(N, d)))
+        if group is None:
+            _lib.check(L.ia_bn_silu_bwd(_ptr(S["z"]), _ptr(dc3), N, d, _ptr(sums[:d]), _ptr(sums[d:2 * d]), _ptr(bn.weight),
+                                        _ptr(bn.bias), float(bn.eps), _ptr(S12[0]), _ptr(S12[1]), _ptr(dz), bn_scr,
+                                        _lib.stream_ptr()), "ia_bn_silu_bwd")
+        else:
+            # SyncBatchNorm: the backward's own exchange -- local S1 | S2 are this rank's d beta | d gamma; dz needs the global
+            # sums, brought to the n_local scale the kernels divide by
+            import torch.distributed as dist
+            _lib.check(L.ia_bn_silu_bwd_reduce(_ptr(S["z"]), _ptr(dc3), N, d, _ptr(sums[:d]), _ptr(sums[d:2 * d]), _ptr(bn.weight),
+                                               _ptr(bn.bias), float(bn.eps), _ptr(S12[0]), _ptr(S12[1]), bn_scr,
+                                               _lib.stream_ptr()), "ia_bn_silu_bwd_reduce")
+            Sg = torch.cat([S12.reshape(-1), torch.full((1,), float(N), dtype=torch.float32, device=dev)])
+            dist.all_reduce(Sg, group=group)
+            Sg = Sg[:2 * d] * (float(N) / Sg[2 * d])
+            _lib.check(L.ia_bn_silu_bwd_apply(_ptr(S["z"]), _ptr(dc3), N, d, _ptr(sums[:d]), _ptr(sums[d:2 * d]), _ptr(bn.weight),
+                                              _ptr(bn.bias), float(bn.eps), _ptr(Sg[:d]), _ptr(Sg[d:]), _ptr(dz),
+                                              _lib.stream_ptr()), "ia_bn_silu_bwd_apply")
         G["conv.batch_norm.bias"], G["conv.batch_norm.weight"] = S12[0], S12[1]
         ksz = cv.depthwise_conv.weight.shape[-1]
         w2 = cv.depthwise_conv.weight.detach().float().reshape(d, ksz).contiguous()
@@ -252,7 +260,7 @@ def pad_pos_emb(pos_emb, d):
 def conformer_block(x2d, layer, lens, pe_bf16, B, T, seed):
     """x2d [B*T, d] f32 residual stream -> [B*T, d] f32 (autograd-connected to x2d and the block's parameters).
     pe_bf16: pad_pos_emb(pos_emb) (>= 2T-1 rows)."""
-    if USE_NATIVE_BLOCKS and layer.training:
+    if USE_NATIVE_BLOCKS and layer.training and fast.bn_sync_group(layer.conv.batch_norm) is None:
         return conformer_block_native(x2d, layer, lens, pe_bf16, B, T, seed)
     return _ConformerBlockFn.apply(x2d, layer, lens, pe_bf16, B, T, seed, *list(layer.parameters()))
 

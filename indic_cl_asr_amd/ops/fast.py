@@ -154,24 +154,66 @@ def ffn_fused(x_f32, ln, lin1, lin2, alpha, p_ff=0.0, seed_ff=0, p_res=0.0, seed
     return x_f32
 
 
-def glu_dwconv_bn_silu_fast(x2_bf16, lens, B, T, d, dw_weight, dw_bias, bn, training):
-    """x2 [B*T, 2d] bf16 -> [B*T, d] bf16 : GLU, pad mask, depthwise conv, BatchNorm (batch stats in training), SiLU."""
+def bn_sync_group(bn):
+    """The process group a SyncBatchNorm module exchanges statistics over, or None when no exchange is due: a plain
+    BatchNorm1d, an uninitialised / single-rank torch.distributed, or eval mode (running statistics).
+    (torch.nn.SyncBatchNorm.convert_sync_batchnorm, R/cl_baseline.py:133; conformer_modules.py:322.)"""
+    import torch.distributed as dist
+    if not isinstance(bn, torch.nn.SyncBatchNorm) or not bn.training:
+        return None
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    group = bn.process_group if bn.process_group is not None else dist.group.WORLD
+    return group if dist.get_world_size(group) > 1 else None
+
+
+def bn_module_ok(bn):
+    """BatchNorm modules the HIP paths handle: nn.BatchNorm1d and what convert_sync_batchnorm makes of it."""
+    return type(bn) in (torch.nn.BatchNorm1d, torch.nn.SyncBatchNorm)
+
+
+def bn_sync_sums(sums_cnt, n_local, d, bn, group):
+    """sums_cnt [2d+1] f32 = [sum | sumsq | -]: all-reduce over the ranks with the row count, running statistics from the
+    global batch, sums rescaled so that sums / n_local are the GLOBAL moments (csrc/encoder_ops.hip bn_sync_finish)."""
+    import torch.distributed as dist
+    sums_cnt[2 * d:].fill_(float(n_local))
+    dist.all_reduce(sums_cnt, group=group)
+    track = bn.track_running_stats and bn.running_mean is not None
+    mom = bn.momentum if bn.momentum is not None else 0.1
+    st = _lib.lib().ia_bn_sync_finish(_lib.ptr(sums_cnt), d, n_local, _lib.ptr(bn.running_mean) if track else None,
+                                      _lib.ptr(bn.running_var) if track else None,
+                                      _lib.ptr(bn.num_batches_tracked) if track else None, float(mom), _lib.stream_ptr())
+    _lib.check(st, "ia_bn_sync_finish")
+
+
+def glu_dwconv_bn_silu_fast(x2_bf16, lens, B, T, d, dw_weight, dw_bias, bn, training, keep=False):
+    """x2 [B*T, 2d] bf16 -> [B*T, d] bf16 : GLU, pad mask, depthwise conv, BatchNorm (batch stats in training), SiLU.
+    SyncBatchNorm with more than one rank: the per-channel sums are all-reduced between the two launches.
+    keep=True also returns (z, sums) for a backward."""
     L = _lib.lib()
     dev = x2_bf16.device
     z = torch.empty(B * T, d, dtype=torch.float32, device=dev)
-    sums = torch.empty(2, d, dtype=torch.float32, device=dev)
+    sums = torch.empty(2 * d + 1, dtype=torch.float32, device=dev)
     ksz = dw_weight.shape[-1]
     st = L.ia_glu_dwconv(_lib.ptr(x2_bf16), _lib.ptr(lens), B, T, d, ksz, _lib.ptr(dw_weight), _lib.ptr(dw_bias),
-                         _lib.ptr(z), _lib.ptr(sums[0]), _lib.ptr(sums[1]),
+                         _lib.ptr(z), _lib.ptr(sums[:d]), _lib.ptr(sums[d:2 * d]),
                          _lib.ptr(scratch(dev, L.ia_dwconv_scratch_elems(B, T, d, ksz))), _lib.stream_ptr())
     _lib.check(st, "ia_glu_dwconv")
     out = torch.empty(B * T, d, dtype=torch.bfloat16, device=dev)
     use_batch = bool(training or not bn.track_running_stats)
     mom = bn.momentum if bn.momentum is not None else 0.1
-    st = L.ia_bn_silu(_lib.ptr(z), B * T, d, _lib.ptr(sums[0]), _lib.ptr(sums[1]), _lib.ptr(bn.weight), _lib.ptr(bn.bias),
-                      _lib.ptr(bn.running_mean), _lib.ptr(bn.running_var), _lib.ptr(bn.num_batches_tracked), float(mom),
-                      float(bn.eps), int(use_batch), _lib.ptr(out), _lib.stream_ptr())
+    group = bn_sync_group(bn) if use_batch else None
+    if group is not None:
+        bn_sync_sums(sums, B * T, d, bn, group)     # (running statistics updated there, from the global batch)
+        rm = rv = nbt = None
+    else:
+        rm, rv, nbt = bn.running_mean, bn.running_var, bn.num_batches_tracked
+    st = L.ia_bn_silu(_lib.ptr(z), B * T, d, _lib.ptr(sums[:d]), _lib.ptr(sums[d:2 * d]), _lib.ptr(bn.weight), _lib.ptr(bn.bias),
+                      _lib.ptr(rm), _lib.ptr(rv), _lib.ptr(nbt), float(mom), float(bn.eps), int(use_batch), _lib.ptr(out),
+                      _lib.stream_ptr())
     _lib.check(st, "ia_bn_silu")
+    if keep:
+        return out, z, sums
     return out
 
 

@@ -90,3 +90,92 @@ def test_deferred_update_matches_immediate_update_two_ranks():
         assert r[1], ("deferred != immediate", r)
         assert r[2], ("ranks diverged", r)
         assert r[3], ("weights did not move", r)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# SyncBatchNorm (torch.nn.SyncBatchNorm.convert_sync_batchnorm, R/cl_baseline.py:133) on the HIP encoder paths: two ranks,
+# each with HALF of a batch, must reproduce the single-process encoder on the UNION batch (plain BatchNorm) -- outputs of
+# the frozen prefix and of the trainable blocks, the blocks' input / parameter gradients (summed over the ranks), and the
+# running statistics.
+def _sync_setup():
+    from indic_cl_asr_amd.config import model_config
+    from indic_cl_asr_amd.model import EncDecHybridRNNTCTCModel, freeze_layer
+    torch.manual_seed(0)
+    cfg = model_config('tiny', d_model=128, n_layers=3, n_heads=2, pred_hidden=64, joint_hidden=64, languages=['hi', 'ta'],
+                       vocab_per_lang=16, fused_batch_size=2, compute_dtype='bf16', dither=0.0)
+    m = EncDecHybridRNNTCTCModel(cfg).disable_dropout().cuda().train()
+    with torch.no_grad():
+        for l in m.encoder.layers:
+            l.conv.batch_norm.weight.uniform_(0.5, 1.5); l.conv.batch_norm.bias.normal_(0, 0.2)
+    m.spec_augment_enabled = False
+    freeze_layer(m, 0); m.encoder.encoder_frozen_till = 1       # layer 0 in the no-grad prefix, layers 1..2 trainable
+    g = torch.Generator().manual_seed(5)
+    L = 16000
+    sig = torch.randn(4, L, generator=g) * 0.1
+    sl = torch.tensor([L, 12000, L, 9000])
+    for i in range(4):
+        sig[i, sl[i]:] = 0
+    R = torch.randn(4, 128, 101, generator=g)
+    return m, sig, sl, R
+
+
+def _encoder_pass(m, sig, sl, R):
+    enc, elen = m(input_signal=sig.cuda(), input_signal_length=sl.cuda())
+    T = enc.shape[2]
+    valid = (torch.arange(T, device="cuda")[None, :] < elen[:, None]).unsqueeze(1)
+    (enc.float() * R[:, :, :T].cuda() * valid).sum().backward()
+    grads = {n: p.grad.detach().float().clone() for n, p in m.named_parameters() if p.grad is not None and n.startswith("encoder.")}
+    bn = m.encoder.layers[0].conv.batch_norm, m.encoder.layers[2].conv.batch_norm
+    return enc.detach().float(), elen, grads, [b.running_var.clone() for b in bn], [int(b.num_batches_tracked) for b in bn]
+
+
+def _sync_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m, sig, sl, R = _sync_setup()
+    m = torch.nn.SyncBatchNorm.convert_sync_batchnorm(m)
+    assert isinstance(m.encoder.layers[0].conv.batch_norm, torch.nn.SyncBatchNorm)
+    half = slice(2 * rank, 2 * rank + 2)
+    enc, elen, grads, rvs, nbt = _encoder_pass(m, sig[half], sl[half], R[half])
+    names = sorted(grads)
+    flat = torch.cat([grads[n].reshape(-1) for n in names])
+    dist.all_reduce(flat)                                      # parameter gradients: sum over the ranks
+    q.put((rank, enc.cpu(), elen.cpu(), names, flat.cpu(), [v.cpu() for v in rvs], nbt))
+    dist.destroy_process_group()
+
+
+def test_sync_batchnorm_two_ranks_equal_single_process_union_batch():
+    m, sig, sl, R = _sync_setup()
+    enc1, elen1, grads1, rvs1, nbt1 = _encoder_pass(m, sig, sl, R)
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_sync_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in ps], key=lambda r: r[0])
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    enc2 = torch.cat([res[0][1], res[1][1]], 0)
+    T = enc1.shape[2]
+    valid = (torch.arange(T)[None, :] < elen1.cpu()[:, None]).unsqueeze(1)
+    scale = (enc1.cpu() * valid).abs().max().item()
+    assert torch.equal(torch.cat([res[0][2], res[1][2]]), elen1.cpu())
+    assert ((enc2 - enc1.cpu()) * valid).abs().max().item() <= 2e-2 * scale      # per-rank BatchNorm would be off by O(1)
+    names, flat2 = res[0][3], res[0][4]
+    flat1 = torch.cat([grads1[n].reshape(-1) for n in names]).cpu()
+    off = 0
+    for n in names:
+        k = grads1[n].numel()
+        a, b = flat2[off:off + k], flat1[off:off + k]
+        off += k
+        if n.endswith("depthwise_conv.bias") or n.endswith("linear_k.bias"):
+            continue
+        rel = ((a - b).norm() / (b.norm() + 1e-12)).item()
+        assert rel < 5e-2, (n, rel)
+    for r in res:                                              # running statistics: the GLOBAL batch on every rank
+        for v2, v1 in zip(r[5], rvs1):
+            assert torch.allclose(v2, v1.cpu(), rtol=2e-2, atol=1e-4)
+        assert r[6] == nbt1
