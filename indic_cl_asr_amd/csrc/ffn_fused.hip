@@ -292,6 +292,10 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ffn_fused_kernel(FfnArgs a) {
         const float rr[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = v[j] * sc + rr[j];
+        if (a.ln2_y_only && live) {   // the residual stream itself is stored before the (next module's) LayerNorm
+            *reinterpret_cast<float4*>(a.x + (size_t)gm * D + vec * 8) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(a.x + (size_t)gm * D + vec * 8 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
         if (a.ln2_g) {
             float s = 0.f;
 #pragma unroll

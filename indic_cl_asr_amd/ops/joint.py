@@ -14,6 +14,7 @@ from .. import _lib
 JOINT_MAX_V = 272
 # csrc/joint_dh.hip fuses the dH GEMM with its mask and reductions (1.4 ms against 1.4 + 0.6 ms for the library GEMM +
 # ia_joint_dh_reduce at bs32 x 15 s); False selects the unfused path (also the fallback for H % 80 != 0).
+MFMA_PROFILE_HOOK = None   # bench.py: callable(flops) -> (start, stop) torch events recorded around the hidden-gradient kernel
 USE_FUSED_DH = True
 # csrc/joint_dw.hip regenerates the hidden tile in LDS and contracts it with G row-major (transposing LDS reads): no
 # hidden^T tensor, no transposed copy of G.  False selects hidden^T + the batched split-K library GEMM.
@@ -114,10 +115,15 @@ class _FusedJointRNNT(torch.autograd.Function):
             Wt = torch.zeros(H, L.ia_joint_dh_k(), dtype=torch.float16, device=dev)
             Wt[:, :JOINT_MAX_V] = Wp.t()
             scr = torch.empty(L.ia_joint_dh_fused_scratch_bytes(B, T, U1, H), dtype=torch.uint8, device=dev)
+            ev = MFMA_PROFILE_HOOK(2.0 * cells * H * LD) if MFMA_PROFILE_HOOK is not None else None   # bench.py: torch events
+            if ev is not None:
+                ev[0].record()
             st = L.ia_joint_dh_fused(_lib.ptr(G), _lib.ptr(Wt), _lib.ptr(f16), _lib.ptr(g16), _lib.ptr(act_lens),
                                      _lib.ptr(label_lens), _lib.ptr(df), _lib.ptr(dg), B, T, U1, H, LD, 1.0 / kappa, p, seed,
                                      _lib.ptr(scr), _lib.stream_ptr())
             _lib.check(st, "ia_joint_dh_fused")
+            if ev is not None:
+                ev[1].record()
         else:
             dH = torch.mm(G, Wp[:LD])  # [cells, H] f16 (plain library GEMM)
             scr = torch.empty(L.ia_joint_dh_reduce_scratch_bytes(B, T, U1, H), dtype=torch.uint8, device=dev)

@@ -141,7 +141,8 @@ def _sync_worker(rank, world, port, q):
     names = sorted(grads)
     flat = torch.cat([grads[n].reshape(-1) for n in names])
     dist.all_reduce(flat)                                      # parameter gradients: sum over the ranks
-    q.put((rank, enc.cpu(), elen.cpu(), names, flat.cpu(), [v.cpu() for v in rvs], nbt))
+    # (numpy arrays are pickled by value: torch tensors travel as shared-memory handles that die with this process)
+    q.put((rank, enc.cpu().numpy(), elen.cpu().numpy(), names, flat.cpu().numpy(), [v.cpu().numpy() for v in rvs], nbt))
     dist.destroy_process_group()
 
 
@@ -158,6 +159,8 @@ def test_sync_batchnorm_two_ranks_equal_single_process_union_batch():
     for p in ps:
         p.join(60)
         assert p.exitcode == 0
+    res = [(r[0], torch.from_numpy(r[1]), torch.from_numpy(r[2]), r[3], torch.from_numpy(r[4]), [torch.from_numpy(v) for v in r[5]], r[6])
+           for r in res]
     enc2 = torch.cat([res[0][1], res[1][1]], 0)
     T = enc1.shape[2]
     valid = (torch.arange(T)[None, :] < elen1.cpu()[:, None]).unsqueeze(1)
