@@ -84,18 +84,22 @@ __global__ __launch_bounds__(G_THREADS, (BM == 128 ? 3 : 4)) void gemm_bf16_nt_k
         }
     }
     uint4 ra0, ra1, ra2 = make_uint4(0, 0, 0, 0), ra3 = make_uint4(0, 0, 0, 0), rb0, rb1, rb2, rb3;
+    // 16-byte vector at column k_ of a K-contiguous row; columns >= K read as zero (K % 8 == 0: d_model = 144 -> K = 144 is two
+    // 64-wide k-tiles and a 16-wide tail).  The address is clamped, the select applied to the value: no branch around the load.
+#define G_LDK(rowp_, k_) ([&]() { const int kk_ = (k_); const uint4 v_ = *reinterpret_cast<const uint4*>((rowp_) + (kk_ < a.K ? kk_ : 0)); \
+                                  return kk_ < a.K ? v_ : make_uint4(0, 0, 0, 0); }())
 #define G_LOAD(k0_) \
     do { \
-        { const int idx_ = tid + 0 * G_THREADS, kv_ = idx_ & 7; if constexpr (CONV) { ra0 = conv_a_load(a, crow[0], (k0_), kv_); } else { const int row_ = idx_ >> 3; const int gr_ = (m0 + row_ < a.M) ? (m0 + row_) : (a.M - 1); ra0 = *reinterpret_cast<const uint4*>(a.A + (size_t)gr_ * a.lda + (k0_) + kv_ * 8); } } \
-        { const int idx_ = tid + 1 * G_THREADS, kv_ = idx_ & 7; if constexpr (CONV) { ra1 = conv_a_load(a, crow[1], (k0_), kv_); } else { const int row_ = idx_ >> 3; const int gr_ = (m0 + row_ < a.M) ? (m0 + row_) : (a.M - 1); ra1 = *reinterpret_cast<const uint4*>(a.A + (size_t)gr_ * a.lda + (k0_) + kv_ * 8); } } \
+        { const int idx_ = tid + 0 * G_THREADS, kv_ = idx_ & 7; if constexpr (CONV) { ra0 = conv_a_load(a, crow[0], (k0_), kv_); } else { const int row_ = idx_ >> 3; const int gr_ = (m0 + row_ < a.M) ? (m0 + row_) : (a.M - 1); ra0 = G_LDK(a.A + (size_t)gr_ * a.lda, (k0_) + kv_ * 8); } } \
+        { const int idx_ = tid + 1 * G_THREADS, kv_ = idx_ & 7; if constexpr (CONV) { ra1 = conv_a_load(a, crow[1], (k0_), kv_); } else { const int row_ = idx_ >> 3; const int gr_ = (m0 + row_ < a.M) ? (m0 + row_) : (a.M - 1); ra1 = G_LDK(a.A + (size_t)gr_ * a.lda, (k0_) + kv_ * 8); } } \
         if constexpr (AV == 4) { \
-        { const int idx_ = tid + 2 * G_THREADS, kv_ = idx_ & 7; if constexpr (CONV) { ra2 = conv_a_load(a, crow[2], (k0_), kv_); } else { const int row_ = idx_ >> 3; const int gr_ = (m0 + row_ < a.M) ? (m0 + row_) : (a.M - 1); ra2 = *reinterpret_cast<const uint4*>(a.A + (size_t)gr_ * a.lda + (k0_) + kv_ * 8); } } \
-        { const int idx_ = tid + 3 * G_THREADS, kv_ = idx_ & 7; if constexpr (CONV) { ra3 = conv_a_load(a, crow[3], (k0_), kv_); } else { const int row_ = idx_ >> 3; const int gr_ = (m0 + row_ < a.M) ? (m0 + row_) : (a.M - 1); ra3 = *reinterpret_cast<const uint4*>(a.A + (size_t)gr_ * a.lda + (k0_) + kv_ * 8); } } \
+        { const int idx_ = tid + 2 * G_THREADS, kv_ = idx_ & 7; if constexpr (CONV) { ra2 = conv_a_load(a, crow[2], (k0_), kv_); } else { const int row_ = idx_ >> 3; const int gr_ = (m0 + row_ < a.M) ? (m0 + row_) : (a.M - 1); ra2 = G_LDK(a.A + (size_t)gr_ * a.lda, (k0_) + kv_ * 8); } } \
+        { const int idx_ = tid + 3 * G_THREADS, kv_ = idx_ & 7; if constexpr (CONV) { ra3 = conv_a_load(a, crow[3], (k0_), kv_); } else { const int row_ = idx_ >> 3; const int gr_ = (m0 + row_ < a.M) ? (m0 + row_) : (a.M - 1); ra3 = G_LDK(a.A + (size_t)gr_ * a.lda, (k0_) + kv_ * 8); } } \
         } \
-        { const int idx_ = tid + 0 * G_THREADS, row_ = idx_ >> 3, kv_ = idx_ & 7; const int gr_ = (n0 + row_ < a.N) ? (n0 + row_) : (a.N - 1); rb0 = *reinterpret_cast<const uint4*>(a.W + (size_t)gr_ * a.ldw + (k0_) + kv_ * 8); } \
-        { const int idx_ = tid + 1 * G_THREADS, row_ = idx_ >> 3, kv_ = idx_ & 7; const int gr_ = (n0 + row_ < a.N) ? (n0 + row_) : (a.N - 1); rb1 = *reinterpret_cast<const uint4*>(a.W + (size_t)gr_ * a.ldw + (k0_) + kv_ * 8); } \
-        { const int idx_ = tid + 2 * G_THREADS, row_ = idx_ >> 3, kv_ = idx_ & 7; const int gr_ = (n0 + row_ < a.N) ? (n0 + row_) : (a.N - 1); rb2 = *reinterpret_cast<const uint4*>(a.W + (size_t)gr_ * a.ldw + (k0_) + kv_ * 8); } \
-        { const int idx_ = tid + 3 * G_THREADS, row_ = idx_ >> 3, kv_ = idx_ & 7; const int gr_ = (n0 + row_ < a.N) ? (n0 + row_) : (a.N - 1); rb3 = *reinterpret_cast<const uint4*>(a.W + (size_t)gr_ * a.ldw + (k0_) + kv_ * 8); } \
+        { const int idx_ = tid + 0 * G_THREADS, row_ = idx_ >> 3, kv_ = idx_ & 7; const int gr_ = (n0 + row_ < a.N) ? (n0 + row_) : (a.N - 1); rb0 = G_LDK(a.W + (size_t)gr_ * a.ldw, (k0_) + kv_ * 8); } \
+        { const int idx_ = tid + 1 * G_THREADS, row_ = idx_ >> 3, kv_ = idx_ & 7; const int gr_ = (n0 + row_ < a.N) ? (n0 + row_) : (a.N - 1); rb1 = G_LDK(a.W + (size_t)gr_ * a.ldw, (k0_) + kv_ * 8); } \
+        { const int idx_ = tid + 2 * G_THREADS, row_ = idx_ >> 3, kv_ = idx_ & 7; const int gr_ = (n0 + row_ < a.N) ? (n0 + row_) : (a.N - 1); rb2 = G_LDK(a.W + (size_t)gr_ * a.ldw, (k0_) + kv_ * 8); } \
+        { const int idx_ = tid + 3 * G_THREADS, row_ = idx_ >> 3, kv_ = idx_ & 7; const int gr_ = (n0 + row_ < a.N) ? (n0 + row_) : (a.N - 1); rb3 = G_LDK(a.W + (size_t)gr_ * a.ldw, (k0_) + kv_ * 8); } \
     } while (0)
 #define G_STORE(buf_) \
     do { \
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(G_THREADS, (BM == 128 ? 3 : 4)) void gemm_bf16_nt_k
 #pragma unroll
         for (int j = 0; j < TJ; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = a.K / G_BK;
+    const int nk = (a.K + G_BK - 1) / G_BK;
     G_LOAD(0);
     G_STORE(0);
     __syncthreads();
@@ -233,7 +237,7 @@ extern "C" int ia_gemm_bf16(const void* A, int lda, const void* W, int ldw, int 
                             int act, float dropout_p, unsigned seed, float alpha, const float* R, int ldr, float* outF,
                             int ldof, void* outH, int ldoh, ia_stream_t stream) {
     if (!A || !W || (!outF && !outH) || M <= 0 || N <= 0 || K <= 0) return IA_INVALID_VALUE;
-    if (K % G_BK != 0 || N % 8 != 0 || lda % 8 != 0 || ldw % 8 != 0) return IA_UNSUPPORTED;
+    if (K % 8 != 0 || N % 8 != 0 || lda % 8 != 0 || ldw % 8 != 0) return IA_UNSUPPORTED;
     if ((R && ldr % 4 != 0) || (outF && ldof % 4 != 0) || (outH && ldoh % 8 != 0)) return IA_UNSUPPORTED;
     if (!ia_is_aligned(A, 16) || !ia_is_aligned(W, 16) || (bias && !ia_is_aligned(bias, 16)) || (R && !ia_is_aligned(R, 16)) ||
         (outF && !ia_is_aligned(outF, 16)) || (outH && !ia_is_aligned(outH, 16)))

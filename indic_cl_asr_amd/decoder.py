@@ -315,7 +315,7 @@ class ConvASRDecoder(nn.Module):
             elif len(set(language_ids)) == 1:
                 rows = self._rows(language_ids[0], x.device)
                 w_sel, b_sel = w.index_select(0, rows), b.index_select(0, rows)
-                if self.cfg.compute_dtype == "bf16" and x.is_cuda and x.shape[-1] % 64 == 0:
+                if self.cfg.compute_dtype == "bf16" and x.is_cuda and x.shape[-1] % 8 == 0:
                     out = _CtcHeadHip.apply(x, w_sel, b_sel)
                 else:
                     out = F.linear(x, w_sel, b_sel)

@@ -158,7 +158,7 @@ class ConformerLayer(nn.Module):
         from .ops import fast
         d = x.shape[-1]
         bn = self.conv.batch_norm
-        return (x.is_cuda and not torch.is_grad_enabled() and fast.gemm_supported(d, d) and d % 64 == 0 and d <= 1024
+        return (x.is_cuda and not torch.is_grad_enabled() and fast.gemm_supported(d, d) and d % 8 == 0 and d <= 1024
                 and fast.bn_module_ok(bn) and self.conv.depthwise_conv.weight.shape[-1] <= 31)
 
     def forward_fast(self, x, y, lens, pos_emb, B, T, seed, next_ln=None):

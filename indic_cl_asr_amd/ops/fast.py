@@ -103,7 +103,9 @@ def scratch(dev, n):
 
 
 def gemm_supported(K, N):
-    return K % 64 == 0 and N % 8 == 0
+    """ia_gemm_bf16 shapes: rows of 16-byte vectors (K, N multiples of 8); K need not be a multiple of the 64-wide k-tile
+    (d_model = 144: the tail of the last tile reads as zero)."""
+    return K % 8 == 0 and N % 8 == 0
 
 
 def gemm(a_bf16, w_bf16, bias=None, act=0, dropout_p=0.0, seed=0, alpha=1.0, residual=None, out_f32=None,

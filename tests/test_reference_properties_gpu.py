@@ -30,13 +30,13 @@ def _model(compute_dtype, **kw):
 
 
 @pytest.mark.parametrize("compute_dtype,d_model,n_heads,tol", [("bf16", 128, 2, 1e-6), ("bf16", 256, 4, 1e-6),
-                                                             ("bf16", 144, 4, 5e-3), ("fp32", 32, 4, 2e-5)])
+                                                             ("bf16", 144, 4, 1e-6), ("fp32", 32, 4, 2e-5)])
 def test_forward_batch_of_4_equals_4_batches_of_1(compute_dtype, d_model, n_heads, tol):
     """test_forward of the reference (eval mode, dither 0, pad_to 0): every utterance's encoder output is independent
     of what else is in the batch.  The reference asserts <= 1e-6 on fp32 log-probs; the HIP bf16 path computes every
     output row with the same instruction sequence whatever the batch, so it meets the same bound (observed: equal).
-    d = 144 is not on the HIP kernels yet: its library GEMMs pick tile shapes by batch size (observed 3e-3 mean), and
-    the fp32 mode's library GEMMs likewise differ in summation order."""
+    (d = 144: head dim 36 and K = 144 GEMM tails on the HIP kernels; its ATen subsampling convolutions and the fp32 mode's
+    library GEMMs pick algorithms by batch size, hence the looser bound there.)"""
     m = _model(compute_dtype, d_model=d_model, n_heads=n_heads).eval()
     g = torch.Generator().manual_seed(1)
     sig = torch.randn(4, 24000, generator=g).cuda()

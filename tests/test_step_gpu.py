@@ -284,14 +284,17 @@ def test_fused_joint_step_matches_unfused_and_oracle():
         assert (a - b).abs().max().item() <= 0.03 * b.abs().max().item() + 1e-6, n
 
 
-def test_fast_encoder_prefix_matches_aten_path_and_oracle():
-    """The fused no-autograd encoder path (HIP GEMM+epilogues, LayerNorm, GLU/dwconv/BN kernels) against the ATen
-    composition on the same bf16 model, and against the fp32 oracle (train-mode BatchNorm, dropout off)."""
+@pytest.mark.parametrize("d_model,n_heads", [(128, 2), (144, 4), (256, 4)])
+def test_fast_encoder_prefix_matches_aten_path_and_oracle(d_model, n_heads):
+    """The fused no-autograd encoder path (HIP GEMM+epilogues, LayerNorm, GLU/dwconv/BN kernels, rel-pos attention; at
+    d = 256 the row-resident feed-forward kernel) against the ATen composition on the same bf16 model, and against the
+    fp32 oracle (train-mode BatchNorm, dropout off).  d = 144 / 4 heads (head dim 36, K = 144 GEMM tails) is BASELINE
+    configs[0]'s encoder width."""
     from indic_cl_asr_amd.config import model_config
     from indic_cl_asr_amd.model import EncDecHybridRNNTCTCModel
     torch.manual_seed(0)
-    kw = dict(d_model=128, n_layers=3, n_heads=2, pred_hidden=64, joint_hidden=64, languages=['hi', 'ta'],
-              vocab_per_lang=16, fused_batch_size=2)   # head dim 64: exercises the HIP rel-pos attention kernel
+    kw = dict(d_model=d_model, n_layers=3, n_heads=n_heads, pred_hidden=64, joint_hidden=64, languages=['hi', 'ta'],
+              vocab_per_lang=16, fused_batch_size=2)
     o = S.OracleHybridModel(**kw)
     with torch.no_grad():
         for l in o.encoder.layers:
