@@ -114,6 +114,31 @@ int ia_joint_fwd(const void* f, const void* g, const void* W, const float* bias,
                  const int64_t* act_lens, const int64_t* label_lens, int B, int T, int U1, int H, int V, int blank,
                  float dropout_p, unsigned seed, void* logits, int LD, void* workspace, size_t workspace_bytes,
                  ia_stream_t stream);
+/* ia_joint_fwd_box: the same, but the logits of every cell with t < box_t[b], u < box_u[b] are kept (box >= the valid
+ * lattice; NULL, NULL = ia_joint_fwd): the MAS / LwF terms of the CL scripts read the whole narrowed sub-batch tensors
+ * the reference stashes (A/modules/rnnt.py:1463-1496), padded cells included.
+ *
+ * Continual-learning terms on the f16 lattice (csrc/joint_extra.hip), per-utterance weights w_sq / w_kd [B] f32:
+ *   ia_joint_extra_reduce  sums4[0] = sum_b w_sq[b] sum_{box_b, v<V} z^2       (MAS importance, cl_baseline_mas.py:258-265)
+ *                          sums4[1] = sum_b w_kd[b] sum_{box_b, v<V} e^t (t-z)  (LwF: F.kl_div(z, exp(t)), cl_baseline_lwf.py:242-257)
+ *                          sums4[2] = max |z|, sums4[3] = max t (the host sizes the f16 gradient scale from them)
+ *                          teacher = NULL skips the second; scratch: f32 x ia_joint_extra_scratch_elems().
+ *   ia_joint_extra_grad    E [cells, LD] f16 = upstream2[0]*w_sq*2z - upstream2[1]*w_kd*e^t inside the box, 0 elsewhere
+ *                          (upstream2: 2 device floats, already multiplied by the gradient scale kappa of the lattice)
+ *   ia_lattice_add_f16     G += E (n f16 elements, n % 8 == 0): folded into the transducer gradient before the joint's
+ *                          backward kernels, which are then given the box extents as lengths. */
+int ia_joint_fwd_box(const void* f, const void* g, const void* W, const float* bias, const int64_t* labels,
+                     const int64_t* act_lens, const int64_t* label_lens, const int64_t* box_t, const int64_t* box_u, int B,
+                     int T, int U1, int H, int V, int blank, float dropout_p, unsigned seed, void* logits, int LD,
+                     void* workspace, size_t workspace_bytes, ia_stream_t stream);
+int64_t ia_joint_extra_scratch_elems(void);
+int ia_joint_extra_reduce(const void* logits, const void* teacher, const int64_t* box_t, const int64_t* box_u,
+                          const float* w_sq, const float* w_kd, int B, int T, int U1, int V, int LD, float* sums4,
+                          float* scratch, ia_stream_t stream);
+int ia_joint_extra_grad(const void* logits, const void* teacher, const int64_t* box_t, const int64_t* box_u, const float* w_sq,
+                        const float* w_kd, const float* upstream2, int B, int T, int U1, int V, int LD, void* E,
+                        ia_stream_t stream);
+int ia_lattice_add_f16(void* G, const void* E, int64_t n, ia_stream_t stream);
 int ia_rnnt_lattice(const int64_t* act_lens, const int64_t* label_lens, int B, int T, int U1, float fastemit_lambda,
                     int need_backward, float* costs, void* workspace, size_t workspace_bytes, ia_stream_t stream);
 int ia_joint_backward_g(void* logits_inout, const int64_t* labels, const int64_t* act_lens, const int64_t* label_lens,

@@ -55,6 +55,11 @@ SIGNATURES = {
     "ia_rnnt_export_alphas_betas": (_i, [_vp, _sz, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "ia_joint_ld": (_i, [_i]),
     "ia_joint_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _c.c_uint, _vp, _i, _vp, _sz, _vp]),
+    "ia_joint_fwd_box": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _c.c_uint, _vp, _i, _vp, _sz, _vp]),
+    "ia_joint_extra_scratch_elems": (_i64, []),
+    "ia_joint_extra_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "ia_joint_extra_grad": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "ia_lattice_add_f16": (_i, [_vp, _vp, _i64, _vp]),
     "ia_rnnt_lattice": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _sz, _vp]),
     "ia_joint_backward_g": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _f, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp,
                                  _vp]),

@@ -237,11 +237,15 @@ def penalty(model, main_importance: FlatDict, prev_params: FlatDict):
 def mas_importance_loss(model, mas_ctx: float):
     """R/cl_baseline_mas.py:258-265 on the stashed raw logits (joint.store_list, ctc_decoder.decoder_logits)."""
     m = getattr(model, "module", model)
+    from .ops.joint import LatticeStash, lattice_sumsq_term
     decoder_logits = (m.ctc_decoder.decoder_logits.flatten(end_dim=-2).float() ** 2).sum(dim=-1).mean()
-    rnn_logits = 0
-    for i in m.joint.store_list:
-        rnn_logits = rnn_logits + (i.flatten(end_dim=-2).float() ** 2).sum(dim=-1).mean()
-    rnn_logits = rnn_logits / len(m.joint.store_list)
+    if isinstance(m.joint.store_list, LatticeStash):   # fused joint: one streaming pass over the f16 lattice
+        rnn_logits = lattice_sumsq_term(m.joint.store_list)
+    else:
+        rnn_logits = 0
+        for i in m.joint.store_list:
+            rnn_logits = rnn_logits + (i.flatten(end_dim=-2).float() ** 2).sum(dim=-1).mean()
+        rnn_logits = rnn_logits / len(m.joint.store_list)
     return rnn_logits * (1 - mas_ctx) + decoder_logits * mas_ctx
 
 
@@ -268,10 +272,18 @@ def lwf_kd_loss(loss, prob, prob_, pred_store_list, store_list, knowledge_distil
     # fp32 arithmetic whatever the stash dtype (the bf16 path stashes bf16 lattices; kl_div evaluated in bf16 rounds
     # log(exp(i)) - j, a difference of nearly equal numbers, to 8 bits: observed 4.5 % off the fp32 value)
     ctc_kd_loss = F.kl_div(prob.float(), prob_.float().exp(), reduction='batchmean')
-    rnnt_kd = 0
-    for i, j in zip(store_list, pred_store_list):
-        rnnt_kd = rnnt_kd + F.kl_div(j.float(), i.float().exp(), reduction='batchmean')
-    rnnt_kd = rnnt_kd / len(store_list)
+    from .ops.joint import LatticeStash, lattice_kd_term
+    if isinstance(store_list, LatticeStash) and isinstance(pred_store_list, LatticeStash):
+        rnnt_kd = lattice_kd_term(pred_store_list, store_list)   # fused joint: both lattices stay f16 in HBM, two streaming passes
+    else:
+        if isinstance(store_list, LatticeStash) or isinstance(pred_store_list, LatticeStash):
+            raise ValueError("lwf_kd_loss: one of the two stashes is a fused-joint lattice and the other a list of tensors; "
+                             "run the teacher and the student passes on the same joint path (joint.use_fused)")
+        assert len(store_list) == len(pred_store_list)
+        rnnt_kd = 0
+        for i, j in zip(store_list, pred_store_list):
+            rnnt_kd = rnnt_kd + F.kl_div(j.float(), i.float().exp(), reduction='batchmean')
+        rnnt_kd = rnnt_kd / len(store_list)
     total = loss * (1 - knowledge_distillation) + knowledge_distillation * ((1 - kd_ctx) * rnnt_kd + kd_ctx * ctc_kd_loss)
     return total, rnnt_kd, ctc_kd_loss
 

@@ -32,6 +32,8 @@ struct JointFwdArgs {
     const int64_t* labels;   // [B,U1-1]
     const int64_t* act_lens; // [B]
     const int64_t* label_lens;
+    const int64_t* box_t;    // optional [B]: logits are stored for every cell with t < box_t[b], u < box_u[b] (>= the valid
+    const int64_t* box_u;    //   lattice): the continual-learning terms read whole sub-batch boxes (joint_extra.hip)
     _Float16* logits;        // [B*T*U1, LD]
     float* denom; float* PB; float* PL; float* PLa;
     int B, T, U1, H, V, LD, blank, rows, U1s;
@@ -56,7 +58,8 @@ __global__ __launch_bounds__(J_THREADS, 1) void joint_fwd_kernel(JointFwdArgs a)
     const int b = bid / ntt;
     const int t0 = tt * JT, u0 = ut * JU;
     const int Tb = (int)a.act_lens[b], Ub = (int)a.label_lens[b] + 1;
-    if (t0 >= Tb || u0 >= Ub) return;  // whole tile outside this utterance's lattice (wave-uniform)
+    const int Tx = a.box_t ? (int)a.box_t[b] : Tb, Ux = a.box_u ? (int)a.box_u[b] : Ub;   // cells whose logits are kept
+    if (t0 >= Tx || u0 >= Ux) return;  // whole tile outside this utterance's box (wave-uniform)
 
     // ---- stage f and g tiles (zero rows past T / U1)
     {
@@ -196,19 +199,19 @@ __global__ __launch_bounds__(J_THREADS, 1) void joint_fwd_kernel(JointFwdArgs a)
             *reinterpret_cast<uint2*>(sT + c * LDT + (16 * n + 4 * q) * 2) = w2.u;
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS writes landed (scratch is wave-private)
-        if (t < Tb) {
+        if (t < Tx) {
             // coalesced row stores: 16 rows x (LD*2/16) vectors
             const int vec_per_row = a.LD / 8;
             for (int i = lane; i < 16 * vec_per_row; i += 64) {
                 const int r = i / vec_per_row, v = i - r * vec_per_row;
                 const int u = u0 + r;
-                if (u < Ub) {
+                if (u < Ux) {
                     const uint4 val = *reinterpret_cast<const uint4*>(sT + r * LDT + v * 16);
                     reinterpret_cast<uint4*>(a.logits + (((size_t)b * a.T + t) * a.U1 + u) * a.LD)[v] = val;
                 }
             }
-            // per-row scalars: lanes q == 0 own row c
-            if (q == 0) {
+            // per-row scalars (valid lattice cells only): lanes q == 0 own row c
+            if (q == 0 && t < Tb) {
                 const int ul = c, u = u0 + ul;
                 if (u < Ub) {
                     const float dn = -m - 0.69314718055994531f * __builtin_amdgcn_logf(sum);
@@ -236,6 +239,15 @@ extern "C" int ia_joint_fwd(const void* f, const void* g, const void* W, const f
                             const int64_t* act_lens, const int64_t* label_lens, int B, int T, int U1, int H, int V,
                             int blank, float dropout_p, unsigned seed, void* logits, int LD, void* workspace,
                             size_t workspace_bytes, ia_stream_t stream) {
+    return ia_joint_fwd_box(f, g, W, bias, labels, act_lens, label_lens, nullptr, nullptr, B, T, U1, H, V, blank, dropout_p, seed,
+                            logits, LD, workspace, workspace_bytes, stream);
+}
+
+extern "C" int ia_joint_fwd_box(const void* f, const void* g, const void* W, const float* bias, const int64_t* labels,
+                                const int64_t* act_lens, const int64_t* label_lens, const int64_t* box_t, const int64_t* box_u,
+                                int B, int T, int U1, int H, int V, int blank, float dropout_p, unsigned seed, void* logits,
+                                int LD, void* workspace, size_t workspace_bytes, ia_stream_t stream) {
+    if ((box_t == nullptr) != (box_u == nullptr)) return IA_INVALID_VALUE;
     if (!f || !g || !W || !bias || !act_lens || !label_lens || !logits || !workspace) return IA_INVALID_VALUE;
     if (B <= 0 || T <= 0 || U1 <= 0 || V < 1 || blank < 0 || blank >= V) return IA_INVALID_VALUE;
     if (U1 > 1 && !labels) return IA_INVALID_VALUE;
@@ -252,6 +264,7 @@ extern "C" int ia_joint_fwd(const void* f, const void* g, const void* W, const f
     JointFwdArgs a;
     a.f = (const _Float16*)f; a.g = (const _Float16*)g; a.W = (const _Float16*)W; a.bias = bias; a.labels = labels;
     a.act_lens = act_lens; a.label_lens = label_lens; a.logits = (_Float16*)logits;
+    a.box_t = box_t; a.box_u = box_u;
     a.denom = (float*)(ws + w.off_denom); a.PB = (float*)(ws + w.off_pb); a.PL = (float*)(ws + w.off_pl);
     a.PLa = (float*)(ws + w.off_pla);
     a.B = B; a.T = T; a.U1 = U1; a.H = H; a.V = V; a.LD = LD; a.blank = blank; a.rows = w.rows; a.U1s = w.U1s;

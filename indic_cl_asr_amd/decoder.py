@@ -167,9 +167,9 @@ class RNNTJoint(nn.Module):
             host_lengths = (encoder_lengths.tolist(), transcript_lengths.tolist())
         h_enc, h_tgt = host_lengths
         B = int(enc.size(0))
-        if self._fused_eligible(enc, language_ids):
+        if self._fused_eligible(enc, language_ids, max(h_tgt) + 1):
             return self._forward_fused(enc, dec, encoder_lengths, transcripts, transcript_lengths, language_ids,
-                                       max(h_enc), max(h_tgt)), None, None, None
+                                       h_enc, h_tgt), None, None, None
         amp = (torch.autocast(device_type="cuda", dtype=torch.bfloat16)
                if self.cfg.compute_dtype == "bf16" and enc.is_cuda else nullcontext())
         losses, target_lengths, stash = [], [], []
@@ -201,15 +201,29 @@ class RNNTJoint(nn.Module):
 
 
     # ------------------------------------------------------------------ fused path
-    def _fused_eligible(self, enc, language_ids):
+    def _fused_eligible(self, enc, language_ids, U1):
+        from . import _lib
         from .ops.joint import fused_joint_supported
         lk = self._loss._loss
-        return (self.use_fused and self.cfg.compute_dtype == "bf16" and not (self.store_sub_enc or self.store_sub_logits)
-                and language_ids is not None and len(set(language_ids)) == 1 and lk.clamp <= 0.0
-                and fused_joint_supported(self.cfg.joint_hidden, self.cfg.vocab_per_lang + 1, enc.device))
+        H, V = self.cfg.joint_hidden, self.cfg.vocab_per_lang + 1
+        ok = (self.use_fused and self.cfg.compute_dtype == "bf16"
+              and language_ids is not None and len(set(language_ids)) == 1 and lk.clamp <= 0.0
+              and fused_joint_supported(H, V, enc.device))
+        if ok and (self.store_sub_enc or self.store_sub_logits):
+            # the stash of the MAS / LwF passes stays on the lattice (ops.joint.LatticeStash); its terms' gradient needs the
+            # fused hidden- and weight-gradient kernels
+            L = _lib.lib()
+            LD = L.ia_joint_ld(V)
+            ok = bool(L.ia_joint_dh_fused_supported(U1, H, LD) and L.ia_joint_dw_fused_supported(U1, H, LD))
+        return ok
 
-    def _forward_fused(self, enc, dec, encoder_lengths, transcripts, transcript_lengths, language_ids, max_t, max_u):
+    def _forward_fused(self, enc, dec, encoder_lengths, transcripts, transcript_lengths, language_ids, h_enc, h_tgt):
         from .ops.joint import fused_joint_rnnt
+        max_t, max_u = max(h_enc), max(h_tgt)
+        req = None
+        if self.store_sub_enc or self.store_sub_logits:
+            req = {"sub": self._fused_batch_size, "h_enc": h_enc, "h_tgt": h_tgt,
+                   "detach": bool(self.detach_sub_enc) or not torch.is_grad_enabled()}
         head = self.joint_net[-1][language_ids[0]]
         p = 0.0
         for m in self.joint_net[:-1]:
@@ -225,7 +239,9 @@ class RNNTJoint(nn.Module):
         costs = fused_joint_rnnt(f, g, head.weight, head.bias, transcripts[:, :max_u].contiguous().long(),
                                  encoder_lengths.long(), transcript_lengths.long(), lk.blank, dropout_p=p,
                                  seed=self.dropout_seed, fastemit_lambda=lk.fastemit_lambda,
-                                 scale_hint=self.loss_scale_hint)
+                                 scale_hint=self.loss_scale_hint, stash_req=req)
+        if req is not None:
+            self.store_list = req["out"]
         return self._loss.reduce([costs], [transcript_lengths])
 
 

@@ -34,11 +34,162 @@ def _kappa_for(scale_hint):
     return float(2.0 ** math.floor(-math.log2(s))) if s > 0 else 1.0
 
 
+# ------------------------------------------------------------------------------------------------------------------------
+# The sub-batch logits stash of the CL scripts (joint.store_list, A/modules/rnnt.py:1463-1496) on the fused path.
+class _RangeTracker:
+    """max |z| / max t of the lattices the extra terms were evaluated on, read back without stalling the host: each
+    reduction leaves its maxima in a pinned buffer behind an event; the gradient scale of a backward is sized from the
+    newest reading that has ARRIVED (the very first one is waited for).  A reading that is one step old is fine: the
+    scale is a power of two with 2^10 of headroom below f16's largest number."""
+
+    def __init__(self):
+        self.last = None       # (zmax, tmax) host floats
+        self.pending = []      # [(pinned [4] f32, event)]
+
+    def push(self, sums4):
+        host = torch.empty(4, dtype=torch.float32, pin_memory=True)
+        host.copy_(sums4.detach(), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.pending.append((host, ev))
+        del self.pending[:-4]
+
+    def read(self):
+        newest = None
+        for host, ev in reversed(self.pending):
+            if ev.query():
+                newest = host
+                break
+        if newest is None and self.last is None and self.pending:
+            newest, ev = self.pending[-1]
+            ev.synchronize()
+        if newest is not None:
+            self.last = (float(newest[2]), float(newest[3]))
+        return self.last
+
+
+_RANGES = {}
+
+
+class LatticeStash:
+    """What `joint.store_list` holds after a fused forward with store_sub_enc / store_sub_logits set: the whole batch's raw
+    logits as ONE f16 lattice [B*T*U1, LD] (the buffer the loss read -- no clones) plus, per utterance, the extent of
+    the sub-batch box the reference would have stashed it in.  len() = number of sub-batches; iterating materialises the
+    reference's per-sub-batch tensors [b, max_t, max_u+1, V] (debugging / third-party code: detached copies).
+    cl.mas_importance_loss / cl.lwf_kd_loss evaluate their terms on the lattice itself (csrc/joint_extra.hip)."""
+
+    def __init__(self, logits, geom, boxes, weights, n_sub, sub_size, token, detached):
+        self.logits = logits                  # [cells, LD] f16; None once the joint's backward has consumed it
+        self.B, self.T, self.U1, self.V, self.LD = geom
+        self.box_t, self.box_u, self.box_um1 = boxes          # device int64 [B]
+        self.w_sq, self.w_kd = weights                        # device f32 [B]
+        self.n_sub, self.sub_size = n_sub, sub_size
+        self.token = token                    # autograd handle of the lattice (None when detached / no_grad)
+        self.detached = detached
+        self.pending_E = None                 # kappa * d(extra terms)/d logits, f16, accumulated by the terms' backward
+        self.kappa = None
+        self.scale_hint = 1.0                 # |d loss / d cost_b| the transducer part of the gradient is expected to carry
+        self.host_boxes = None                # (box_t, box_u) host lists
+        self.host_weights = (0.0, 0.0)        # (max w_sq, max w_kd)
+
+    def __len__(self):
+        return self.n_sub
+
+    def _live(self):
+        if self.logits is None:
+            raise RuntimeError("joint.store_list: this lattice was overwritten by the joint's backward (the fused path keeps "
+                               "one f16 lattice per forward and turns it into its gradient in place); evaluate "
+                               "mas_importance_loss / lwf_kd_loss before calling backward")
+        return self.logits
+
+    def __iter__(self):
+        z = self._live().view(self.B, self.T, self.U1, self.LD)
+        bt, bu = self.host_boxes
+        for b0 in range(0, self.B, self.sub_size):
+            yield z[b0:b0 + self.sub_size, :bt[b0], :bu[b0], :self.V].detach().clone()
+
+    def same_geometry(self, other):
+        return (self.B, self.T, self.U1, self.V, self.LD, self.n_sub) == (other.B, other.T, other.U1, other.V, other.LD, other.n_sub)
+
+
+class _LatticeTerm(torch.autograd.Function):
+    """One weighted reduction over a stash (kind 0: sum of squares, kind 1: KL against a teacher lattice).  Its backward
+    does not return a gradient tensor for the lattice (that would be a second lattice-sized round trip): it leaves
+    kappa * d term / d logits in stash.pending_E, which the joint's backward -- ordered after this node by `token` --
+    adds to the transducer gradient before its MFMA kernels run."""
+
+    @staticmethod
+    def forward(ctx, token, stash, teacher, kind):
+        L = _lib.lib()
+        z = stash._live()
+        dev = z.device
+        sums = torch.empty(4, dtype=torch.float32, device=dev)
+        scr = torch.empty(L.ia_joint_extra_scratch_elems(), dtype=torch.float32, device=dev)
+        t = teacher._live() if teacher is not None else None
+        st = L.ia_joint_extra_reduce(_lib.ptr(z), _lib.ptr(t), _lib.ptr(stash.box_t), _lib.ptr(stash.box_u),
+                                     _lib.ptr(stash.w_sq) if kind == 0 else None, _lib.ptr(stash.w_kd) if kind == 1 else None,
+                                     stash.B, stash.T, stash.U1, stash.V, stash.LD, _lib.ptr(sums), _lib.ptr(scr),
+                                     _lib.stream_ptr())
+        _lib.check(st, "ia_joint_extra_reduce")
+        ctx.stash, ctx.teacher, ctx.kind = stash, teacher, kind
+        _RANGES.setdefault((dev.index, kind), _RangeTracker()).push(sums)
+        return sums[kind].clone()
+
+    @staticmethod
+    def backward(ctx, gval):
+        L = _lib.lib()
+        stash, teacher, kind = ctx.stash, ctx.teacher, ctx.kind
+        z = stash._live()
+        dev = z.device
+        if stash.kappa is None:
+            # power-of-two gradient scale: the largest of |d rnnt|, |d sq| = w 2|z|, |d kd| = w e^t lands near 2^6
+            big = abs(float(stash.scale_hint))
+            r = _RANGES.get((dev.index, 0))
+            if r is not None and r.read() is not None:
+                big = max(big, stash.host_weights[0] * 2.0 * r.last[0])
+            r = _RANGES.get((dev.index, 1))
+            if r is not None and r.read() is not None:
+                big = max(big, stash.host_weights[1] * math.exp(min(r.last[1], 80.0)))
+            stash.kappa = float(2.0 ** math.floor(math.log2(64.0 / max(big, 1e-30))))
+        ups = torch.zeros(2, dtype=torch.float32, device=dev)
+        ups[kind] = gval.float() * stash.kappa
+        t = teacher._live() if teacher is not None else None
+        E = torch.empty_like(z)
+        st = L.ia_joint_extra_grad(_lib.ptr(z), _lib.ptr(t), _lib.ptr(stash.box_t), _lib.ptr(stash.box_u),
+                                   _lib.ptr(stash.w_sq) if kind == 0 else None, _lib.ptr(stash.w_kd) if kind == 1 else None,
+                                   _lib.ptr(ups), stash.B, stash.T, stash.U1, stash.V, stash.LD, _lib.ptr(E), _lib.stream_ptr())
+        _lib.check(st, "ia_joint_extra_grad")
+        if stash.pending_E is None:
+            stash.pending_E = E
+        else:
+            st = L.ia_lattice_add_f16(_lib.ptr(stash.pending_E), _lib.ptr(E), E.numel(), _lib.stream_ptr())
+            _lib.check(st, "ia_lattice_add_f16")
+        return gval.new_zeros(()), None, None, None
+
+
+def lattice_sumsq_term(stash: LatticeStash):
+    """(1/n_sub) sum_sub mean_{cells of the sub-batch box} sum_v z^2  (R/cl_baseline_mas.py:260-263), differentiable."""
+    if stash.token is None:
+        tok = torch.zeros((), dtype=torch.float32, device=stash._live().device)
+    else:
+        tok = stash.token
+    return _LatticeTerm.apply(tok, stash, None, 0)
+
+
+def lattice_kd_term(stash: LatticeStash, teacher: LatticeStash):
+    """(1/n_sub) sum_sub F.kl_div(z_sub, exp(t_sub), 'batchmean')  (R/cl_baseline_lwf.py:249-257), differentiable in z."""
+    if not stash.same_geometry(teacher):
+        raise ValueError("lwf: teacher and student lattices come from different batches")
+    tok = stash.token if stash.token is not None else torch.zeros((), dtype=torch.float32, device=stash._live().device)
+    return _LatticeTerm.apply(tok, stash, teacher, 1)
+
+
 class _FusedJointRNNT(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, f, g, W, bias, labels, act_lens, label_lens, blank, dropout_p, seed, fastemit, scale_hint):
+    def forward(ctx, f, g, W, bias, labels, act_lens, label_lens, blank, dropout_p, seed, fastemit, scale_hint, stash_req):
         from ..losses import rnnt as rl
         L = _lib.lib()
+        ctx.set_materialize_grads(False)
         B, T, H = f.shape
         U1 = g.shape[1]
         V = W.shape[0]
@@ -56,41 +207,40 @@ class _FusedJointRNNT(torch.autograd.Function):
             raise RuntimeError("fused joint: unsupported lattice size (U1 <= 1024)")
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         logits = torch.empty(B * T * U1, LD, dtype=torch.float16, device=dev)
-        st = L.ia_joint_fwd(_lib.ptr(f16), _lib.ptr(g16), _lib.ptr(Wp), _lib.ptr(bias32), _lib.ptr(labels),
-                            _lib.ptr(act_lens), _lib.ptr(label_lens), B, T, U1, H, V, int(blank), p, int(seed) & 0xFFFFFFFF,
-                            _lib.ptr(logits), LD, _lib.ptr(ws), nbytes, _lib.stream_ptr())
-        _lib.check(st, "ia_joint_fwd")
+        stash = None
+        if stash_req is not None:
+            stash = _make_stash(stash_req, logits, (B, T, U1, V, LD), dev)
+            stash.scale_hint = scale_hint if scale_hint else 1.0
+            stash_req["out"] = stash
+        st = L.ia_joint_fwd_box(_lib.ptr(f16), _lib.ptr(g16), _lib.ptr(Wp), _lib.ptr(bias32), _lib.ptr(labels),
+                                _lib.ptr(act_lens), _lib.ptr(label_lens), _lib.ptr(stash.box_t) if stash else None,
+                                _lib.ptr(stash.box_u) if stash else None, B, T, U1, H, V, int(blank), p,
+                                int(seed) & 0xFFFFFFFF, _lib.ptr(logits), LD, _lib.ptr(ws), nbytes, _lib.stream_ptr())
+        _lib.check(st, "ia_joint_fwd_box")
         costs = torch.empty(B, dtype=torch.float32, device=dev)
         st = L.ia_rnnt_lattice(_lib.ptr(act_lens), _lib.ptr(label_lens), B, T, U1, float(fastemit), int(need),
                                _lib.ptr(costs), _lib.ptr(ws), nbytes, _lib.stream_ptr())
         _lib.check(st, "ia_rnnt_lattice")
+        ctx.stash = stash
         if need:
             ctx.saved = (f16, g16, Wp, logits, ws, labels, act_lens, label_lens)
             ctx.meta = (B, T, U1, H, V, LD, int(blank), p, int(seed) & 0xFFFFFFFF, float(fastemit),
                         _kappa_for(scale_hint), f.dtype, g.dtype, W.dtype, bias.dtype, nbytes)
-        return costs
+        # the second output is the autograd handle of the lattice: the CL terms hang their nodes on it (_LatticeTerm)
+        return costs, torch.zeros((), dtype=torch.float32, device=dev)
 
     @staticmethod
-    def backward(ctx, gcosts):
-        from ..losses import rnnt as rl
-        L = _lib.lib()
-        if ctx.saved is None:   # the gradient overwrites the saved logits in place: one backward per forward
-            raise RuntimeError("fused joint+loss: trying to backward through the graph a second time -- the saved lattice "
-                               "was overwritten in place by the first backward (the fused path does not support "
-                               "retain_graph=True; run the forward again)")
-        f16, g16, Wp, logits, ws, labels, act_lens, label_lens = ctx.saved
-        B, T, U1, H, V, LD, blank, p, seed, fastemit, kappa, fdt, gdt, wdt, bdt, nbytes = ctx.meta
-        ctx.saved = None
-        dev = f16.device
-        cg = gcosts.reshape(-1).float().contiguous()
+    def _rnnt_gradient(ctx, L, rl, gcosts, logits, ws, labels, act_lens, label_lens, fused_dw, kappa):
+        """logits -> kappa * d loss / d logits in place (csrc/joint_bwd.hip); returns (G, kappa*dbias | None, GT, S, Kc)."""
+        B, T, U1, H, V, LD, blank, p, seed, fastemit, _, fdt, gdt, wdt, bdt, nbytes = ctx.meta
+        dev = logits.device
         cells = B * T * U1
-        fused_dw = USE_FUSED_DW and cells < 2 ** 31 and L.ia_joint_dw_fused_supported(U1, H, LD)
+        cg = gcosts.reshape(-1).float().contiguous()
         GT, S, Kc = None, 0, 0
         if not fused_dw:
             # split-K layout for the library weight-gradient GEMM: S chunks of Kc lattice cells, both operands K-contiguous
             S = 64
             Kc = ((cells + S - 1) // S + 63) // 64 * 64
-            LDH = H + 8
             GT = torch.empty(S, LD, Kc, dtype=torch.float16, device=dev)
         hook = None
         if rl.PROFILE_HOOK is not None:   # bench.py: HIP events around the gradient kernel on its launch stream
@@ -108,6 +258,53 @@ class _FusedJointRNNT(torch.autograd.Function):
         LAST_GRAD_KERNEL_EVENT = torch.cuda.Event()
         LAST_GRAD_KERNEL_EVENT.record()
         G = logits  # [cells, LD] f16, = kappa * dL/dlogits
+        return G, dbk, GT, S, Kc
+
+    @staticmethod
+    def backward(ctx, gcosts, gtoken):
+        from ..losses import rnnt as rl
+        L = _lib.lib()
+        stash = ctx.stash
+        E = stash.pending_E if (stash is not None and gtoken is not None) else None
+        if gcosts is None and E is None:
+            return (None,) * 13
+        if ctx.saved is None:   # the gradient overwrites the saved logits in place: one backward per forward
+            raise RuntimeError("fused joint+loss: trying to backward through the graph a second time -- the saved lattice "
+                               "was overwritten in place by the first backward (the fused path does not support "
+                               "retain_graph=True; run the forward again)")
+        f16, g16, Wp, logits, ws, labels, act_lens, label_lens = ctx.saved
+        B, T, U1, H, V, LD, blank, p, seed, fastemit, kappa, fdt, gdt, wdt, bdt, nbytes = ctx.meta
+        ctx.saved = None
+        dev = f16.device
+        cells = B * T * U1
+        fused_dw = USE_FUSED_DW and cells < 2 ** 31 and L.ia_joint_dw_fused_supported(U1, H, LD)
+        if stash is not None:
+            stash.logits = None   # consumed below
+        if E is not None:
+            kappa = stash.kappa
+            stash.pending_E = None
+            if not (fused_dw and USE_FUSED_DH and L.ia_joint_dh_fused_supported(U1, H, LD)):
+                raise RuntimeError("fused joint: the continual-learning terms need the fused hidden- and weight-gradient "
+                                   "kernels (U1 <= 128, H % 80 == 0); set joint.use_fused = False for this shape")
+        have_rnnt = gcosts is not None
+        dbk = None
+        if not have_rnnt:
+            # importance pass (R/cl_baseline_mas.py:258-266): only the extra terms are differentiated -- their gradient IS
+            # the lattice gradient, the transducer's gradient kernel does not run
+            G = E
+            dbk = torch.sum(E, 0, dtype=torch.float32)
+            GT, S, Kc = None, 0, 0
+        else:
+            G, dbk, GT, S, Kc = _FusedJointRNNT._rnnt_gradient(ctx, L, rl, gcosts, logits, ws, labels, act_lens, label_lens,
+                                                               fused_dw, kappa)
+            if E is not None:
+                st = L.ia_lattice_add_f16(_lib.ptr(G), _lib.ptr(E), G.numel(), _lib.stream_ptr())
+                _lib.check(st, "ia_lattice_add_f16")
+                dbk = dbk + torch.sum(E, 0, dtype=torch.float32)
+        if E is not None:   # the extra terms live on the sub-batch boxes, not only on the valid lattice
+            act_lens, label_lens = stash.box_t, stash.box_um1
+        del E
+        LDH = H + 8
         df = torch.zeros(B, T, H, dtype=torch.float32, device=dev)
         dg = torch.zeros(B, U1, H, dtype=torch.float32, device=dev)
         if USE_FUSED_DH and L.ia_joint_dh_fused_supported(U1, H, LD):
@@ -149,11 +346,41 @@ class _FusedJointRNNT(torch.autograd.Function):
             dWx = torch.bmm(GT, HT.transpose(1, 2), out_dtype=torch.float32).sum(0)  # [LD, LDH]
             dW = dWx[:V, :H] * (1.0 / (kappa * (1.0 - p)))
             db = dWx[:V, H] * (1.0 / kappa)
-        return df.to(fdt), dg.to(gdt), dW.to(wdt), db.to(bdt), None, None, None, None, None, None, None, None
+        return df.to(fdt), dg.to(gdt), dW.to(wdt), db.to(bdt), None, None, None, None, None, None, None, None, None
+
+
+def _make_stash(req, logits, geom, dev):
+    """Box extents and weights of the reference's sub-batch loop (A/modules/rnnt.py:1436-1447: each sub-batch is narrowed
+    to its own max T / max U) from the host-side lengths: utterance b of sub-batch s gets box (max_t_s, max_u_s + 1),
+    w_sq = 1 / (n_sub * b_s * max_t_s * (max_u_s+1)) (mean over cells, mean over sub-batches) and w_kd = 1 / (n_sub * b_s)
+    ('batchmean', mean over sub-batches).  One pinned H2D copy each for the integers and the floats."""
+    import numpy as np
+    B, T, U1, V, LD = geom
+    sub, h_enc, h_tgt = int(req["sub"]), req["h_enc"], req["h_tgt"]
+    n_sub = (B + sub - 1) // sub
+    ints = np.empty((3, B), dtype=np.int64)
+    w = np.empty((2, B), dtype=np.float32)
+    for b0 in range(0, B, sub):
+        b1 = min(b0 + sub, B)
+        mt, mu1 = min(max(h_enc[b0:b1]), T), min(max(h_tgt[b0:b1]) + 1, U1)
+        ints[0, b0:b1], ints[1, b0:b1], ints[2, b0:b1] = mt, mu1, mu1 - 1
+        w[0, b0:b1] = 1.0 / (n_sub * (b1 - b0) * mt * mu1)
+        w[1, b0:b1] = 1.0 / (n_sub * (b1 - b0))
+    di = torch.from_numpy(ints).pin_memory().to(dev, non_blocking=True)
+    dw = torch.from_numpy(w).pin_memory().to(dev, non_blocking=True)
+    st = LatticeStash(logits, geom, (di[0], di[1], di[2]), (dw[0], dw[1]), n_sub, sub, None, bool(req.get("detach")))
+    st.host_boxes = (ints[0].tolist(), ints[1].tolist())
+    st.host_weights = (float(w[0].max()), float(w[1].max()))
+    return st
 
 
 def fused_joint_rnnt(f, g, W, bias, labels, act_lens, label_lens, blank, dropout_p=0.0, seed=0, fastemit_lambda=0.0,
-                     scale_hint=1.0):
-    """f [B,T,H], g [B,U1,H] (any float dtype), W [V,H], bias [V] -> costs [B] f32 (differentiable)."""
-    return _FusedJointRNNT.apply(f, g, W, bias, labels.contiguous(), act_lens.contiguous(), label_lens.contiguous(),
-                                 blank, dropout_p, seed, fastemit_lambda, scale_hint)
+                     scale_hint=1.0, stash_req=None):
+    """f [B,T,H], g [B,U1,H] (any float dtype), W [V,H], bias [V] -> costs [B] f32 (differentiable).
+    stash_req = {"sub": fused_batch_size, "h_enc": [...], "h_tgt": [...], "detach": bool}: also keeps the logits of every
+    sub-batch box and leaves a LatticeStash in stash_req["out"]."""
+    costs, token = _FusedJointRNNT.apply(f, g, W, bias, labels.contiguous(), act_lens.contiguous(), label_lens.contiguous(),
+                                         blank, dropout_p, seed, fastemit_lambda, scale_hint, stash_req)
+    if stash_req is not None and not stash_req.get("detach") and token.requires_grad:
+        stash_req["out"].token = token
+    return costs
