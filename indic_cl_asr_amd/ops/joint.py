@@ -36,39 +36,13 @@ def _kappa_for(scale_hint):
 
 # ------------------------------------------------------------------------------------------------------------------------
 # The sub-batch logits stash of the CL scripts (joint.store_list, A/modules/rnnt.py:1463-1496) on the fused path.
-class _RangeTracker:
-    """max |z| / max t of the lattices the extra terms were evaluated on, read back without stalling the host: each
-    reduction leaves its maxima in a pinned buffer behind an event; the gradient scale of a backward is sized from the
-    newest reading that has ARRIVED (the very first one is waited for).  A reading that is one step old is fine: the
-    scale is a power of two with 2^10 of headroom below f16's largest number."""
-
-    def __init__(self):
-        self.last = None       # (zmax, tmax) host floats
-        self.pending = []      # [(pinned [4] f32, event)]
-
-    def push(self, sums4):
-        host = torch.empty(4, dtype=torch.float32, pin_memory=True)
-        host.copy_(sums4.detach(), non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        self.pending.append((host, ev))
-        del self.pending[:-4]
-
-    def read(self):
-        newest = None
-        for host, ev in reversed(self.pending):
-            if ev.query():
-                newest = host
-                break
-        if newest is None and self.last is None and self.pending:
-            newest, ev = self.pending[-1]
-            ev.synchronize()
-        if newest is not None:
-            self.last = (float(newest[2]), float(newest[3]))
-        return self.last
-
-
-_RANGES = {}
+def _range_push(stash, kind, sums4):
+    """max |z| / max t of a term's reduction -> pinned host memory behind an event (read when the backward sizes kappa)."""
+    host = torch.empty(4, dtype=torch.float32, pin_memory=True)
+    host.copy_(sums4.detach(), non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    stash.ranges[kind] = (host, ev)
 
 
 class LatticeStash:
@@ -91,6 +65,7 @@ class LatticeStash:
         self.scale_hint = 1.0                 # |d loss / d cost_b| the transducer part of the gradient is expected to carry
         self.host_boxes = None                # (box_t, box_u) host lists
         self.host_weights = (0.0, 0.0)        # (max w_sq, max w_kd)
+        self.ranges = {}                      # kind -> (pinned [4] f32, event) of the terms evaluated on this lattice
 
     def __len__(self):
         return self.n_sub
@@ -132,7 +107,7 @@ class _LatticeTerm(torch.autograd.Function):
                                      _lib.stream_ptr())
         _lib.check(st, "ia_joint_extra_reduce")
         ctx.stash, ctx.teacher, ctx.kind = stash, teacher, kind
-        _RANGES.setdefault((dev.index, kind), _RangeTracker()).push(sums)
+        _range_push(stash, kind, sums)
         return sums[kind].clone()
 
     @staticmethod
@@ -143,13 +118,13 @@ class _LatticeTerm(torch.autograd.Function):
         dev = z.device
         if stash.kappa is None:
             # power-of-two gradient scale: the largest of |d rnnt|, |d sq| = w 2|z|, |d kd| = w e^t lands near 2^6
+            # (the one host wait of a MAS / LwF step: the reductions of THIS forward have to have finished.  A stale
+            #  reading from an earlier step would do most of the time and fail badly when the workload changes.)
             big = abs(float(stash.scale_hint))
-            r = _RANGES.get((dev.index, 0))
-            if r is not None and r.read() is not None:
-                big = max(big, stash.host_weights[0] * 2.0 * r.last[0])
-            r = _RANGES.get((dev.index, 1))
-            if r is not None and r.read() is not None:
-                big = max(big, stash.host_weights[1] * math.exp(min(r.last[1], 80.0)))
+            for k, (host, ev) in stash.ranges.items():
+                ev.synchronize()
+                big = max(big, stash.host_weights[0] * 2.0 * float(host[2]) if k == 0
+                          else stash.host_weights[1] * math.exp(min(float(host[3]), 80.0)))
             stash.kappa = float(2.0 ** math.floor(math.log2(64.0 / max(big, 1e-30))))
         ups = torch.zeros(2, dtype=torch.float32, device=dev)
         ups[kind] = gval.float() * stash.kappa
@@ -285,7 +260,7 @@ class _FusedJointRNNT(torch.autograd.Function):
             stash.pending_E = None
             if not (fused_dw and USE_FUSED_DH and L.ia_joint_dh_fused_supported(U1, H, LD)):
                 raise RuntimeError("fused joint: the continual-learning terms need the fused hidden- and weight-gradient "
-                                   "kernels (U1 <= 128, H % 80 == 0); set joint.use_fused = False for this shape")
+                                   "kernels (U1 <= 128, H % 320 == 0); set joint.use_fused = False for this shape")
         have_rnnt = gcosts is not None
         dbk = None
         if not have_rnnt:

@@ -52,13 +52,14 @@ def _close(a, ref, what, rel=6e-3):
     assert (a - ref).abs().max().item() <= tol, (what, (a - ref).abs().max().item(), ref.abs().max().item())
 
 
-@pytest.mark.parametrize("B,T,U1,H,V,sub", [(5, 37, 19, 160, 257, 2), (4, 50, 33, 320, 130, 4), (3, 21, 9, 640, 257, 1)])
+@pytest.mark.parametrize("B,T,U1,H,V,sub", [(5, 37, 19, 320, 257, 2), (4, 50, 33, 320, 130, 4), (3, 21, 9, 640, 257, 1)])
 def test_importance_term_and_its_gradient_match_the_stash_loop(B, T, U1, H, V, sub):
     from indic_cl_asr_amd.ops import joint as J
     f, g, W, b, labels, fl, gl = _inputs(B, T, U1, H, V, seed=B * 31 + T)
     # fp64 reference with autograd through the f16-quantised operands
     leaves = [x.clone().double().requires_grad_(True) for x in (f.half(), g.half(), W.half(), b)]
     pre = leaves[0][:, :, None, :] + leaves[1][:, None, :, :]
+    pre = pre + ((f.half()[:, :, None, :] + g.half()[:, None, :, :]).double() - pre.detach())   # the kernel adds in f16
     z = torch.relu(pre) @ leaves[2].t() + leaves[3]
     z = z + (z.detach().half().double() - z.detach())    # value rounded to f16 as the kernel stores it, gradient straight through
     sq_ref, _ = _sub_terms(z, None, fl, gl, sub, V)
@@ -81,7 +82,7 @@ def test_importance_term_and_its_gradient_match_the_stash_loop(B, T, U1, H, V, s
         _close(got.grad, ref.grad, what)
 
 
-@pytest.mark.parametrize("B,T,U1,H,V,sub", [(4, 33, 17, 160, 257, 2), (3, 45, 21, 320, 100, 4)])
+@pytest.mark.parametrize("B,T,U1,H,V,sub", [(4, 33, 17, 320, 257, 2), (3, 45, 21, 640, 100, 4)])
 def test_distillation_term_adds_to_the_transducer_gradient(B, T, U1, H, V, sub):
     from indic_cl_asr_amd.ops import joint as J
     from oracle import rnnt_oracle as orc
@@ -96,6 +97,7 @@ def test_distillation_term_adds_to_the_transducer_gradient(B, T, U1, H, V, sub):
     t64 = t64.half().double()
     leaves = [x.clone().double().requires_grad_(True) for x in (f.half(), g.half(), W.half(), b)]
     pre = leaves[0][:, :, None, :] + leaves[1][:, None, :, :]
+    pre = pre + ((f.half()[:, :, None, :] + g.half()[:, None, :, :]).double() - pre.detach())   # the kernel adds in f16
     hid = torch.relu(pre)
     z = hid @ leaves[2].t() + leaves[3]
     z = z + (z.detach().half().double() - z.detach())
@@ -122,7 +124,7 @@ def test_stash_on_the_model_path_is_a_lattice_and_unused_stash_costs_nothing():
     from indic_cl_asr_amd.model import EncDecHybridRNNTCTCModel
     from indic_cl_asr_amd.ops.joint import LatticeStash
     torch.manual_seed(0)
-    cfg = model_config('tiny', d_model=64, n_layers=2, n_heads=1, pred_hidden=64, joint_hidden=160, vocab_per_lang=64,
+    cfg = model_config('tiny', d_model=64, n_layers=2, n_heads=1, pred_hidden=64, joint_hidden=320, vocab_per_lang=64,
                        compute_dtype="bf16")
     m = EncDecHybridRNNTCTCModel(cfg).cuda()
     m.train()

@@ -1,0 +1,34 @@
+#!/bin/bash
+# Per-round profile collection on the GPU box (developer tool):  bash tools/profile_round.sh r02
+# 1) kernel trace + stats of the bench command, 2) three PMC passes (separate runs, --kernel-trace only).
+# Outputs under gpurun_out/<tag>/; tools/pmc_traffic.py / pmc_mfma.py / trace_timeline.py fold them into profiles/.
+set -o pipefail
+TAG=${1:-r02}
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+CMD="python3 $ROOT/bench.py --steps 8 --warmup 4 --no-cpu-baseline"
+timeout -k 10 420 rocprofv3 --kernel-trace --stats -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1 || { echo trace failed; tail -5 $OUT/trace.log; exit 1; }
+echo trace done
+PM="python3 $ROOT/bench.py --steps 2 --warmup 2 --no-cpu-baseline"
+timeout -k 10 420 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -- $PM > $OUT/pmc_fetch.log 2>&1 || { echo fetch failed; tail -5 $OUT/pmc_fetch.log; exit 1; }
+echo fetch done
+timeout -k 10 420 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -- $PM > $OUT/pmc_write.log 2>&1 || { echo write failed; tail -5 $OUT/pmc_write.log; exit 1; }
+echo write done
+timeout -k 10 420 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES -d $OUT/pmc_mfma -- $PM > $OUT/pmc_mfma.log 2>&1 || { echo mfma failed; tail -5 $OUT/pmc_mfma.log; exit 1; }
+echo mfma done
+cd $ROOT
+T=$(find $OUT/trace -name "*kernel_trace.csv" | head -1)
+python3 tools/trace_timeline.py $T --skip-frac 0.5 > $OUT/timeline.txt 2>&1
+KS="joint_grad_h_db_kernel joint_dh_fused_kernel joint_dw_fused_kernel joint_fwd_kernel ffn_fused_kernel relpos_flash_fwd_kernel relpos_attn_bwd_kernel gemm_bf16_nt_kernel gemm_tn_kernel dwconv_fwd_kernel lstm_fwd_kernel lstm_bwd_kernel adamw_seg_kernel cl_penalty_kernel layernorm_kernel conv1_relu_cl_kernel"
+python3 tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_traffic.json $KS > $OUT/pmc_traffic.txt 2>&1
+python3 tools/pmc_mfma.py $OUT/pmc_mfma $OUT/pmc_mfma.json $KS > $OUT/pmc_mfma.txt 2>&1
+# keep the returned payload small: the raw trace / counter CSVs are large
+python3 - <<PY
+import glob, os
+for f in glob.glob("$OUT/**/*", recursive=True):
+    if os.path.isfile(f) and os.path.getsize(f) > 12e6:
+        os.remove(f)
+PY
+du -sh $OUT
