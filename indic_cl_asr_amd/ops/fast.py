@@ -317,6 +317,31 @@ def colsum(x_bf16):
     return out
 
 
+def gemm_tn(dy_bf16, x_bf16):
+    """(dW [N,K] f32, db [N] f32) = (dY^T X, column sums of dY) on csrc/gemm_tn.hip; dY [M,N], X [M,K] bf16 with 16-byte
+    aligned rows (row strides may exceed the widths: slices of a wider matrix are fine)."""
+    L = _lib.lib()
+    M, N = dy_bf16.shape
+    K = x_bf16.shape[1]
+    buf = torch.empty(N * K + N, dtype=torch.float32, device=dy_bf16.device)
+    dW, db = buf[:N * K].view(N, K), buf[N * K:]
+    st = L.ia_gemm_tn_bf16(_lib.ptr(dy_bf16), dy_bf16.stride(0), _lib.ptr(x_bf16), x_bf16.stride(0), M, N, K, _lib.ptr(dW),
+                           _lib.ptr(db), _lib.ptr(scratch(dy_bf16.device, L.ia_gemm_tn_scratch_elems(M, N, K))),
+                           _lib.stream_ptr())
+    _lib.check(st, "ia_gemm_tn_bf16")
+    return dW, db
+
+
+def weight_t_shadow(weight):
+    """W^T [K,N] bf16, cached per parameter version: the 'weight' of the data-gradient GEMM dX = dY W = dY (W^T)^T."""
+    return _cached(("wT", id(weight)), (weight,), lambda: bf16_shadow(weight).t().contiguous())
+
+
+def gemm_data_grad(dy_bf16, weight):
+    """dX [M,K] bf16 = dY W for y = x W^T, on the HIP NT GEMM against the cached transposed shadow of `weight` [N,K]."""
+    return gemm(dy_bf16, weight_t_shadow(weight))[1]
+
+
 class _LinearHip(torch.autograd.Function):
     """y = x W^T + b for trainable projections outside the fused blocks (joint enc / pred): forward on the HIP GEMM (bias
     in the epilogue, bf16 out), data gradient as a library GEMM, weight + bias gradient by csrc/gemm_tn.hip (hipBLASLt's
@@ -330,6 +355,7 @@ class _LinearHip(torch.autograd.Function):
         wb = bf16_shadow(weight)
         _, y = gemm(xb, wb, bias.detach().float() if bias is not None else None)
         ctx.save_for_backward(xb, wb)
+        ctx.weight = weight
         ctx.meta = (shp, x.dtype, weight.dtype, weight.shape, bias.dtype if bias is not None else None)
         return y.view(*shp[:-1], wb.shape[0])
 
@@ -342,15 +368,13 @@ class _LinearHip(torch.autograd.Function):
         K = xb.shape[1]
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
-            dx = torch.mm(dyb, wb).view(shp).to(xdt)
+            if gemm_supported(N, K):   # dX = dY W on the HIP GEMM against the cached W^T
+                dx = gemm_data_grad(dyb, ctx.weight).view(shp).to(xdt)
+            else:
+                dx = torch.mm(dyb, wb).view(shp).to(xdt)
         if ctx.needs_input_grad[1] or (bdt is not None and ctx.needs_input_grad[2]):
             if N % 8 == 0 and K % 8 == 0:
-                L = _lib.lib()
-                buf = torch.empty(N * K + N, dtype=torch.float32, device=dyb.device)
-                dWf, dbf = buf[:N * K].view(N, K), buf[N * K:]
-                st = L.ia_gemm_tn_bf16(_lib.ptr(dyb), dyb.stride(0), _lib.ptr(xb), xb.stride(0), M, N, K, _lib.ptr(dWf), _lib.ptr(dbf),
-                                       _lib.ptr(scratch(dyb.device, L.ia_gemm_tn_scratch_elems(M, N, K))), _lib.stream_ptr())
-                _lib.check(st, "ia_gemm_tn_bf16")
+                dWf, dbf = gemm_tn(dyb, xb)
             else:
                 dWf = torch.mm(dyb.t(), xb, out_dtype=torch.float32)
                 dbf = dyb.float().sum(0)

@@ -9,14 +9,14 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 CMD="python3 $ROOT/bench.py --steps 8 --warmup 4 --no-cpu-baseline"
-timeout -k 10 420 rocprofv3 --kernel-trace --stats -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1 || { echo trace failed; tail -5 $OUT/trace.log; exit 1; }
+timeout -k 10 420 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1 || { echo trace failed; tail -5 $OUT/trace.log; exit 1; }
 echo trace done
 PM="python3 $ROOT/bench.py --steps 2 --warmup 2 --no-cpu-baseline"
-timeout -k 10 420 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -- $PM > $OUT/pmc_fetch.log 2>&1 || { echo fetch failed; tail -5 $OUT/pmc_fetch.log; exit 1; }
+timeout -k 10 420 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -- $PM > $OUT/pmc_fetch.log 2>&1 || { echo fetch failed; tail -5 $OUT/pmc_fetch.log; exit 1; }
 echo fetch done
-timeout -k 10 420 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -- $PM > $OUT/pmc_write.log 2>&1 || { echo write failed; tail -5 $OUT/pmc_write.log; exit 1; }
+timeout -k 10 420 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/pmc_write -- $PM > $OUT/pmc_write.log 2>&1 || { echo write failed; tail -5 $OUT/pmc_write.log; exit 1; }
 echo write done
-timeout -k 10 420 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES -d $OUT/pmc_mfma -- $PM > $OUT/pmc_mfma.log 2>&1 || { echo mfma failed; tail -5 $OUT/pmc_mfma.log; exit 1; }
+timeout -k 10 420 rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES -d $OUT/pmc_mfma -- $PM > $OUT/pmc_mfma.log 2>&1 || { echo mfma failed; tail -5 $OUT/pmc_mfma.log; exit 1; }
 echo mfma done
 cd $ROOT
 T=$(find $OUT/trace -name "*kernel_trace.csv" | head -1)
