@@ -478,6 +478,8 @@ int ia_silu_dropout_bwd(const void* h_pre, const void* dh, int64_t M, int N, flo
                         ia_stream_t stream);
 int ia_scale_dropout_bf16(const float* dy, int64_t M, int N, float alpha, float dropout_p, unsigned seed, void* out,
                           ia_stream_t stream);
+/* dst [M, ldd] bf16 = src [M, N] f32 (row stride lds), columns N..ldd zero (ldd % 8 == 0): ragged-width gradients -> GEMM operand */
+int ia_cast_pad_bf16(const float* src, int lds, int64_t M, int N, void* dst, int ldd, ia_stream_t stream);
 int ia_bn_silu_bwd(const float* z, const void* dc3, int64_t n_rows, int d, const float* bn_sum, const float* bn_sumsq,
                    const float* gamma, const float* beta, float eps, float* S1, float* S2, float* dz, float* scratch,
                    ia_stream_t stream);

@@ -60,6 +60,7 @@ SIGNATURES = {
     "ia_joint_extra_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "ia_joint_extra_grad": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "ia_lattice_add_f16": (_i, [_vp, _vp, _i64, _vp]),
+    "ia_cast_pad_bf16": (_i, [_vp, _i, _i64, _i, _vp, _i, _vp]),
     "ia_rnnt_lattice": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _sz, _vp]),
     "ia_joint_backward_g": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _f, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp,
                                  _vp]),

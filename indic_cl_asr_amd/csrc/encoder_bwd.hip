@@ -345,6 +345,33 @@ extern "C" int ia_scale_dropout_bf16(const float* dy, int64_t M, int N, float al
 }
 
 namespace {
+// dst[m][0..ldd) = bf16(src[m][n]) for n < N, 0 beyond: a ragged-width f32 gradient (the CTC head's 257 columns) becomes the
+// 16-byte-row bf16 operand of the HIP GEMMs in one pass.  Thread = 8 output columns.
+__global__ __launch_bounds__(256) void cast_pad_bf16_kernel(const float* __restrict__ src, int lds, int64_t M, int N,
+                                                            __bf16* __restrict__ dst, int ldd) {
+    const int vpr = ldd / 8;
+    const int64_t total = M * vpr;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i / vpr;
+        const int n0 = (int)(i - m * vpr) * 8;
+        const float* s = src + m * lds + n0;
+        union { uint4 u; __bf16 h[8]; } o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.h[j] = (__bf16)((n0 + j < N) ? s[j] : 0.f);
+        *reinterpret_cast<uint4*>(dst + m * ldd + n0) = o.u;
+    }
+}
+}  // namespace
+
+extern "C" int ia_cast_pad_bf16(const float* src, int lds, int64_t M, int N, void* dst, int ldd, ia_stream_t stream) {
+    if (!src || !dst || M <= 0 || N <= 0 || lds < N || ldd < N || ldd % 8 != 0 || !ia_is_aligned(dst, 16)) return IA_INVALID_VALUE;
+    hipLaunchKernelGGL(cast_pad_bf16_kernel, dim3(ew_grid(M * (ldd / 8))), dim3(256), 0, (hipStream_t)stream, src, lds, M, N,
+                       (__bf16*)dst, ldd);
+    IA_RETURN_IF_LAUNCH_FAILED();
+    return IA_OK;
+}
+
+namespace {
 inline int bnb_rows_per_block(int64_t n_rows) {
     int64_t rpb = (n_rows + 1023) / 1024;
     return (int)(rpb < 32 ? 32 : rpb);
