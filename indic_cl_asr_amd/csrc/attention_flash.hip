@@ -19,15 +19,9 @@
 //   O^T += V^T P^T         [64 dv x 16 queries]             8 MFMAs   (A = V^T fragments by ds_read_b64_tr_b16 from the
 //   row-major V tile: no pre-transposed V copy, no probability round trip through LDS).
 // Key tiles at or beyond the utterance's length are skipped.
-#include <hip/hip_bf16.h>
-
-#include "ia_common.h"
+#include "attention_flash.h"
 
 namespace {
-
-typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
-typedef short s4v __attribute__((ext_vector_type(4)));
-typedef float f4 __attribute__((ext_vector_type(4)));
 
 constexpr int FA_THREADS = 256;
 constexpr int FA_KT = 64;                  // keys per tile
@@ -39,33 +33,10 @@ constexpr int FA_SR_LD = 104;              // bf16 elements per band-strip row (
 constexpr int FA_SR_BYTES = 16 * FA_SR_LD * 2;
 constexpr int FA_LDS = 2 * FA_STAGE + 4 * FA_SR_BYTES;   // 78 848 B
 
-__device__ __forceinline__ unsigned fa_hash32(unsigned x) {
-    x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
-    return x;
-}
-// attention-dropout randomness of this kernel: one hash per (head, query, group of 4 keys); key j uses byte j & 3
-__device__ __forceinline__ unsigned fa_keep_rand4(unsigned seed, int bh, int T, int i, int j4) {
-    const unsigned idx = ((unsigned)bh * (unsigned)T + (unsigned)i) * (unsigned)((T + 3) >> 2) + (unsigned)j4;
-    return fa_hash32(idx * 0x9E3779B1u + seed);
-}
-
-// 16-byte slot `slot` (8 elements) of a head row of `dk` elements starting at `row` (8-byte aligned), zero beyond dk
-template <bool FULL>
-__device__ __forceinline__ uint4 fa_load_slot(const __bf16* row, int slot, int dk) {
-    if constexpr (FULL) {
-        return *reinterpret_cast<const uint4*>(row + slot * 8);
-    } else {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        const int e0 = slot * 8;
-        if (e0 < dk) { const uint2 a = *reinterpret_cast<const uint2*>(row + e0); v.x = a.x; v.y = a.y; }
-        if (e0 + 4 < dk) { const uint2 a = *reinterpret_cast<const uint2*>(row + e0 + 4); v.z = a.x; v.w = a.y; }
-        return v;
-    }
-}
-
 struct FaArgs {
     const __bf16* qkv; const __bf16* pl; const float* bias_u; const float* bias_v; const int64_t* lens;
     __bf16* ctx; int B, T, H, dk; float scale; unsigned seed, thr; float keep_scale;
+    float* lse;   // optional [B*H, T]: log-sum-exp of each query's scaled scores (the backward recomputes P = exp(s - lse))
 };
 
 template <bool DK64>
@@ -88,9 +59,11 @@ __global__ __launch_bounds__(FA_THREADS, 2) void relpos_flash_fwd_kernel(FaArgs 
     const int iq = iw + c;                               // this lane's query
     __bf16* orow = a.ctx + ((size_t)b * T + (iq < T ? iq : T - 1)) * d + h * dk;
     if (I0 >= len) {                                     // workgroup-uniform: only padded queries -> zero context
-        if (iq < T)
+        if (iq < T) {
             for (int mt = 0; mt < 4; ++mt)
                 if (mt * 16 + q4 * 4 < dk) *reinterpret_cast<uint2*>(orow + mt * 16 + q4 * 4) = make_uint2(0, 0);
+            if (a.lse && q4 == 0) a.lse[(size_t)bh * T + iq] = 0.f;
+        }
         return;
     }
     unsigned char* sR = smem + 2 * FA_STAGE + wave * FA_SR_BYTES;
@@ -261,6 +234,7 @@ __global__ __launch_bounds__(FA_THREADS, 2) void relpos_flash_fwd_kernel(FaArgs 
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);
     if (iq < T) {
+        if (a.lse && q4 == 0) a.lse[(size_t)bh * T + iq] = (iq < len && l_run > 0.f) ? m_run + __logf(l_run) : 0.f;
         const float inv = (iq < len && l_run > 0.f) ? 1.f / l_run : 0.f;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
@@ -281,12 +255,19 @@ extern "C" int ia_relpos_attention_flash_supported(int T, int dk) { return (T > 
 extern "C" int ia_relpos_attention_flash(const void* qkv, const void* pos_proj, const float* bias_u, const float* bias_v,
                                          const int64_t* lens, int B, int T, int H, int dk, float dropout_p, unsigned seed,
                                          void* ctx, ia_stream_t stream) {
+    return ia_relpos_attention_flash_lse(qkv, pos_proj, bias_u, bias_v, lens, B, T, H, dk, dropout_p, seed, ctx, nullptr, stream);
+}
+
+extern "C" int ia_relpos_attention_flash_lse(const void* qkv, const void* pos_proj, const float* bias_u, const float* bias_v,
+                                             const int64_t* lens, int B, int T, int H, int dk, float dropout_p, unsigned seed,
+                                             void* ctx, float* lse, ia_stream_t stream) {
     if (!qkv || !pos_proj || !bias_u || !bias_v || !lens || !ctx || B <= 0 || T <= 0 || H <= 0) return IA_INVALID_VALUE;
     if (!ia_relpos_attention_flash_supported(T, dk)) return IA_UNSUPPORTED;
     if (dropout_p < 0.f || dropout_p >= 1.f) return IA_INVALID_VALUE;
     if (!ia_is_aligned(qkv, 16) || !ia_is_aligned(pos_proj, 16) || !ia_is_aligned(ctx, 8)) return IA_INVALID_VALUE;
     FaArgs a;
     a.qkv = (const __bf16*)qkv; a.pl = (const __bf16*)pos_proj; a.bias_u = bias_u; a.bias_v = bias_v; a.lens = lens;
+    a.lse = lse;
     a.ctx = (__bf16*)ctx; a.B = B; a.T = T; a.H = H; a.dk = dk; a.scale = 1.f / sqrtf((float)dk); a.seed = seed;
     a.thr = (unsigned)(dropout_p * 256.f + 0.5f);
     a.keep_scale = a.thr > 0 ? 256.f / (256.f - (float)a.thr) : 1.f;
