@@ -428,18 +428,19 @@ int ia_conformer_prefix_fwd(const ia_block_params* layers, int n_layers, float* 
 /* ------------------------------------------------------------------------------------------------
  * Native executors of ONE TRAINABLE Conformer block (csrc/block_train.hip): ConformerLayer.forward
  * (conformer_modules.py:141-214) keeping what its backward needs, and that backward as two calls around the attention
- * core's backward (ia_relpos_attention_bwd + the caller's contractions).  Replaces the per-op Python autograd node:
+ * core's backward (ia_relpos_attention_flash_bwd + the caller's position-gradient GEMMs).  Replaces the per-op Python autograd node:
  * one C call enqueues the ~25 (forward) / ~35 + ~25 (backward) kernels of a block on `stream`.
  *   ia_block_saved  activations kept from forward to backward (caller-owned; bf16 unless noted): y1,y2,y3,y4 [N,d] =
  *                   LayerNorm outputs; h1p,h1,h4p,h4 [N,d_ff] = feed-forward pre-activation / dropout(SiLU(.));
  *                   x1..x4 [N,d] f32 = residual stream after each module; qkv [N,3d]; pl [pos_rows,d]; ctxv [N,d];
  *                   c2 [N,2d] (pointwise_conv1 output); z [N,d] f32 (depthwise conv output); sums [2,d] f32 (BatchNorm
- *                   sum / sum of squares); c3 [N,d].
+ *                   sum / sum of squares); c3 [N,d]; lse [B*H,T] f32 (attention log-sum-exp).
  *   ia_block_grads  where the parameter gradients are WRITTEN (f32, caller-owned; the q|k|v weight / bias gradients are
  *                   one [3d,d] / [3d] block in that order).
  *   forward   x0 [N,d] f32 -> out [N,d] f32 (= norm_out(...)); train-mode BatchNorm (running statistics updated); dropout
  *             sites seed + {1..7} as in ia_conformer_prefix_fwd; vt_scratch = ia_attn_vt_elems bf16, dw_scratch =
- *             ia_dwconv_scratch_elems f32.  Limits: ia_conformer_block_supported (head dim 64, T <= 384, taps <= 31).
+ *             ia_dwconv_scratch_elems f32.  Limits: ia_conformer_block_supported (head dim 64, taps <= 31; any T: the
+ *             attention core is the key-tiled ia_relpos_attention_flash_lse, vt_scratch is unused).
  *   bwd_a     dout [N,d] f32 -> gradients of norm_out, feed_forward2, conv module, linear_out; *dx2_out (f32 [N,d]) and
  *             *dctx_out (bf16 [N,d]) point INTO the workspace: d(residual in front of the attention branch), d(ctx).
  *   bwd_b     dqkv [N,3d], dpl [pos_rows,d] (bf16, from the attention backward) -> remaining gradients, dx0 [N,d] f32,
@@ -451,6 +452,7 @@ typedef struct ia_block_saved {
     void *y2, *qkv, *pl, *ctxv; float* x2;
     void *y3, *c2; float *z, *sums; void* c3; float* x3;
     void *y4, *h4p, *h4; float* x4;
+    float* lse;   /* [B*n_heads, T] f32: the attention core's per-query log-sum-exp (ia_relpos_attention_flash_lse) */
 } ia_block_saved;
 typedef struct ia_block_grads {
     float *w_ff1a, *b_ff1a, *w_ff1b, *b_ff1b, *w_qkv, *b_qkv, *w_pos, *w_out, *b_out, *w_pw1, *b_pw1, *w_pw2, *b_pw2;

@@ -34,7 +34,7 @@ class BlockParams(_c.Structure):
 class BlockSaved(_c.Structure):
     """ia_block_saved of include/indicasr.h (activations a trainable block keeps from forward to backward)."""
     _fields_ = [(n, _c.c_void_p) for n in ("y1", "h1p", "h1", "x1", "y2", "qkv", "pl", "ctxv", "x2", "y3", "c2", "z", "sums",
-                                           "c3", "x3", "y4", "h4p", "h4", "x4")]
+                                           "c3", "x3", "y4", "h4p", "h4", "x4", "lse")]
 
 
 class BlockGrads(_c.Structure):

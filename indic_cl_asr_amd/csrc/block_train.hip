@@ -127,7 +127,7 @@ extern "C" size_t ia_conformer_block_bwd_ws_bytes(int B, int T, int d, int d_ff,
 
 extern "C" int ia_conformer_block_supported(int d, int d_ff, int H, int ksz, int T) {
     if (d <= 0 || H <= 0 || d % H != 0) return 0;
-    return (d % 64 == 0 && d <= 1024 && 256 % (d / 4) == 0 && d_ff % 64 == 0 && ksz <= 31 && d / H == 64 && T <= 384) ? 1 : 0;
+    return (d % 64 == 0 && d <= 1024 && 256 % (d / 4) == 0 && d_ff % 64 == 0 && ksz <= 31 && d / H == 64 && T >= 1) ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------ forward
@@ -149,7 +149,7 @@ extern "C" int ia_conformer_block_fwd(const ia_block_params* Lp, const float* x0
     IA_TRY(ia_layernorm(S.x1, d, N, d, L.ln_att_g, L.ln_att_b, L.ln_eps, nullptr, 0, nullptr, nullptr, S.y2, d, stream));
     IA_TRY(ia_gemm_bf16(S.y2, d, L.w_qkv, d, N, 3 * d, d, L.b_qkv, 0, 0.f, 0, 1.f, nullptr, 0, nullptr, 0, S.qkv, 3 * d, stream));
     IA_TRY(ia_gemm_bf16(pos_emb, d, L.w_pos, d, pos_rows, d, d, nullptr, 0, 0.f, 0, 1.f, nullptr, 0, nullptr, 0, S.pl, d, stream));
-    IA_TRY(ia_relpos_attention(S.qkv, S.pl, L.pos_u, L.pos_v, lens, B, T, H, dk, patt, seed + 7, vt_scratch, S.ctxv, stream));
+    IA_TRY(ia_relpos_attention_flash_lse(S.qkv, S.pl, L.pos_u, L.pos_v, lens, B, T, H, dk, patt, seed + 7, S.ctxv, S.lse, stream));
     IA_TRY(ia_gemm_bf16(S.ctxv, d, L.w_out, d, N, d, d, L.b_out, 0, p, seed + 3, 1.f, S.x1, d, S.x2, d, nullptr, 0, stream));
     // convolution module (train-mode BatchNorm: batch statistics, running statistics updated)
     IA_TRY(ia_layernorm(S.x2, d, N, d, L.ln_conv_g, L.ln_conv_b, L.ln_eps, nullptr, 0, nullptr, nullptr, S.y3, d, stream));

@@ -3,8 +3,8 @@
 Forward = the fused no-autograd path of encoder.ConformerLayer.forward_fast (GEMMs with fused epilogues, LayerNorm,
 GLU+depthwise conv+BatchNorm+SiLU, rel-pos attention) keeping the intermediates the backward needs; backward = manual
 chain rule: bf16 library GEMMs for the data gradients, batched split-K GEMMs for the weight gradients, and the
-kernels of csrc/encoder_bwd.hip for everything in between; the attention core's backward is csrc/attention.hip's row
-pass + batched GEMMs (ops/fast.relpos_attention_bwd).
+kernels of csrc/encoder_bwd.hip for everything in between; the attention core is the key-tiled pair
+csrc/attention_flash.hip / attention_flash_bwd.hip (any T, no [T,T] matrices in HBM).
 
 Semantics: ConformerLayer.forward, A/parts/submodules/conformer_modules.py:141-214 (bf16 projections, fp32 residual
 stream / norms / BatchNorm statistics), dropout masks are counter-based and regenerated in the backward.
@@ -82,7 +82,7 @@ def block_supported(layer, x2d, T):
     d = x2d.shape[-1]
     bn = layer.conv.batch_norm
     return (x2d.is_cuda and d % 64 == 0 and d <= 1024 and fast.bn_module_ok(bn) and 256 % (d // 4) == 0
-            and layer.conv.depthwise_conv.weight.shape[-1] <= 31 and fast.attention_supported(T, layer.self_attn.d_k))
+            and layer.conv.depthwise_conv.weight.shape[-1] <= 31 and fast.attention_flash_supported(T, layer.self_attn.d_k))
 
 
 class _ConformerBlockFn(torch.autograd.Function):
@@ -114,7 +114,8 @@ class _ConformerBlockFn(torch.autograd.Function):
         y2 = fast.layernorm(x1, layer.norm_self_att.weight, layer.norm_self_att.bias, layer.norm_self_att.eps)
         _, qkv = fast.gemm(y2, W["wqkv"], fast.f32_cat(att.linear_q.bias, att.linear_k.bias, att.linear_v.bias))
         _, pl = fast.gemm(pe, W["wpos"])
-        ctxv = fast.relpos_attention(qkv, pl, att.pos_bias_u, att.pos_bias_v, lens, B, T, att.h, att.d_k, patt, seed + 7)
+        ctxv, lse = fast.relpos_attention_flash(qkv, pl, att.pos_bias_u, att.pos_bias_v, lens, B, T, att.h, att.d_k, patt, seed + 7,
+                                                want_lse=True)
         x2, _ = fast.gemm(ctxv, W["wo"], att.linear_out.bias, dropout_p=p, seed=seed + 3, residual=x1, out_f32=new(),
                           want_bf16=False)
         # convolution module
@@ -136,7 +137,7 @@ class _ConformerBlockFn(torch.autograd.Function):
         fast.layernorm(x4, layer.norm_out.weight, layer.norm_out.bias, layer.norm_out.eps, out_f32=out, want_bf16=False)
         if not use_batch:
             raise RuntimeError("trainable fused block expects train-mode BatchNorm (batch statistics)")
-        ctx.S = dict(x0=x0, y1=y1, h1p=h1p, h1=h1, x1=x1, y2=y2, qkv=qkv, pl=pl, ctxv=ctxv, x2=x2, y3=y3, c2=c2, z=z, sums=sums,
+        ctx.S = dict(x0=x0, y1=y1, h1p=h1p, h1=h1, x1=x1, y2=y2, qkv=qkv, pl=pl, ctxv=ctxv, lse=lse, x2=x2, y3=y3, c2=c2, z=z, sums=sums,
                      c3=c3, x3=x3, y4=y4, h4p=h4p, h4=h4, x4=x4, W=W, pe=pe, lens=lens)
         ctx.meta = (layer, B, T, seed, p, pff1, pff2, patt, [n for n, _ in layer.named_parameters()],
                     [q.requires_grad for q in params], params)
@@ -214,8 +215,8 @@ class _ConformerBlockFn(torch.autograd.Function):
         # self-attention
         dB = _branch_grad(dx2, 1.0, p, seed + 3)
         dctx, G["self_attn.linear_out.weight"], G["self_attn.linear_out.bias"] = _lin_bwd(dB, S["ctxv"], W["wo"])
-        dqkv, dpl, du, dv = fast.relpos_attention_bwd(S["qkv"], S["pl"], att.pos_bias_u, att.pos_bias_v, S["lens"], S["ctxv"],
-                                                      dctx, B, T, att.h, att.d_k, patt, seed + 7)
+        dqkv, dpl, du, dv = fast.relpos_attention_flash_bwd(S["qkv"], S["pl"], att.pos_bias_u, att.pos_bias_v, S["lens"], S["ctxv"],
+                                                            dctx, S["lse"], B, T, att.h, att.d_k, patt, seed + 7)
         G["self_attn.pos_bias_u"], G["self_attn.pos_bias_v"] = du, dv
         dy, dWqkv, dbqkv = _lin_bwd(dqkv, S["y2"], W["wqkv"])
         for i, nm in enumerate(("q", "k", "v")):
@@ -261,7 +262,10 @@ def conformer_block(x2d, layer, lens, pe_bf16, B, T, seed):
     """x2d [B*T, d] f32 residual stream -> [B*T, d] f32 (autograd-connected to x2d and the block's parameters).
     pe_bf16: pad_pos_emb(pos_emb) (>= 2T-1 rows)."""
     if USE_NATIVE_BLOCKS and layer.training and fast.bn_sync_group(layer.conv.batch_norm) is None:
-        return conformer_block_native(x2d, layer, lens, pe_bf16, B, T, seed)
+        att = layer.self_attn
+        if _lib.lib().ia_conformer_block_supported(x2d.shape[-1], layer.feed_forward1.linear1.weight.shape[0], att.h,
+                                                   layer.conv.depthwise_conv.weight.shape[-1], T):
+            return conformer_block_native(x2d, layer, lens, pe_bf16, B, T, seed)
     return _ConformerBlockFn.apply(x2d, layer, lens, pe_bf16, B, T, seed, *list(layer.parameters()))
 
 
@@ -271,14 +275,14 @@ def conformer_block(x2d, layer, lens, pe_bf16, B, T, seed):
 # each: 4.5 ms of a 12 ms step on the host); here Python only carves two arenas and calls three functions.
 USE_NATIVE_BLOCKS = True
 
-_SAVED_FIELDS = ("y1", "h1p", "h1", "x1", "y2", "qkv", "pl", "ctxv", "x2", "y3", "c2", "z", "sums", "c3", "x3", "y4", "h4p", "h4", "x4")
+_SAVED_FIELDS = ("y1", "h1p", "h1", "x1", "y2", "qkv", "pl", "ctxv", "x2", "y3", "c2", "z", "sums", "c3", "x3", "y4", "h4p", "h4", "x4", "lse")
 
 
-def _saved_layout(N, d, dff, pos_rows):
+def _saved_layout(N, d, dff, pos_rows, H):
     """(field -> (byte offset, bytes)), total bytes: every buffer 256-byte aligned."""
     sizes = dict(y1=N * d * 2, h1p=N * dff * 2, h1=N * dff * 2, x1=N * d * 4, y2=N * d * 2, qkv=N * 3 * d * 2, pl=pos_rows * d * 2,
                  ctxv=N * d * 2, x2=N * d * 4, y3=N * d * 2, c2=N * 2 * d * 2, z=N * d * 4, sums=2 * d * 4, c3=N * d * 2,
-                 x3=N * d * 4, y4=N * d * 2, h4p=N * dff * 2, h4=N * dff * 2, x4=N * d * 4)
+                 x3=N * d * 4, y4=N * d * 2, h4p=N * dff * 2, h4=N * dff * 2, x4=N * d * 4, lse=N * H * 4)
     lay, o = {}, 0
     for f in _SAVED_FIELDS:
         lay[f] = (o, sizes[f])
@@ -374,7 +378,7 @@ class _ConformerBlockNativeFn(torch.autograd.Function):
             raise RuntimeError("trainable fused block expects train-mode BatchNorm (batch statistics)")
         bp = fast._block_params(layer)
         x0 = x.contiguous()
-        lay, nbytes = _saved_layout(N, d, rt.dff, pe.shape[0])
+        lay, nbytes = _saved_layout(N, d, rt.dff, pe.shape[0], layer.self_attn.h)
         arena = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         saved = _lib.BlockSaved()
         base = arena.data_ptr()
@@ -419,7 +423,7 @@ class _ConformerBlockNativeFn(torch.autograd.Function):
         st = L.ia_conformer_block_bwd_a(ctypes.addressof(bp), ctypes.addressof(saved), ctypes.addressof(rt.grads), _ptr(dout), _ptr(lens), B, T,
                                         int(seed) & 0xFFFFFFFF, _ptr(ws), n_ws, ctypes.addressof(dx2_p), ctypes.addressof(dctx_p), sp)
         _lib.check(st, "ia_conformer_block_bwd_a")
-        # attention core: row pass + batched contractions (ops/fast.relpos_attention_bwd) on views of the saved arena / workspace
+        # attention core: key-tiled backward (ops/fast.relpos_attention_flash_bwd) on views of the saved arena / workspace
         def view(buf, off, shape, dtype):
             n = 1
             for s_ in shape:
@@ -429,9 +433,10 @@ class _ConformerBlockNativeFn(torch.autograd.Function):
         pl = view(arena, lay["pl"][0], (pe.shape[0], d), torch.bfloat16)
         ctxv = view(arena, lay["ctxv"][0], (N, d), torch.bfloat16)
         dctx = view(ws, dctx_p.value - ws.data_ptr(), (N, d), torch.bfloat16)
+        lse = view(arena, lay["lse"][0], (B * att.h, T), torch.float32)
         patt = float(att.dropout_rate)
-        dqkv, dpl, du, dv = fast.relpos_attention_bwd(qkv, pl, att.pos_bias_u, att.pos_bias_v, lens, ctxv, dctx, B, T, att.h, att.d_k,
-                                                      patt, seed + 7, dub_out=(rt.pos_u, rt.pos_v))
+        dqkv, dpl, du, dv = fast.relpos_attention_flash_bwd(qkv, pl, att.pos_bias_u, att.pos_bias_v, lens, ctxv, dctx, lse, B, T, att.h,
+                                                            att.d_k, patt, seed + 7, dub_out=(rt.pos_u, rt.pos_v))
         dx0 = torch.empty(N, d, dtype=torch.float32, device=dev)
         table, n_rows = rt.add_table() if DIRECT_ACCUMULATE else (None, 0)
         st = L.ia_conformer_block_bwd_b(ctypes.addressof(bp), ctypes.addressof(saved), ctypes.addressof(rt.grads), _ptr(x0), _ptr(pe), pe.shape[0],
