@@ -292,16 +292,16 @@ int ia_relpos_attention_flash_lse(const void* qkv, const void* pos_proj, const f
                                   float* lse, ia_stream_t stream);
 /* Key-tiled backward of the same attention core (csrc/attention_flash_bwd.hip; autograd of multi_head_attention.py:197-250):
  * no [T,T] matrices in HBM.  In: the forward's qkv / pos_proj / biases / lens / ctx / lse, dctx [B*T, d] bf16 and the
- * forward's dropout p / seed.  Out: dqkv [B*T, 3d] bf16 (every row written), dbias_u / dbias_v [H*dk] f32, and the two
- * operands of the position-projection gradient  dpos[h][r] = sum_rows dBand[h][row][pad0 + r] * QvHM[h][row][:]  (a TN GEMM,
- * ia_gemm_tn_bf16 per head):  dBand [H, B*T, Rs] bf16 (zeroed by this call), QvHM [H, B*T, 64] bf16 (q + pos_bias_v, zero
- * padded to 64).  Scratch: Dbuf [B*H*T] f32, part [ia_relpos_attention_flash_bwd_part_elems()] f32.  Rs, pad0 from _dims. */
+ * forward's dropout p / seed.  Out: dqkv [B*T, 3d] bf16 (every row written), dpl [pl_rows, d] bf16 (rows >= 2T-1 zero),
+ * dbias_u / dbias_v [H*dk] f32.  Scratch: dBand [H, B*T, Rs] bf16 (the band-skewed score gradient on the absolute
+ * relative-position axis, Rs from _dims), QvHM [H, B*T, 64] bf16 (q + pos_bias_v head-major), ws f32 x _ws_elems: the
+ * position-projection gradient is the TN GEMM dBand_h^T QvHM_h per head (ia_gemm_tn_bf16), issued by this call. */
 int ia_relpos_attention_flash_bwd_dims(int T, int* Rs, int* pad0);
-int64_t ia_relpos_attention_flash_bwd_part_elems(int B, int T, int H, int dk);
+int64_t ia_relpos_attention_flash_bwd_ws_elems(int B, int T, int H, int dk);
 int ia_relpos_attention_flash_bwd(const void* qkv, const void* pos_proj, const float* bias_u, const float* bias_v,
                                   const int64_t* lens, const void* ctx, const void* dctx, const float* lse, int B, int T, int H,
-                                  int dk, float dropout_p, unsigned seed, void* dqkv, void* dBand, void* QvHM, float* Dbuf,
-                                  float* part, float* dbias_u, float* dbias_v, ia_stream_t stream);
+                                  int dk, float dropout_p, unsigned seed, void* dqkv, void* dpl, int pl_rows, float* dbias_u,
+                                  float* dbias_v, void* dBand, void* QvHM, float* ws, ia_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Persistent single-layer LSTM: the recurrence of the RNNT prediction network (RNNTDecoder.predict

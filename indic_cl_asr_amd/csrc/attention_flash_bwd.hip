@@ -287,9 +287,10 @@ __global__ __launch_bounds__(FB_THREADS, 2) void relpos_flash_bwd_q_kernel(FbArg
                 *reinterpret_cast<uint4*>(sB + (frow * FB_SB_LD + 104) * 2) = n1;
             }
             if (fvalid) {
-                const int gcol = T - 16 - iw + j0 + a.pad0 + fch * 8;   // multiple of 8
-                *reinterpret_cast<uint4*>(brow + gcol) = v0;
-                *reinterpret_cast<uint4*>(brow + gcol + 8) = v1;
+                // multiple of 8; negative only in a partial last wave (T - iw < 16), whose leading band columns are all zero
+                const int gcol = T - 16 - iw + j0 + a.pad0 + fch * 8;
+                if (gcol >= 0) *reinterpret_cast<uint4*>(brow + gcol) = v0;
+                if (gcol + 8 >= 0) *reinterpret_cast<uint4*>(brow + gcol + 8) = v1;
             }
         }
         __syncthreads();
@@ -560,6 +561,26 @@ __global__ __launch_bounds__(FB_THREADS, 2) void relpos_flash_bwd_kv_kernel(FbAr
     }
 }
 
+// dpl[r][h*dk + e] = bf16(dpos[h][pad0 + r][e]) for r < R = 2T-1, zero rows beyond (dpos rows are [Rs*64 | Rs] f32 blocks:
+// the TN GEMM's weight and bias gradient outputs, the latter unused)
+__global__ __launch_bounds__(256) void fb_dpos_pack_kernel(const float* __restrict__ dpos, int H, int Rs, int pad0, int R, int dk,
+                                                           int rows, __bf16* __restrict__ out) {
+    const int d = H * dk, q = dk / 4;
+    const int64_t total = (int64_t)rows * H * q;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int e4 = (int)(i % q);
+        const int h = (int)((i / q) % H);
+        const int r = (int)(i / ((int64_t)q * H));
+        union { uint2 u; __bf16 e[4]; } o;
+        o.u = make_uint2(0, 0);
+        if (r < R) {
+            const float4 v = *reinterpret_cast<const float4*>(dpos + (size_t)h * ((size_t)Rs * 64 + Rs) + (size_t)(pad0 + r) * 64 + e4 * 4);
+            o.e[0] = (__bf16)v.x; o.e[1] = (__bf16)v.y; o.e[2] = (__bf16)v.z; o.e[3] = (__bf16)v.w;
+        }
+        *reinterpret_cast<uint2*>(out + (size_t)r * d + h * dk + e4 * 4) = o.u;
+    }
+}
+
 }  // namespace
 
 extern "C" int ia_relpos_attention_flash_bwd_dims(int T, int* Rs, int* pad0) {
@@ -572,29 +593,46 @@ extern "C" int ia_relpos_attention_flash_bwd_dims(int T, int* Rs, int* pad0) {
     return IA_OK;
 }
 
-extern "C" int64_t ia_relpos_attention_flash_bwd_part_elems(int B, int T, int H, int dk) {
+namespace {
+struct FbWs { int64_t part, D, dpos, tn, total; };
+inline FbWs fb_ws_layout(int B, int T, int H, int dk) {
+    int rs, p0;
+    ia_relpos_attention_flash_bwd_dims(T, &rs, &p0);
+    FbWs w;
+    auto up = [](int64_t x) { return (x + 63) / 64 * 64; };
+    w.part = 0;
+    w.D = up((int64_t)B * ((T + 63) / 64) * 2 * H * dk);
+    w.dpos = w.D + up((int64_t)B * H * T);
+    w.tn = w.dpos + up((int64_t)H * ((int64_t)rs * 64 + rs));
+    w.total = w.tn + up(ia_gemm_tn_scratch_elems(B * T, rs, 64));
+    return w;
+}
+}  // namespace
+
+extern "C" int64_t ia_relpos_attention_flash_bwd_ws_elems(int B, int T, int H, int dk) {
     if (B <= 0 || T <= 0 || H <= 0 || dk <= 0) return 0;
-    return (int64_t)B * ((T + 63) / 64) * 2 * H * dk;
+    return fb_ws_layout(B, T, H, dk).total;
 }
 
 extern "C" int ia_relpos_attention_flash_bwd(const void* qkv, const void* pos_proj, const float* bias_u, const float* bias_v,
                                              const int64_t* lens, const void* ctx, const void* dctx, const float* lse, int B,
-                                             int T, int H, int dk, float dropout_p, unsigned seed, void* dqkv, void* dBand,
-                                             void* QvHM, float* Dbuf, float* part, float* dbias_u, float* dbias_v,
+                                             int T, int H, int dk, float dropout_p, unsigned seed, void* dqkv, void* dpl,
+                                             int pl_rows, float* dbias_u, float* dbias_v, void* dBand, void* QvHM, float* ws,
                                              ia_stream_t stream) {
-    if (!qkv || !pos_proj || !bias_u || !bias_v || !lens || !ctx || !dctx || !lse || !dqkv || !dBand || !QvHM || !Dbuf || !part ||
-        !dbias_u || !dbias_v || B <= 0 || T <= 0 || H <= 0)
+    if (!qkv || !pos_proj || !bias_u || !bias_v || !lens || !ctx || !dctx || !lse || !dqkv || !dpl || !dBand || !QvHM || !ws ||
+        !dbias_u || !dbias_v || B <= 0 || T <= 0 || H <= 0 || pl_rows < 2 * T - 1)
         return IA_INVALID_VALUE;
     if (!ia_relpos_attention_flash_supported(T, dk)) return IA_UNSUPPORTED;
-    if (T < 16) return IA_UNSUPPORTED;                           // (band column origin T - 16 - iw must not be negative for wave 0)
     if (dropout_p < 0.f || dropout_p >= 1.f) return IA_INVALID_VALUE;
     if (!ia_is_aligned(qkv, 16) || !ia_is_aligned(pos_proj, 16) || !ia_is_aligned(ctx, 8) || !ia_is_aligned(dctx, 8) ||
-        !ia_is_aligned(dqkv, 8) || !ia_is_aligned(dBand, 16) || !ia_is_aligned(QvHM, 16))
+        !ia_is_aligned(dqkv, 8) || !ia_is_aligned(dBand, 16) || !ia_is_aligned(QvHM, 16) || !ia_is_aligned(ws, 16) ||
+        !ia_is_aligned(dpl, 8))
         return IA_INVALID_VALUE;
+    const FbWs w = fb_ws_layout(B, T, H, dk);
     FbArgs a;
     a.qkv = (const __bf16*)qkv; a.pl = (const __bf16*)pos_proj; a.bias_u = bias_u; a.bias_v = bias_v; a.lens = lens;
     a.ctx = (const __bf16*)ctx; a.dctx = (const __bf16*)dctx; a.lse = lse; a.dqkv = (__bf16*)dqkv; a.dBand = (__bf16*)dBand;
-    a.QvHM = (__bf16*)QvHM; a.D = Dbuf; a.part = part; a.B = B; a.T = T; a.H = H; a.dk = dk;
+    a.QvHM = (__bf16*)QvHM; a.D = ws + w.D; a.part = ws + w.part; a.B = B; a.T = T; a.H = H; a.dk = dk;
     int rs, p0;
     ia_relpos_attention_flash_bwd_dims(T, &rs, &p0);
     a.Rs = rs; a.pad0 = p0;
@@ -623,7 +661,21 @@ extern "C" int ia_relpos_attention_flash_bwd(const void* qkv, const void* pos_pr
         hipLaunchKernelGGL((relpos_flash_bwd_kv_kernel<false>), dim3(grid), dim3(FB_THREADS), FB_KV_LDS, st, a);
     }
     IA_RETURN_IF_LAUNCH_FAILED();
-    ia_partials_finish(part, B * nt, 2 * H * dk, H * dk, dbias_u, dbias_v, st);
+    ia_partials_finish(a.part, B * nt, 2 * H * dk, H * dk, dbias_u, dbias_v, st);
+    IA_RETURN_IF_LAUNCH_FAILED();
+    // position-projection gradient: per head dpos_h [Rs, 64] = dBand_h^T (q+v)_h over the B*T rows (split-K TN GEMM), then
+    // the band columns pad0 .. pad0 + 2T-2 go to dpl [pl_rows, d] bf16
+    float* dpos = ws + w.dpos;
+    for (int h = 0; h < H; ++h) {
+        float* o = dpos + (size_t)h * ((size_t)rs * 64 + rs);
+        const int rc = ia_gemm_tn_bf16((const __bf16*)dBand + (size_t)h * B * T * rs, rs, (const __bf16*)QvHM + (size_t)h * B * T * 64, 64,
+                                       B * T, rs, 64, o, o + (size_t)rs * 64, ws + w.tn, stream);
+        if (rc != IA_OK) return rc;
+    }
+    const int64_t items = (int64_t)pl_rows * H * (dk / 4);
+    const int64_t blocks = (items + 255) / 256;
+    hipLaunchKernelGGL(fb_dpos_pack_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, (const float*)dpos, H, rs,
+                       p0, 2 * T - 1, dk, pl_rows, (__bf16*)dpl);
     IA_RETURN_IF_LAUNCH_FAILED();
     return IA_OK;
 }

@@ -254,28 +254,25 @@ def attention_flash_bwd_dims(T):
 def relpos_attention_flash_bwd(qkv, pl, bias_u, bias_v, lens, ctx, dctx, lse, B, T, H, dk, dropout_p=0.0, seed=0, dub_out=None):
     """Backward of relpos_attention_flash (csrc/attention_flash_bwd.hip): qkv [B*T,3d], pl [>=2T-1,d], ctx / dctx [B*T,d] bf16,
     lse [B*H,T] f32 -> (dqkv [B*T,3d] bf16, dpl [pl rows, d] bf16, dbias_u [H,dk] f32, dbias_v [H,dk] f32).  Two key-tiled
-    kernels (query-owner: dq, bias gradients, band-skewed dS; key-owner: dK, dV) + one TN GEMM per head for dpl."""
+    kernels (query-owner: dq, bias gradients, band-skewed dS; key-owner: dK, dV) + one TN GEMM per head for dpl, all issued
+    by one C call."""
     L = _lib.lib()
     dev = qkv.device
     d = H * dk
     bf = torch.bfloat16
     Rs, pad0 = attention_flash_bwd_dims(T)
     dqkv = torch.empty(B * T, 3 * d, dtype=bf, device=dev)
-    dBand = torch.empty(H, B * T, Rs, dtype=bf, device=dev)
-    QvHM = torch.empty(H, B * T, 64, dtype=bf, device=dev)
-    Dbuf = torch.empty(B * H * T, dtype=torch.float32, device=dev)
-    part = torch.empty(L.ia_relpos_attention_flash_bwd_part_elems(B, T, H, dk), dtype=torch.float32, device=dev)
+    dpl = torch.empty_like(pl)
+    dBand = torch.empty(H * B * T * Rs, dtype=bf, device=dev)
+    QvHM = torch.empty(H * B * T * 64, dtype=bf, device=dev)
+    ws = torch.empty(L.ia_relpos_attention_flash_bwd_ws_elems(B, T, H, dk), dtype=torch.float32, device=dev)
     dub = dub_out if dub_out is not None else torch.empty(2, H, dk, dtype=torch.float32, device=dev)
     dctx = dctx.contiguous()
     st = L.ia_relpos_attention_flash_bwd(_lib.ptr(qkv), _lib.ptr(pl), _lib.ptr(bias_u), _lib.ptr(bias_v), _lib.ptr(lens), _lib.ptr(ctx),
                                          _lib.ptr(dctx), _lib.ptr(lse), B, T, H, dk, float(dropout_p), int(seed) & 0xFFFFFFFF,
-                                         _lib.ptr(dqkv), _lib.ptr(dBand), _lib.ptr(QvHM), _lib.ptr(Dbuf), _lib.ptr(part),
-                                         _lib.ptr(dub[0]), _lib.ptr(dub[1]), _lib.stream_ptr())
+                                         _lib.ptr(dqkv), _lib.ptr(dpl), pl.shape[0], _lib.ptr(dub[0]), _lib.ptr(dub[1]),
+                                         _lib.ptr(dBand), _lib.ptr(QvHM), _lib.ptr(ws), _lib.stream_ptr())
     _lib.check(st, "ia_relpos_attention_flash_bwd")
-    R = 2 * T - 1
-    dpos = torch.stack([gemm_tn(dBand[h], QvHM[h])[0] for h in range(H)])      # [H, Rs, 64] f32
-    dpl = torch.zeros_like(pl)
-    dpl[:R] = dpos[:, pad0:pad0 + R, :dk].permute(1, 0, 2).reshape(R, d)
     return dqkv, dpl, dub[0], dub[1]
 
 
