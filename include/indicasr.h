@@ -221,6 +221,16 @@ int ia_gemm_bf16(const void* A, int lda, const void* W, int ldw, int M, int N, i
  *                       to [N,3,3,C]), out [B,T2,F2,N] bf16.  C % 64 == 0.
  *   The final Linear(C*F2 -> d) is ia_gemm_bf16 on the [B*T2, F2*N] view with the weight's columns permuted from the
  *   reference's (c,f) order to (f,c). */
+/* fp8 (OCP e4m3) projections of the frozen prefix (csrc/gemm_fp8.hip; BASELINE configs[4] "fp8 MFMA"; no reference
+ * semantics -- tolerance vs the fp32 oracle stated in tests/test_fp8_gpu.py):
+ *   ia_quantize_fp8_rows   q [M, ldq] e4m3 = x / scale[m], scale[m] = amax(row m) / 448 (1 for a zero row); x bf16 or f32
+ *                          [M, K] (row stride ld), K % 8 == 0, ldq % 16 == 0 (padding bytes zeroed)
+ *   ia_gemm_fp8            out = alpha*dropout(act((Aq Wq^T) o a_scale[m] o w_scale[n] + bias)) + R : the operator of
+ *                          ia_gemm_bf16 (same epilogue / dropout mask), operands e4m3 with per-row scales; K % 16 == 0. */
+int ia_quantize_fp8_rows(const void* x, int is_f32, int ld, int64_t M, int K, void* q, int ldq, float* scale, ia_stream_t stream);
+int ia_gemm_fp8(const void* Aq, int lda, const float* a_scale, const void* Wq, int ldw, const float* w_scale, int M, int N, int K,
+                const float* bias, int act, float dropout_p, unsigned seed, float alpha, const float* R, int ldr, float* outF,
+                int ldof, void* outH, int ldoh, ia_stream_t stream);
 int ia_subsample_conv1(const float* feats, int B, int Fm, int Tm, int C, const float* w1, const float* b1, void* out,
                        ia_stream_t stream);
 int ia_subsample_conv2(const void* in_cl, int B, int T1, int F1, int C, const void* w2r, const float* b2, int N, void* out,

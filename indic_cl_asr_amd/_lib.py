@@ -65,6 +65,8 @@ SIGNATURES = {
     "ia_relpos_attention_flash_bwd_ws_elems": (_i64, [_i, _i, _i, _i]),
     "ia_relpos_attention_flash_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _c.c_uint, _vp, _vp, _i, _vp,
                                            _vp, _vp, _vp, _vp, _vp]),
+    "ia_quantize_fp8_rows": (_i, [_vp, _i, _i, _i64, _i, _vp, _i, _vp, _vp]),
+    "ia_gemm_fp8": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _i, _f, _c.c_uint, _f, _vp, _i, _vp, _i, _vp, _i, _vp]),
     "ia_cast_pad_bf16": (_i, [_vp, _i, _i64, _i, _vp, _i, _vp]),
     "ia_rnnt_lattice": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _sz, _vp]),
     "ia_joint_backward_g": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _f, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp,

@@ -57,6 +57,9 @@ class ModelConfig:
     clamp: float = -1.0
     # MI355X compute dtype for the dense projections ("bf16" | "fp32"); losses, norms and softmax stay fp32
     compute_dtype: str = "bf16"
+    # BASELINE configs[4] ("fp8 MFMA"): the projections of the frozen / no-grad Conformer blocks run on e4m3 operands with
+    # per-row scales (csrc/gemm_fp8.hip); everything trainable, the joint and the losses stay as with compute_dtype "bf16"
+    fp8_frozen_prefix: bool = False
 
     @property
     def d_ff(self):

@@ -170,7 +170,11 @@ class ConformerLayer(nn.Module):
         tr = self.training
         p = self.dropout.p if tr else 0.0
         ff1, ff2, att, cv = self.feed_forward1, self.feed_forward2, self.self_attn, self.conv
-        ffn_fused = fast.ffn_fused_supported(d, ff1.linear1.weight.shape[0])
+        fp8 = bool(getattr(self, "fp8_projections", False))
+        # projections: bf16 MFMA GEMM, or e4m3 operands with per-row scales (activations quantised per call)
+        G = fast.gemm_fp8 if fp8 else fast.gemm
+        Wt = fast.fp8_shadow if fp8 else fast.bf16_shadow
+        ffn_fused = (not fp8) and fast.ffn_fused_supported(d, ff1.linear1.weight.shape[0])
         # 1/2 FFN
         if ffn_fused:   # LayerNorm + both projections + residual in one row-resident launch (csrc/ffn_fused.hip)
             fast.ffn_fused(x, self.norm_feed_forward1, ff1.linear1, ff1.linear2, self.fc_factor,
@@ -178,13 +182,13 @@ class ConformerLayer(nn.Module):
         else:
             if y is None:
                 y = fast.layernorm(x, self.norm_feed_forward1.weight, self.norm_feed_forward1.bias, self.norm_feed_forward1.eps)
-            _, h = fast.gemm(y, fast.bf16_shadow(ff1.linear1.weight), ff1.linear1.bias, act=1,
+            _, h = G(y, Wt(ff1.linear1.weight), ff1.linear1.bias, act=1,
                              dropout_p=ff1.dropout.p if tr else 0.0, seed=seed + 1)
-            fast.gemm(h, fast.bf16_shadow(ff1.linear2.weight), ff1.linear2.bias, dropout_p=p, seed=seed + 2, alpha=self.fc_factor,
+            G(h, Wt(ff1.linear2.weight), ff1.linear2.bias, dropout_p=p, seed=seed + 2, alpha=self.fc_factor,
                       residual=x, out_f32=x, want_bf16=False)
         # self-attention
         y = fast.layernorm(x, self.norm_self_att.weight, self.norm_self_att.bias, self.norm_self_att.eps)
-        _, qkv = fast.gemm(y, fast.bf16_shadow(att.linear_q.weight, att.linear_k.weight, att.linear_v.weight),
+        _, qkv = G(y, Wt(att.linear_q.weight, att.linear_k.weight, att.linear_v.weight),
                            fast.f32_cat(att.linear_q.bias, att.linear_k.bias, att.linear_v.bias))
         _, pl = fast.gemm(pos_emb, fast.bf16_shadow(att.linear_pos.weight))
         if fast.attention_flash_supported(T, att.d_k):
@@ -199,14 +203,14 @@ class ConformerLayer(nn.Module):
             ctx = ops.rel_pos_attention(q, k, v, pl.view(-1, att.h, att.d_k).transpose(0, 1), att.pos_bias_u,
                                         att.pos_bias_v, lens, att.dropout_rate, tr)
             ctx = ctx.transpose(1, 2).reshape(B * T, d).contiguous()
-        fast.gemm(ctx, fast.bf16_shadow(att.linear_out.weight), att.linear_out.bias, dropout_p=p, seed=seed + 3,
+        G(ctx, Wt(att.linear_out.weight), att.linear_out.bias, dropout_p=p, seed=seed + 3,
                   residual=x, out_f32=x, want_bf16=False)
         # convolution module
         y = fast.layernorm(x, self.norm_conv.weight, self.norm_conv.bias, self.norm_conv.eps)
-        _, c2 = fast.gemm(y, fast.bf16_shadow(cv.pointwise_conv1.weight), cv.pointwise_conv1.bias)
+        _, c2 = G(y, Wt(cv.pointwise_conv1.weight), cv.pointwise_conv1.bias)
         c3 = fast.glu_dwconv_bn_silu_fast(c2, lens, B, T, d, cv.depthwise_conv.weight, cv.depthwise_conv.bias,
                                           cv.batch_norm, tr)
-        fast.gemm(c3, fast.bf16_shadow(cv.pointwise_conv2.weight), cv.pointwise_conv2.bias, dropout_p=p, seed=seed + 4,
+        G(c3, Wt(cv.pointwise_conv2.weight), cv.pointwise_conv2.bias, dropout_p=p, seed=seed + 4,
                   residual=x, out_f32=x, want_bf16=False)
         # 1/2 FFN
         if ffn_fused:   # ... and norm_out in the same launch
@@ -214,9 +218,9 @@ class ConformerLayer(nn.Module):
                            ff2.dropout.p if tr else 0.0, seed + 5, p, seed + 6, ln2=self.norm_out)
             return x, None
         y = fast.layernorm(x, self.norm_feed_forward2.weight, self.norm_feed_forward2.bias, self.norm_feed_forward2.eps)
-        _, h = fast.gemm(y, fast.bf16_shadow(ff2.linear1.weight), ff2.linear1.bias, act=1,
+        _, h = G(y, Wt(ff2.linear1.weight), ff2.linear1.bias, act=1,
                          dropout_p=ff2.dropout.p if tr else 0.0, seed=seed + 5)
-        fast.gemm(h, fast.bf16_shadow(ff2.linear2.weight), ff2.linear2.bias, dropout_p=p, seed=seed + 6, alpha=self.fc_factor,
+        G(h, Wt(ff2.linear2.weight), ff2.linear2.bias, dropout_p=p, seed=seed + 6, alpha=self.fc_factor,
                   residual=x, out_f32=x, want_bf16=False)
         # norm_out (+ the next block's first LayerNorm chained in registers)
         if next_ln is not None:
@@ -332,6 +336,11 @@ class ConformerEncoder(nn.Module):
         # (SyncBatchNorm across more than one rank exchanges the BatchNorm sums between two launches of every block: the
         #  per-op path below does that; one rank, or plain BatchNorm: the native executor)
         sync = any(fast.bn_sync_group(l.conv.batch_norm) is not None for l in self.layers[:n_fast])
+        fp8 = bool(getattr(self.cfg, "fp8_frozen_prefix", False)) and d % 16 == 0
+        for l in self.layers[:n_fast]:
+            l.fp8_projections = fp8
+        if fp8:
+            sync = True   # (the native executor and the fused feed-forward kernel are bf16: per-op path below)
         if ((fast.attention_flash_supported(T, l0.self_attn.d_k) or fast.attention_supported(T, l0.self_attn.d_k)) and bn_ok
                 and same_mode and not sync):
             # native executor: one C call enqueues the 14 kernels of every block (csrc/block_exec.hip)

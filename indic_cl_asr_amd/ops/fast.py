@@ -124,6 +124,42 @@ def gemm(a_bf16, w_bf16, bias=None, act=0, dropout_p=0.0, seed=0, alpha=1.0, res
     return out_f32, outH
 
 
+def quantize_fp8_rows(x):
+    """x [M,K] bf16 or f32 (K % 8 == 0) -> (q [M, K16] e4m3 bytes, scale [M] f32): x ~ scale[m] * q  (csrc/gemm_fp8.hip)."""
+    M, K = x.shape
+    ldq = (K + 15) // 16 * 16
+    q = torch.empty(M, ldq, dtype=torch.uint8, device=x.device)
+    sc = torch.empty(M, dtype=torch.float32, device=x.device)
+    st = _lib.lib().ia_quantize_fp8_rows(_lib.ptr(x), int(x.dtype == torch.float32), x.stride(0), M, K, _lib.ptr(q), ldq,
+                                         _lib.ptr(sc), _lib.stream_ptr())
+    _lib.check(st, "ia_quantize_fp8_rows")
+    return q, sc
+
+
+def fp8_shadow(*params):
+    """(e4m3 rows, per-row scales) of the concatenated weights, cached per parameter version like bf16_shadow."""
+    def make():
+        w = torch.cat([p.detach().reshape(p.shape[0], -1).float() for p in params], 0).contiguous()
+        return quantize_fp8_rows(w)
+    return _cached(("fp8",) + tuple(id(p) for p in params), params, make)
+
+
+def gemm_fp8(a, wq_ws, bias=None, act=0, dropout_p=0.0, seed=0, alpha=1.0, residual=None, out_f32=None, want_bf16=True):
+    """gemm() with e4m3 operands: `a` [M,K] bf16 / f32 is quantised per row on the fly, wq_ws = fp8_shadow(weights)."""
+    wq, ws = wq_ws
+    M, K = a.shape
+    N = wq.shape[0]
+    aq, asc = quantize_fp8_rows(a)
+    outH = torch.empty(M, N, dtype=torch.bfloat16, device=a.device) if want_bf16 else None
+    st = _lib.lib().ia_gemm_fp8(_lib.ptr(aq), aq.stride(0), _lib.ptr(asc), _lib.ptr(wq), wq.stride(0), _lib.ptr(ws), M, N,
+                                aq.shape[1], _lib.ptr(bias), int(act), float(dropout_p), int(seed) & 0xFFFFFFFF, float(alpha),
+                                _lib.ptr(residual), residual.stride(0) if residual is not None else 0,
+                                _lib.ptr(out_f32), out_f32.stride(0) if out_f32 is not None else 0, _lib.ptr(outH), N,
+                                _lib.stream_ptr())
+    _lib.check(st, "ia_gemm_fp8")
+    return out_f32, outH
+
+
 def layernorm(x_f32, g1, b1, eps=1e-5, out_f32=None, g2=None, b2=None, want_bf16=True):
     N, d = x_f32.shape
     outH = torch.empty(N, d, dtype=torch.bfloat16, device=x_f32.device) if want_bf16 else None

@@ -1,0 +1,93 @@
+"""csrc/gemm_fp8.hip: e4m3 projections with per-row scales (BASELINE configs[4] names "fp8 MFMA" for Conformer-large).
+The reference has no fp8 semantics (its AMP is fp16 autocast): the kernels are checked against fp64 on the
+SAME quantised operands (exact up to f32 accumulation), the quantiser against torch's float8_e4m3fn rounding, and the
+model-level effect against the fp32 oracle with the tolerance stated below."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _deq(q, scale, K):
+    return q[:, :K].contiguous().view(torch.float8_e4m3fn).double() * scale.double()[:, None]
+
+
+@pytest.mark.parametrize("M,K,dtype", [(300, 256, torch.bfloat16), (64, 144, torch.float32), (1000, 2048, torch.bfloat16)])
+def test_row_quantiser_matches_e4m3_rounding(M, K, dtype):
+    from indic_cl_asr_amd.ops import fast
+    g = torch.Generator().manual_seed(M + K)
+    x = (torch.randn(M, K, generator=g) * torch.rand(M, 1, generator=g) * 3).to(dtype).cuda()
+    x[5] = 0                                                                   # an all-zero row
+    q, s = fast.quantize_fp8_rows(x)
+    amax = x.float().abs().amax(1)
+    ref_s = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+    assert torch.allclose(s, ref_s, rtol=1e-6)
+    ref_q = (x.float() / s[:, None]).to(torch.float8_e4m3fn)
+    got = q[:, :K].contiguous().view(torch.float8_e4m3fn)
+    diff = (got.float() - ref_q.float()).abs()
+    # round-to-nearest-even on both sides; the division vs multiply-by-reciprocal may flip a tie: at most one e4m3 step, rarely
+    assert (diff > 0).float().mean().item() < 2e-3
+    assert (diff <= 0.0626 * ref_q.float().abs() + 2 ** -9).all()
+    assert q[:, K:].abs().sum().item() == 0                                    # padding bytes
+    assert _deq(q, s, K)[5].abs().sum().item() == 0
+
+
+@pytest.mark.parametrize("M,N,K", [(12032 // 8, 768, 256), (500, 1024, 256), (333, 256, 1024), (200, 2048, 512), (96, 288, 144)])
+def test_fp8_gemm_is_exact_on_its_quantised_operands(M, N, K):
+    from indic_cl_asr_amd.ops import fast
+    if K % 16:
+        pytest.skip("K % 16")
+    g = torch.Generator().manual_seed(N + K)
+    a = (torch.randn(M, K, generator=g) * 0.7).bfloat16().cuda()
+    w = torch.nn.Parameter((torch.randn(N, K, generator=g) * 0.1).cuda())
+    bias = (torch.randn(N, generator=g) * 0.1).cuda()
+    res = torch.randn(M, N, generator=g).cuda()
+    aq, asc = fast.quantize_fp8_rows(a)
+    wq, wsc = fast.fp8_shadow(w)
+    ref = _deq(aq, asc, K) @ _deq(wq, wsc, K).t() + bias.double()
+    out = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    fast.gemm_fp8(a, (wq, wsc), bias, out_f32=out, want_bf16=False)
+    assert (out.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-5
+    # SiLU + scale + residual epilogue, bf16 output
+    ref2 = 0.5 * torch.nn.functional.silu(ref) + res.double()
+    out2 = torch.empty_like(out)
+    _, h = fast.gemm_fp8(a, (wq, wsc), bias, act=1, alpha=0.5, residual=res, out_f32=out2)
+    assert (out2.double() - ref2).abs().max().item() <= 2e-5 * ref2.abs().max().item() + 1e-5
+    assert (h.double() - ref2).abs().max().item() <= 5e-3 * ref2.abs().max().item()
+    # and against the unquantised product: e4m3 carries 3 mantissa bits (2^-4 relative per element, averaged over K)
+    full = a.double() @ w.detach().double().t() + bias.double()
+    rel = ((out.double() - full).norm() / full.norm()).item()
+    assert rel <= 0.05, rel
+
+
+def test_fp8_gemm_dropout_mask_is_the_bf16_gemms():
+    from indic_cl_asr_amd.ops import fast
+    M, N, K = 256, 512, 256
+    a = torch.randn(M, K).bfloat16().cuda()
+    w = torch.nn.Parameter(torch.randn(N, K).cuda() * 0.1)
+    _, h8 = fast.gemm_fp8(a, fast.fp8_shadow(w), dropout_p=0.25, seed=11)
+    _, h16 = fast.gemm(a, fast.bf16_shadow(w), dropout_p=0.25, seed=11)
+    assert torch.equal(h8 == 0, h16 == 0)
+
+
+def test_frozen_prefix_in_fp8_tracks_the_fp32_oracle():
+    """Conformer-medium dims, layers <= 12 frozen and run with e4m3 projections: the step's losses against the fp32 CPU oracle.
+    Tolerance: 3 mantissa bits per operand through 13 blocks move the encoder output by a few percent; the losses (sums over
+    ~10^5 lattice cells) are asserted within 3e-2 relative (observed value printed), the bf16 prefix within 1e-3."""
+    import test_parity_configs_gpu as P
+    o, m = P._pair('medium', freeze=12)
+    m.encoder.cfg.fp8_frozen_prefix = True          # (model_config('medium', fp8_frozen_prefix=True) on a fresh model)
+    batch = P._synth(2, 8.0, seed=21)
+    o.train(); m.train()
+    lo, mo = o.training_step(batch, ['hi'] * 2)
+    lp, mp = m.training_step(tuple(t.cuda() for t in batch), ['hi'] * 2)
+    lp.backward()
+    torch.cuda.synchronize()
+    assert getattr(m.encoder.layers[0], "fp8_projections", False) is True
+    errs = {k: abs(mp[k] - mo[k]) / abs(mo[k]) for k in ('train_rnnt_loss', 'train_ctc_loss', 'train_loss')}
+    print("fp8 prefix loss rel err", {k: f"{v:.2e}" for k, v in errs.items()})
+    for k, v in errs.items():
+        assert v <= 3e-2, (k, v)
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
