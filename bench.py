@@ -174,6 +174,7 @@ def main():
     ap.add_argument("--preset", default="medium")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--freeze", type=int, default=12, help="config.yaml model.freeze_encoder_till (-1: train everything)")
+    ap.add_argument("--fp8-prefix", action="store_true", help="e4m3 projections in the frozen prefix (BASELINE configs[4]; never the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-bs", type=int, default=4)
     args = ap.parse_args()
@@ -195,7 +196,7 @@ def main():
     from indic_cl_asr_amd.model import EncDecHybridRNNTCTCModel, freeze_layer
 
     torch.manual_seed(1234)
-    cfg = model_config(args.preset, compute_dtype=args.dtype)
+    cfg = model_config(args.preset, compute_dtype=args.dtype, fp8_frozen_prefix=bool(args.fp8_prefix))
     model = EncDecHybridRNNTCTCModel(cfg).to(dev)
     if args.freeze >= 0:
         freeze_layer(model, args.freeze)
@@ -292,7 +293,7 @@ def main():
             "metric": "utterances/sec (15 s @16 kHz) Conformer-M RNNT-CTC+EWC train step",
             "value": round(value, 3), "unit": "utterances/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype + ("+fp8 frozen prefix" if args.fp8_prefix else ""), "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: Conformer-{args.preset} (d={cfg.d_model}, {cfg.n_layers}L, "
                                    f"H={cfg.joint_hidden}) hybrid RNNT-CTC + EWC, bs={args.batch}/GPU x {args.seconds:g} s, "
                                    f"{args.dtype} projections, freeze_encoder_till={args.freeze}, 22x257 heads, "

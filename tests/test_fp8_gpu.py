@@ -29,7 +29,7 @@ def test_row_quantiser_matches_e4m3_rounding(M, K, dtype):
     diff = (got.float() - ref_q.float()).abs()
     # round-to-nearest-even on both sides; the division vs multiply-by-reciprocal may flip a tie: at most one e4m3 step, rarely
     assert (diff > 0).float().mean().item() < 2e-3
-    assert (diff <= 0.0626 * ref_q.float().abs() + 2 ** -9).all()
+    assert (diff <= 0.126 * ref_q.float().abs() + 2 ** -9).all()                 # one step (1/8 relative just above a power of two)
     assert q[:, K:].abs().sum().item() == 0                                    # padding bytes
     assert _deq(q, s, K)[5].abs().sum().item() == 0
 
@@ -49,12 +49,13 @@ def test_fp8_gemm_is_exact_on_its_quantised_operands(M, N, K):
     ref = _deq(aq, asc, K) @ _deq(wq, wsc, K).t() + bias.double()
     out = torch.empty(M, N, dtype=torch.float32, device="cuda")
     fast.gemm_fp8(a, (wq, wsc), bias, out_f32=out, want_bf16=False)
-    assert (out.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-5
+    # (the fp8 MFMA's f32 accumulation is not bit-IEEE: observed 2e-5 of the largest output)
+    assert (out.double() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item() + 1e-5
     # SiLU + scale + residual epilogue, bf16 output
     ref2 = 0.5 * torch.nn.functional.silu(ref) + res.double()
     out2 = torch.empty_like(out)
     _, h = fast.gemm_fp8(a, (wq, wsc), bias, act=1, alpha=0.5, residual=res, out_f32=out2)
-    assert (out2.double() - ref2).abs().max().item() <= 2e-5 * ref2.abs().max().item() + 1e-5
+    assert (out2.double() - ref2).abs().max().item() <= 1e-4 * ref2.abs().max().item() + 1e-5
     assert (h.double() - ref2).abs().max().item() <= 5e-3 * ref2.abs().max().item()
     # and against the unquantised product: e4m3 carries 3 mantissa bits (2^-4 relative per element, averaged over K)
     full = a.double() @ w.detach().double().t() + bias.double()
@@ -75,7 +76,7 @@ def test_fp8_gemm_dropout_mask_is_the_bf16_gemms():
 def test_frozen_prefix_in_fp8_tracks_the_fp32_oracle():
     """Conformer-medium dims, layers <= 12 frozen and run with e4m3 projections: the step's losses against the fp32 CPU oracle.
     Tolerance: 3 mantissa bits per operand through 13 blocks move the encoder output by a few percent; the losses (sums over
-    ~10^5 lattice cells) are asserted within 3e-2 relative (observed value printed), the bf16 prefix within 1e-3."""
+    ~10^5 lattice cells) are asserted within 5e-3 relative (observed 5e-4; the bf16 prefix: 1e-5)."""
     import test_parity_configs_gpu as P
     o, m = P._pair('medium', freeze=12)
     m.encoder.cfg.fp8_frozen_prefix = True          # (model_config('medium', fp8_frozen_prefix=True) on a fresh model)
@@ -89,5 +90,5 @@ def test_frozen_prefix_in_fp8_tracks_the_fp32_oracle():
     errs = {k: abs(mp[k] - mo[k]) / abs(mo[k]) for k in ('train_rnnt_loss', 'train_ctc_loss', 'train_loss')}
     print("fp8 prefix loss rel err", {k: f"{v:.2e}" for k, v in errs.items()})
     for k, v in errs.items():
-        assert v <= 3e-2, (k, v)
+        assert v <= 5e-3, (k, v)
     assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
