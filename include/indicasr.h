@@ -387,6 +387,14 @@ int ia_ctc_backward(const float* log_probs, const int64_t* targets, const int64_
  * ldy/ldx multiples of 8), tiles transposed on the fly by ds_read_b64_tr_b16, split-K partial tiles in `scratch`
  * (f32 x ia_gemm_tn_scratch_elems) + a finishing sum (one pass when db == dW + n*k).  n, k multiples of 8.  Replaces autograd's x^T @ dy of
  * nn.Linear / pointwise Conv1d in the trainable Conformer blocks. */
+/* Grouped form: up to 8 weight gradients in one GEMM launch + one finishing launch (a trainable block's projections:
+ * single launches are latency-bound).  n*k and n multiples of 4 per problem (n, k % 8 == 0); db may be NULL. */
+typedef struct ia_tn_problem {
+    const void* dY; const void* X; float* dW; float* db;
+    int ldy, ldx, M, n, k;
+} ia_tn_problem;
+int64_t ia_gemm_tn_grouped_scratch_elems(const ia_tn_problem* problems, int count);
+int ia_gemm_tn_bf16_grouped(const ia_tn_problem* problems, int count, float* scratch, ia_stream_t stream);
 int64_t ia_gemm_tn_scratch_elems(int M, int n, int k);
 int ia_gemm_tn_bf16(const void* dY, int ldy, const void* X, int ldx, int M, int n, int k, float* dW, float* db,
                     float* scratch, ia_stream_t stream);

@@ -37,6 +37,12 @@ class BlockSaved(_c.Structure):
                                            "c3", "x3", "y4", "h4p", "h4", "x4", "lse")]
 
 
+class TnProblem(_c.Structure):
+    """ia_tn_problem of include/indicasr.h (one weight gradient of a grouped TN GEMM launch)."""
+    _fields_ = [("dY", _c.c_void_p), ("X", _c.c_void_p), ("dW", _c.c_void_p), ("db", _c.c_void_p),
+                ("ldy", _c.c_int), ("ldx", _c.c_int), ("M", _c.c_int), ("n", _c.c_int), ("k", _c.c_int)]
+
+
 class BlockGrads(_c.Structure):
     """ia_block_grads of include/indicasr.h (where a trainable block's parameter gradients are written)."""
     _fields_ = [(n, _c.c_void_p) for n in (
@@ -67,6 +73,8 @@ SIGNATURES = {
                                            _vp, _vp, _vp, _vp, _vp]),
     "ia_quantize_fp8_rows": (_i, [_vp, _i, _i, _i64, _i, _vp, _i, _vp, _vp]),
     "ia_gemm_fp8": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _i, _f, _c.c_uint, _f, _vp, _i, _vp, _i, _vp, _i, _vp]),
+    "ia_gemm_tn_grouped_scratch_elems": (_i64, [_vp, _i]),
+    "ia_gemm_tn_bf16_grouped": (_i, [_vp, _i, _vp, _vp]),
     "ia_cast_pad_bf16": (_i, [_vp, _i, _i64, _i, _vp, _i, _vp]),
     "ia_rnnt_lattice": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _sz, _vp]),
     "ia_joint_backward_g": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _f, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp,

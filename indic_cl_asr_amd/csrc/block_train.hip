@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void multi_add_kernel(const AddRow* __restrict
 }
 
 struct BwdWs {   // workspace of the two backward calls (offsets in bytes)
-    size_t dxa, dxb, dB, dh, dhp, dy, dc3, dz, dG, Gm, dc2, dctx, wt, scr, total;
+    size_t dxa, dxb, dB, dB1, dB2, dh, dhp, dy, dc3, dz, dG, Gm, dc2, dctx, wt, scr, total;
 };
 
 size_t max3(size_t a, size_t b, size_t c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
@@ -85,7 +85,9 @@ BwdWs bwd_ws(int B, int T, int d, int d_ff, int ksz) {
     size_t o = 0;
     w.dxa = o;  o = up256(o + N * d * 4);          // residual-stream gradients ping-pong
     w.dxb = o;  o = up256(o + N * d * 4);
-    w.dB = o;   o = up256(o + N * d * 2);          // gradient entering a branch (bf16)
+    w.dB = o;   o = up256(o + N * d * 2);          // gradients entering the branches (bf16): kept until the grouped
+    w.dB1 = o;  o = up256(o + N * d * 2);          // weight-gradient launch at the end of each backward call
+    w.dB2 = o;  o = up256(o + N * d * 2);
     w.dh = o;   o = up256(o + N * d_ff * 2);
     w.dhp = o;  o = up256(o + N * d_ff * 2);
     w.dy = o;   o = up256(o + N * d * 2);
@@ -103,6 +105,18 @@ BwdWs bwd_ws(int B, int T, int d, int d_ff, int ksz) {
         scr = e > scr ? e : scr;
     }
     scr = max3(scr, (size_t)ia_bn_silu_bwd_scratch_elems((int64_t)N, d), (size_t)ia_dwconv_scratch_elems(B, T, d, ksz));
+    {   // the two grouped weight-gradient launches (shapes only: the planner does not look at the pointers)
+        const ia_tn_problem ga[5] = {{nullptr, nullptr, nullptr, nullptr, d, d_ff, (int)N, d, d_ff},
+                                     {nullptr, nullptr, nullptr, nullptr, d_ff, d, (int)N, d_ff, d},
+                                     {nullptr, nullptr, nullptr, nullptr, d, d, (int)N, d, d},
+                                     {nullptr, nullptr, nullptr, nullptr, 2 * d, d, (int)N, 2 * d, d},
+                                     {nullptr, nullptr, nullptr, nullptr, d, d, (int)N, d, d}};
+        const ia_tn_problem gb[4] = {{nullptr, nullptr, nullptr, nullptr, 3 * d, d, (int)N, 3 * d, d},
+                                     {nullptr, nullptr, nullptr, nullptr, d, d, (int)(N > (size_t)64 * 512 ? N : (size_t)64 * 512), d, d},   // (any row count: the split count saturates)
+                                     {nullptr, nullptr, nullptr, nullptr, d, d_ff, (int)N, d, d_ff},
+                                     {nullptr, nullptr, nullptr, nullptr, d_ff, d, (int)N, d_ff, d}};
+        scr = max3(scr, (size_t)ia_gemm_tn_grouped_scratch_elems(ga, 5), (size_t)ia_gemm_tn_grouped_scratch_elems(gb, 4));
+    }
     w.scr = o;  o = up256(o + scr * 4);
     w.total = o;
     return w;
@@ -116,6 +130,18 @@ int linear_bwd(const void* dY, const void* X, const void* W, int M, int n, int k
         IA_TRY(ia_gemm_bf16(dY, n, wt, n, M, k, n, nullptr, 0, 0.f, 0, 1.f, nullptr, 0, nullptr, 0, dX, k, stream));
     }
     return ia_gemm_tn_bf16(dY, n, X, k, M, n, k, dW, db, scr, stream);
+}
+
+// the same with the weight gradient deferred: the problem is appended to `grp` (launched together at the end of the call)
+int linear_bwd_deferred(const void* dY, const void* X, const void* W, int M, int n, int k, void* dX, float* dW, float* db, void* wt,
+                        ia_tn_problem* grp, int* ngrp, ia_stream_t stream) {
+    if (dX) {
+        IA_TRY(transpose_bf16(W, n, k, wt, (hipStream_t)stream));
+        IA_TRY(ia_gemm_bf16(dY, n, wt, n, M, k, n, nullptr, 0, 0.f, 0, 1.f, nullptr, 0, nullptr, 0, dX, k, stream));
+    }
+    grp[*ngrp] = ia_tn_problem{dY, X, dW, db, n, k, M, n, k};
+    ++*ngrp;
+    return IA_OK;
 }
 
 }  // namespace
@@ -182,30 +208,34 @@ extern "C" int ia_conformer_block_bwd_a(const ia_block_params* Lp, const ia_bloc
     char* ws = (char*)workspace;
     float *dxa = (float*)(ws + w.dxa), *dxb = (float*)(ws + w.dxb), *dz = (float*)(ws + w.dz), *dG = (float*)(ws + w.dG),
           *Gm = (float*)(ws + w.Gm), *scr = (float*)(ws + w.scr);
-    void *dB = ws + w.dB, *dh = ws + w.dh, *dhp = ws + w.dhp, *dy = ws + w.dy, *dc3 = ws + w.dc3, *dc2 = ws + w.dc2,
+    void *dB = ws + w.dB, *dB1 = ws + w.dB1, *dB2 = ws + w.dB2, *dh = ws + w.dh, *dhp = ws + w.dhp, *dy = ws + w.dy, *dc3 = ws + w.dc3, *dc2 = ws + w.dc2,
          *dctx = ws + w.dctx, *wt = ws + w.wt;
     const float p = L.p_drop, pff = L.p_ff;
+    ia_tn_problem grp[8];
+    int ngrp = 0;
     // norm_out: d x4 -> dxa
     IA_TRY(ia_layernorm_bwd(S.x4, d, dout, nullptr, d, N, d, L.ln_out_g, L.ln_eps, nullptr, dxa, d, G.ln_out_g, G.ln_out_b, scr, stream));
     // feed_forward2
     IA_TRY(ia_scale_dropout_bf16(dxa, N, d, L.fc_factor, p, seed + 6, dB, stream));
-    IA_TRY(linear_bwd(dB, S.h4, L.w_ff2b, N, d, d_ff, dh, G.w_ff2b, G.b_ff2b, wt, scr, stream));
+    IA_TRY(linear_bwd_deferred(dB, S.h4, L.w_ff2b, N, d, d_ff, dh, G.w_ff2b, G.b_ff2b, wt, grp, &ngrp, stream));
     IA_TRY(ia_silu_dropout_bwd(S.h4p, dh, N, d_ff, pff, seed + 5, dhp, stream));
-    IA_TRY(linear_bwd(dhp, S.y4, L.w_ff2a, N, d_ff, d, dy, G.w_ff2a, G.b_ff2a, wt, scr, stream));
+    IA_TRY(linear_bwd_deferred(dhp, S.y4, L.w_ff2a, N, d_ff, d, dy, G.w_ff2a, G.b_ff2a, wt, grp, &ngrp, stream));
     IA_TRY(ia_layernorm_bwd(S.x3, d, nullptr, dy, d, N, d, L.ln_ff2_g, L.ln_eps, dxa, dxb, d, G.ln_ff2_g, G.ln_ff2_b, scr, stream));   // d x3 -> dxb
     // convolution module
-    IA_TRY(ia_scale_dropout_bf16(dxb, N, d, 1.f, p, seed + 4, dB, stream));
-    IA_TRY(linear_bwd(dB, S.c3, L.w_pw2, N, d, d, dc3, G.w_pw2, G.b_pw2, wt, scr, stream));
+    IA_TRY(ia_scale_dropout_bf16(dxb, N, d, 1.f, p, seed + 4, dB1, stream));
+    IA_TRY(linear_bwd_deferred(dB1, S.c3, L.w_pw2, N, d, d, dc3, G.w_pw2, G.b_pw2, wt, grp, &ngrp, stream));
     IA_TRY(ia_bn_silu_bwd(S.z, dc3, N, d, S.sums, S.sums + d, L.bn_g, L.bn_b, L.bn_eps, G.bn_b, G.bn_g, dz, scr, stream));
     IA_TRY(ia_dwconv_time(dz, B, T, d, ksz, L.dw_w, nullptr, 1, dG, stream));
     IA_TRY(ia_glu_mask(S.c2, lens, B, T, d, Gm, stream));
     IA_TRY(ia_dwconv_time_wgrad(Gm, dz, B, T, d, ksz, G.dw_w, G.dw_b, scr, stream));
     IA_TRY(ia_glu_bwd(S.c2, dG, lens, B, T, d, dc2, stream));
-    IA_TRY(linear_bwd(dc2, S.y3, L.w_pw1, N, 2 * d, d, dy, G.w_pw1, G.b_pw1, wt, scr, stream));
+    IA_TRY(linear_bwd_deferred(dc2, S.y3, L.w_pw1, N, 2 * d, d, dy, G.w_pw1, G.b_pw1, wt, grp, &ngrp, stream));
     IA_TRY(ia_layernorm_bwd(S.x2, d, nullptr, dy, d, N, d, L.ln_conv_g, L.ln_eps, dxb, dxa, d, G.ln_conv_g, G.ln_conv_b, scr, stream));  // d x2 -> dxa
     // linear_out
-    IA_TRY(ia_scale_dropout_bf16(dxa, N, d, 1.f, p, seed + 3, dB, stream));
-    IA_TRY(linear_bwd(dB, S.ctxv, L.w_out, N, d, d, dctx, G.w_out, G.b_out, wt, scr, stream));
+    IA_TRY(ia_scale_dropout_bf16(dxa, N, d, 1.f, p, seed + 3, dB2, stream));
+    IA_TRY(linear_bwd_deferred(dB2, S.ctxv, L.w_out, N, d, d, dctx, G.w_out, G.b_out, wt, grp, &ngrp, stream));
+    // the five weight (+ bias) gradients of this half in one GEMM launch + one finishing launch
+    IA_TRY(ia_gemm_tn_bf16_grouped(grp, ngrp, scr, stream));
     *dx2_out = dxa;
     *dctx_out = dctx;
     return IA_OK;
@@ -230,16 +260,19 @@ extern "C" int ia_conformer_block_bwd_b(const ia_block_params* Lp, const ia_bloc
     float *dxa = (float*)(ws + w.dxa), *dxb = (float*)(ws + w.dxb), *scr = (float*)(ws + w.scr);
     void *dB = ws + w.dB, *dh = ws + w.dh, *dhp = ws + w.dhp, *dy = ws + w.dy, *wt = ws + w.wt;
     const float p = L.p_drop, pff = L.p_ff;
+    ia_tn_problem grp[8];
+    int ngrp = 0;
     // q|k|v projection (dW rows q, k, v contiguous; bias likewise) and the bias-free position projection
-    IA_TRY(linear_bwd(dqkv, S.y2, L.w_qkv, N, 3 * d, d, dy, G.w_qkv, G.b_qkv, wt, scr, stream));
-    IA_TRY(ia_gemm_tn_bf16(dpl, d, pos_emb, d, pos_rows, d, d, G.w_pos, nullptr, scr, stream));
+    IA_TRY(linear_bwd_deferred(dqkv, S.y2, L.w_qkv, N, 3 * d, d, dy, G.w_qkv, G.b_qkv, wt, grp, &ngrp, stream));
+    grp[ngrp++] = ia_tn_problem{dpl, pos_emb, G.w_pos, nullptr, d, d, pos_rows, d, d};
     IA_TRY(ia_layernorm_bwd(S.x1, d, nullptr, dy, d, N, d, L.ln_att_g, L.ln_eps, dxa, dxb, d, G.ln_att_g, G.ln_att_b, scr, stream));   // d x1 -> dxb
     // feed_forward1
     IA_TRY(ia_scale_dropout_bf16(dxb, N, d, L.fc_factor, p, seed + 2, dB, stream));
-    IA_TRY(linear_bwd(dB, S.h1, L.w_ff1b, N, d, d_ff, dh, G.w_ff1b, G.b_ff1b, wt, scr, stream));
+    IA_TRY(linear_bwd_deferred(dB, S.h1, L.w_ff1b, N, d, d_ff, dh, G.w_ff1b, G.b_ff1b, wt, grp, &ngrp, stream));
     IA_TRY(ia_silu_dropout_bwd(S.h1p, dh, N, d_ff, pff, seed + 1, dhp, stream));
-    IA_TRY(linear_bwd(dhp, S.y1, L.w_ff1a, N, d_ff, d, dy, G.w_ff1a, G.b_ff1a, wt, scr, stream));
+    IA_TRY(linear_bwd_deferred(dhp, S.y1, L.w_ff1a, N, d_ff, d, dy, G.w_ff1a, G.b_ff1a, wt, grp, &ngrp, stream));
     IA_TRY(ia_layernorm_bwd(x0, d, nullptr, dy, d, N, d, L.ln_ff1_g, L.ln_eps, dxb, dx0, d, G.ln_ff1_g, G.ln_ff1_b, scr, stream));
+    IA_TRY(ia_gemm_tn_bf16_grouped(grp, ngrp, scr, stream));   // the four weight gradients of this half, before the multi-tensor add
     if (add_table && n_add > 0) {
         hipLaunchKernelGGL(multi_add_kernel, dim3(64, n_add < 64 ? n_add : 64), dim3(256), 0, (hipStream_t)stream,
                            (const AddRow*)add_table, n_add);

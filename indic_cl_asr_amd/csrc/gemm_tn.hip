@@ -50,11 +50,11 @@ __device__ __forceinline__ bf8 tn_join(bf4 lo, bf4 hi) {
     return o;
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const __bf16* __restrict__ dY, int ldy, const __bf16* __restrict__ X,
-                                                         int ldx, int M, int n, int k, int rows_per_split,
-                                                         float* __restrict__ part, float* __restrict__ part_b,
-                                                         size_t row_stride) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TN_TILE];  // dY tile | X tile
+// one [128 x 128] output tile of one split: the body shared by the single-problem and the grouped kernel
+__device__ __forceinline__ void tn_tile_body(const __bf16* __restrict__ dY, int ldy, const __bf16* __restrict__ X, int ldx, int M,
+                                             int n, int k, int rows_per_split, float* __restrict__ part,
+                                             float* __restrict__ part_b, size_t row_stride, int tile, int split,
+                                             unsigned char* smem) {
     unsigned char* sY = smem;
     unsigned char* sX = smem + TN_TILE;
     const unsigned ldsY = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)sY);
@@ -63,8 +63,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const __bf16* __restric
     const int c = lane & 15, q4 = lane >> 4;
     const int wn = wave >> 1, wk = wave & 1;                 // 2 x 2 waves, 64 x 64 outputs each
     const int ntk = (k + TN_BK - 1) / TN_BK;
-    const int n0 = (blockIdx.x / ntk) * TN_BN, k0 = (blockIdx.x % ntk) * TN_BK;
-    const int split = blockIdx.y;
+    const int n0 = (tile / ntk) * TN_BN, k0 = (tile % ntk) * TN_BK;
     const int m_beg = split * rows_per_split;
     int m_end = m_beg + rows_per_split; m_end = m_end < M ? m_end : M;
     const bool do_bias = part_b != nullptr && k0 == 0 && wk == 0;
@@ -158,6 +157,59 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const __bf16* __restric
         }
 }
 
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const __bf16* __restrict__ dY, int ldy, const __bf16* __restrict__ X,
+                                                         int ldx, int M, int n, int k, int rows_per_split,
+                                                         float* __restrict__ part, float* __restrict__ part_b,
+                                                         size_t row_stride) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TN_TILE];  // dY tile | X tile
+    tn_tile_body(dY, ldy, X, ldx, M, n, k, rows_per_split, part, part_b, row_stride, blockIdx.x, blockIdx.y, smem);
+}
+
+// Several weight gradients in ONE launch (a trainable block's five / four projections): the single-problem launches are
+// latency-bound (16 us each for 1.6 .. 6.3 GFLOP), together they fill the GPU once.  Workgroup -> (problem, tile, split).
+constexpr int TN_MAX_GROUP = 8;
+struct TnProblem {
+    const __bf16* dY; const __bf16* X; float* part; float* part_b; float* dW; float* db;
+    size_t row_stride; int ldy, ldx, M, n, k, rps, S, tiles, wg_begin; int64_t out_begin;
+};
+struct TnGroup { TnProblem p[TN_MAX_GROUP]; int count; };
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(TnGroup g) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TN_TILE];
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < TN_MAX_GROUP; ++i)
+        if (i < g.count && (int)blockIdx.x >= g.p[i].wg_begin) pi = i;
+    pi = __builtin_amdgcn_readfirstlane(pi);
+    const TnProblem& P = g.p[pi];
+    const int local = blockIdx.x - P.wg_begin;
+    tn_tile_body(P.dY, P.ldy, P.X, P.ldx, P.M, P.n, P.k, P.rps, P.part, P.part_b, P.row_stride, local % P.tiles, local / P.tiles, smem);
+}
+
+// out[e] = sum over the problem's splits of its partial rows, for every problem of the group: element e of the
+// concatenated outputs [dW_0 | db_0 | dW_1 | ...] -> (problem, offset); one thread per 4 floats (n*k and n are multiples of 4)
+__global__ __launch_bounds__(256) void gemm_tn_grouped_finish_kernel(TnGroup g, int64_t total4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const int64_t e = i * 4;
+        int pi = 0;
+#pragma unroll
+        for (int j = 1; j < TN_MAX_GROUP; ++j)
+            if (j < g.count && e >= g.p[j].out_begin) pi = j;
+        const TnProblem& P = g.p[pi];
+        const int64_t off = e - P.out_begin;                 // inside [n*k tile values | n bias sums]
+        const int64_t nk = (int64_t)P.n * P.k;
+        if (off >= nk && !P.db) continue;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* src = P.part + off;
+        for (int s_ = 0; s_ < P.S; ++s_) {
+            const float4 x = *reinterpret_cast<const float4*>(src + (size_t)s_ * P.row_stride);
+            a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
+        }
+        float* dst = off < nk ? P.dW + off : P.db + (off - nk);
+        *reinterpret_cast<float4*>(dst) = a;
+    }
+}
+
 inline int tn_splits(int M, int n, int k) {
     const int tiles = ((n + TN_BN - 1) / TN_BN) * ((k + TN_BK - 1) / TN_BK);
     int s = (320 + tiles - 1) / tiles;
@@ -198,6 +250,77 @@ extern "C" int ia_gemm_tn_bf16(const void* dY, int ldy, const void* X, int ldx, 
             ia_partials_finish_wide_strided(part_b, Seff, (int64_t)n, (int64_t)row_stride, db, st);
         }
     }
+    IA_RETURN_IF_LAUNCH_FAILED();
+    return IA_OK;
+}
+
+// Grouped form: `count` <= 8 problems {dY, ldy, X, ldx, M, n, k, dW, db} in one GEMM launch + one finishing launch.
+// scratch: f32 x ia_gemm_tn_grouped_scratch_elems (the problems' partial rows side by side).
+namespace {
+inline int tn_group_plan(const ia_tn_problem* pr, int count, TnGroup* g, int64_t* scratch_elems, int64_t* out_elems, int* blocks) {
+    if (!pr || count <= 0 || count > TN_MAX_GROUP) return IA_INVALID_VALUE;
+    int tiles_total = 0;
+    for (int i = 0; i < count; ++i) {
+        const ia_tn_problem& q = pr[i];
+        if (q.M <= 0 || q.n <= 0 || q.k <= 0) return IA_INVALID_VALUE;
+        if (q.n % 8 != 0 || q.k % 8 != 0 || q.ldy % 8 != 0 || q.ldx % 8 != 0) return IA_UNSUPPORTED;
+        tiles_total += ((q.n + TN_BN - 1) / TN_BN) * ((q.k + TN_BK - 1) / TN_BK);
+    }
+    // splits: the whole group lands in one residency wave (2 workgroups per CU x 256 CUs), each split at least 64 rows
+    int S0 = 512 / tiles_total;
+    S0 = S0 < 1 ? 1 : S0;
+    int64_t so = 0, oo = 0;
+    int wg = 0;
+    g->count = count;
+    for (int i = 0; i < count; ++i) {
+        const ia_tn_problem& q = pr[i];
+        TnProblem& P = g->p[i];
+        const int cap = (q.M + TN_MS - 1) / TN_MS;
+        int S = S0 > cap ? cap : S0;
+        int rps = (q.M + S - 1) / S;
+        rps = (rps + TN_MS - 1) / TN_MS * TN_MS;
+        S = (q.M + rps - 1) / rps;
+        P.dY = (const __bf16*)q.dY; P.X = (const __bf16*)q.X; P.ldy = q.ldy; P.ldx = q.ldx; P.M = q.M; P.n = q.n; P.k = q.k;
+        P.rps = rps; P.S = S; P.tiles = ((q.n + TN_BN - 1) / TN_BN) * ((q.k + TN_BK - 1) / TN_BK);
+        P.row_stride = (size_t)q.n * q.k + q.n;
+        P.part = nullptr; P.part_b = nullptr;                // filled by the caller from `so`
+        P.dW = q.dW; P.db = q.db;
+        P.wg_begin = wg; wg += P.tiles * S;
+        P.out_begin = oo; oo += (int64_t)P.row_stride;
+        P.part = reinterpret_cast<float*>(so * sizeof(float));   // offset for now
+        so += (int64_t)S * (int64_t)P.row_stride;
+        so = (so + 3) / 4 * 4;
+    }
+    *scratch_elems = so; *out_elems = oo; *blocks = wg;
+    return IA_OK;
+}
+}  // namespace
+
+extern "C" int64_t ia_gemm_tn_grouped_scratch_elems(const ia_tn_problem* problems, int count) {
+    TnGroup g; int64_t so = 0, oo = 0; int blocks = 0;
+    if (tn_group_plan(problems, count, &g, &so, &oo, &blocks) != IA_OK) return 0;
+    return so;
+}
+
+extern "C" int ia_gemm_tn_bf16_grouped(const ia_tn_problem* problems, int count, float* scratch, ia_stream_t stream) {
+    if (!scratch) return IA_INVALID_VALUE;
+    TnGroup g; int64_t so = 0, oo = 0; int blocks = 0;
+    const int rc = tn_group_plan(problems, count, &g, &so, &oo, &blocks);
+    if (rc != IA_OK) return rc;
+    for (int i = 0; i < count; ++i) {
+        TnProblem& P = g.p[i];
+        if (!P.dY || !P.X || !P.dW || !ia_is_aligned(P.dY, 16) || !ia_is_aligned(P.X, 16) || !ia_is_aligned(P.dW, 16) ||
+            (P.db && !ia_is_aligned(P.db, 16)))
+            return IA_INVALID_VALUE;
+        P.part = scratch + reinterpret_cast<size_t>(P.part) / sizeof(float);
+        P.part_b = P.db ? P.part + (size_t)P.n * P.k : nullptr;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(blocks), dim3(256), 0, st, g);
+    IA_RETURN_IF_LAUNCH_FAILED();
+    const int64_t total4 = oo / 4;
+    const int64_t fb = (total4 + 255) / 256;
+    hipLaunchKernelGGL(gemm_tn_grouped_finish_kernel, dim3((unsigned)(fb < 2048 ? fb : 2048)), dim3(256), 0, st, g, total4);
     IA_RETURN_IF_LAUNCH_FAILED();
     return IA_OK;
 }

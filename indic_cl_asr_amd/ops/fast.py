@@ -402,6 +402,28 @@ def gemm_tn(dy_bf16, x_bf16):
     return dW, db
 
 
+def gemm_tn_grouped(pairs):
+    """[(dY [M,N] bf16, X [M,K] bf16), ...] (<= 8) -> [(dW [N,K] f32, db [N] f32), ...] in ONE GEMM launch + one finishing
+    launch (csrc/gemm_tn.hip, grouped form)."""
+    import ctypes
+    L = _lib.lib()
+    n_ = len(pairs)
+    arr = (_lib.TnProblem * n_)()
+    outs = []
+    dev = pairs[0][0].device
+    for i, (dy, x) in enumerate(pairs):
+        M, N = dy.shape
+        K = x.shape[1]
+        buf = torch.empty(N * K + N, dtype=torch.float32, device=dev)
+        outs.append((buf[:N * K].view(N, K), buf[N * K:]))
+        arr[i].dY, arr[i].X, arr[i].dW, arr[i].db = dy.data_ptr(), x.data_ptr(), buf.data_ptr(), buf.data_ptr() + 4 * N * K
+        arr[i].ldy, arr[i].ldx, arr[i].M, arr[i].n, arr[i].k = dy.stride(0), x.stride(0), M, N, K
+    scr = scratch(dev, L.ia_gemm_tn_grouped_scratch_elems(ctypes.addressof(arr), n_))
+    st = L.ia_gemm_tn_bf16_grouped(ctypes.addressof(arr), n_, _lib.ptr(scr), _lib.stream_ptr())
+    _lib.check(st, "ia_gemm_tn_bf16_grouped")
+    return outs
+
+
 def weight_t_shadow(weight):
     """W^T [K,N] bf16, cached per parameter version: the 'weight' of the data-gradient GEMM dX = dY W = dY (W^T)^T."""
     return _cached(("wT", id(weight)), (weight,), lambda: bf16_shadow(weight).t().contiguous())

@@ -30,3 +30,20 @@ def test_gemm_tn_matches_fp32_product(M, n, k, pad):
     _lib.check(L.ia_gemm_tn_bf16(_lib.ptr(dYs), dYs.stride(0), _lib.ptr(Xs), Xs.stride(0), M, n, k, _lib.ptr(dW2), None,
                                  _lib.ptr(scr), _lib.stream_ptr()), "ia_gemm_tn_bf16")
     assert torch.equal(dW2, dW)                          # deterministic (no atomics)
+
+
+def test_grouped_weight_gradients_equal_the_single_launches():
+    """The grouped form (one GEMM launch + one finishing launch for a block's projections) against one launch per problem:
+    same kernel body, different split counts -> equal up to the order of the f32 split sums."""
+    from indic_cl_asr_amd.ops import fast
+    g = torch.Generator().manual_seed(3)
+    shapes = [(3008, 256, 1024), (3008, 1024, 256), (3008, 256, 256), (3008, 512, 256), (751, 256, 256), (3008, 768, 256)]
+    pairs = [((torch.randn(M, N, generator=g) * 0.3).bfloat16().cuda(), (torch.randn(M, K, generator=g) * 0.5).bfloat16().cuda())
+             for M, N, K in shapes]
+    outs = fast.gemm_tn_grouped(pairs)
+    for (dy, x), (dW, db) in zip(pairs, outs):
+        rW, rb = fast.gemm_tn(dy, x)
+        assert (dW - rW).abs().max().item() <= 2e-5 * rW.abs().max().item() + 1e-6
+        assert (db - rb).abs().max().item() <= 2e-5 * rb.abs().max().item() + 1e-6
+        ref = dy.double().t() @ x.double()
+        assert (dW.double() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
