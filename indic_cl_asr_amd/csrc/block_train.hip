@@ -12,6 +12,8 @@
 
 #include <cstdint>
 
+#include <cstdlib>
+
 #include "ia_common.h"
 
 namespace {
@@ -133,6 +135,16 @@ int linear_bwd(const void* dY, const void* X, const void* W, int M, int n, int k
 }
 
 // the same with the weight gradient deferred: the problem is appended to `grp` (launched together at the end of the call)
+bool tn_grouping_enabled() {   // IA_TN_GROUPED=0: one launch per weight gradient (A/B measurements)
+    static const bool on = [] { const char* e = getenv("IA_TN_GROUPED"); return !(e && e[0] == '0'); }();
+    return on;
+}
+int flush_group(const ia_tn_problem* grp, int ngrp, float* scr, ia_stream_t stream) {
+    if (tn_grouping_enabled()) return ia_gemm_tn_bf16_grouped(grp, ngrp, scr, stream);
+    for (int i = 0; i < ngrp; ++i)
+        IA_TRY(ia_gemm_tn_bf16(grp[i].dY, grp[i].ldy, grp[i].X, grp[i].ldx, grp[i].M, grp[i].n, grp[i].k, grp[i].dW, grp[i].db, scr, stream));
+    return IA_OK;
+}
 int linear_bwd_deferred(const void* dY, const void* X, const void* W, int M, int n, int k, void* dX, float* dW, float* db, void* wt,
                         ia_tn_problem* grp, int* ngrp, ia_stream_t stream) {
     if (dX) {
@@ -235,7 +247,7 @@ extern "C" int ia_conformer_block_bwd_a(const ia_block_params* Lp, const ia_bloc
     IA_TRY(ia_scale_dropout_bf16(dxa, N, d, 1.f, p, seed + 3, dB2, stream));
     IA_TRY(linear_bwd_deferred(dB2, S.ctxv, L.w_out, N, d, d, dctx, G.w_out, G.b_out, wt, grp, &ngrp, stream));
     // the five weight (+ bias) gradients of this half in one GEMM launch + one finishing launch
-    IA_TRY(ia_gemm_tn_bf16_grouped(grp, ngrp, scr, stream));
+    IA_TRY(flush_group(grp, ngrp, scr, stream));
     *dx2_out = dxa;
     *dctx_out = dctx;
     return IA_OK;
@@ -272,7 +284,7 @@ extern "C" int ia_conformer_block_bwd_b(const ia_block_params* Lp, const ia_bloc
     IA_TRY(ia_silu_dropout_bwd(S.h1p, dh, N, d_ff, pff, seed + 1, dhp, stream));
     IA_TRY(linear_bwd_deferred(dhp, S.y1, L.w_ff1a, N, d_ff, d, dy, G.w_ff1a, G.b_ff1a, wt, grp, &ngrp, stream));
     IA_TRY(ia_layernorm_bwd(x0, d, nullptr, dy, d, N, d, L.ln_ff1_g, L.ln_eps, dxb, dx0, d, G.ln_ff1_g, G.ln_ff1_b, scr, stream));
-    IA_TRY(ia_gemm_tn_bf16_grouped(grp, ngrp, scr, stream));   // the four weight gradients of this half, before the multi-tensor add
+    IA_TRY(flush_group(grp, ngrp, scr, stream));   // the four weight gradients of this half, before the multi-tensor add
     if (add_table && n_add > 0) {
         hipLaunchKernelGGL(multi_add_kernel, dim3(64, n_add < 64 ? n_add : 64), dim3(256), 0, (hipStream_t)stream,
                            (const AddRow*)add_table, n_add);
