@@ -425,7 +425,7 @@ int ia_ffn_fused(float* x, int N, int d, int d_ff, const float* ln_g, const floa
  * block l uses dropout seeds seed_base + l*seed_stride + {1..7} (the sites of the Python path); training = 0 disables
  * dropout and uses the BatchNorm running statistics.  All pointers in ia_block_params are device pointers: bf16 weights
  * [out, in] (w_qkv = q|k|v rows concatenated, b_qkv likewise), f32 everything else.  Workspace from
- * ia_conformer_prefix_ws_bytes.  Same limits as the kernels it sequences (head dim 64, T <= 384, taps <= 31). */
+ * ia_conformer_prefix_ws_bytes.  Same limits as the kernels it sequences (head dim <= 64, taps <= 31). */
 typedef struct ia_block_params {
     const void *w_ff1a, *w_ff1b, *w_qkv, *w_pos, *w_out, *w_pw1, *w_pw2, *w_ff2a, *w_ff2b;
     const float *b_ff1a, *b_ff1b, *b_qkv, *b_out, *b_pw1, *b_pw2, *b_ff2a, *b_ff2b;
@@ -442,6 +442,15 @@ size_t ia_conformer_prefix_ws_bytes(int B, int T, int d, int d_ff, int H, int ks
 int ia_conformer_prefix_fwd(const ia_block_params* layers, int n_layers, float* x, const void* pos_emb, int pos_rows,
                             const int64_t* lens, int B, int T, unsigned seed_base, unsigned seed_stride, int training,
                             void* workspace, size_t workspace_bytes, ia_stream_t stream);
+/* The same prefix in segments of half blocks, for SyncBatchNorm over several ranks: unit 2k = block k up to and including
+ * the BatchNorm sums, unit 2k+1 = BatchNorm + SiLU onwards; runs units [seg_begin, seg_end).  Between the two halves of a
+ * block the caller all-reduces [sum | sumsq | count] (2d+1 floats at workspace + ia_conformer_prefix_ws_sums_offset) and
+ * calls ia_bn_sync_finish; bn_synced = 1 then keeps ia_bn_silu from touching the running statistics. */
+size_t ia_conformer_prefix_ws_sums_offset(int B, int T, int d, int d_ff, int H, int ksz, int pos_rows);
+int ia_conformer_prefix_fwd_seg(const ia_block_params* layers, int n_layers, float* x, const void* pos_emb, int pos_rows,
+                                const int64_t* lens, int B, int T, unsigned seed_base, unsigned seed_stride, int training,
+                                int seg_begin, int seg_end, int bn_synced, void* workspace, size_t workspace_bytes,
+                                ia_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Native executors of ONE TRAINABLE Conformer block (csrc/block_train.hip): ConformerLayer.forward
@@ -487,6 +496,16 @@ int ia_conformer_block_fwd(const struct ia_block_params* layer, const float* x0,
 int ia_conformer_block_bwd_a(const struct ia_block_params* layer, const ia_block_saved* saved, const ia_block_grads* grads,
                              const float* dout, const int64_t* lens, int B, int T, unsigned seed, void* workspace,
                              size_t workspace_bytes, float** dx2_out, void** dctx_out, ia_stream_t stream);
+/* SyncBatchNorm over several ranks: the same calls split at the BatchNorm exchanges (phase 0 = whole call; forward: 1 = up
+ * to the BatchNorm sums, 2 = BatchNorm + SiLU onwards; backward part 1: 1 = up to the local S1 | S2 in grads->bn_b / bn_g,
+ * 2 = from dz onwards with bn_S12 = the all-reduced sums rescaled by n_local / n_global). */
+int ia_conformer_block_fwd_phase(const struct ia_block_params* layer, const float* x0, const void* pos_emb, int pos_rows,
+                                 const int64_t* lens, int B, int T, unsigned seed, const ia_block_saved* saved, float* out,
+                                 void* vt_scratch, float* dw_scratch, int phase, ia_stream_t stream);
+int ia_conformer_block_bwd_a_phase(const struct ia_block_params* layer, const ia_block_saved* saved, const ia_block_grads* grads,
+                                   const float* dout, const int64_t* lens, int B, int T, unsigned seed, void* workspace,
+                                   size_t workspace_bytes, float** dx2_out, void** dctx_out, int phase, const float* bn_S12,
+                                   ia_stream_t stream);
 int ia_conformer_block_bwd_b(const struct ia_block_params* layer, const ia_block_saved* saved, const ia_block_grads* grads,
                              const float* x0, const void* pos_emb, int pos_rows, const void* dqkv, const void* dpl, int B,
                              int T, unsigned seed, void* workspace, size_t workspace_bytes, float* dx0,

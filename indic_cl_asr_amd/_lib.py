@@ -127,11 +127,15 @@ SIGNATURES = {
     "ia_ffn_fused_supported": (_i, [_i, _i]),
     "ia_ffn_fused": (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _f, _f, _c.c_uint, _f, _c.c_uint, _vp, _vp, _vp, _i, _vp]),
     "ia_conformer_prefix_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
+    "ia_conformer_prefix_ws_sums_offset": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
+    "ia_conformer_prefix_fwd_seg": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _c.c_uint, _c.c_uint, _i, _i, _i, _i, _vp, _sz, _vp]),
     "ia_conformer_prefix_fwd": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _c.c_uint, _c.c_uint, _i, _vp, _sz, _vp]),
     "ia_conformer_block_supported": (_i, [_i, _i, _i, _i, _i]),
     "ia_conformer_block_bwd_ws_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "ia_conformer_block_fwd": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _c.c_uint, _vp, _vp, _vp, _vp, _vp]),
+    "ia_conformer_block_fwd_phase": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _c.c_uint, _vp, _vp, _vp, _vp, _i, _vp]),
     "ia_conformer_block_bwd_a": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _c.c_uint, _vp, _sz, _vp, _vp, _vp]),
+    "ia_conformer_block_bwd_a_phase": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _c.c_uint, _vp, _sz, _vp, _vp, _i, _vp, _vp]),
     "ia_conformer_block_bwd_b": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _c.c_uint, _vp, _sz, _vp, _vp, _i, _vp]),
     "ia_layernorm_bwd": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _f, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "ia_layernorm_bwd_scratch_elems": (_i64, [_i, _i]),

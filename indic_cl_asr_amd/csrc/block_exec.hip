@@ -28,7 +28,7 @@ PrefixWs prefix_ws(int B, int T, int d, int d_ff, int H, int ksz, int pos_rows) 
     w.ctx = o;  o = up256(o + N * d * 2);
     w.c2 = o;   o = up256(o + N * 2 * d * 2);
     w.z = o;    o = up256(o + N * d * 4);
-    w.sums = o; o = up256(o + 2 * (size_t)d * 4);
+    w.sums = o; o = up256(o + (2 * (size_t)d + 64) * 4);   // [sum | sumsq | row count (SyncBatchNorm exchange)]
     w.c3 = o;   o = up256(o + N * d * 2);
     w.vt = o;   o = up256(o + ia_attn_vt_elems(B, T, H) * 2);
     w.scr = o;  o = up256(o + (size_t)ia_dwconv_scratch_elems(B, T, d, ksz) * 4);
@@ -48,10 +48,30 @@ extern "C" size_t ia_conformer_prefix_ws_bytes(int B, int T, int d, int d_ff, in
         if (rc_ != IA_OK) return rc_; \
     } while (0)
 
+extern "C" size_t ia_conformer_prefix_ws_sums_offset(int B, int T, int d, int d_ff, int H, int ksz, int pos_rows) {
+    if (B <= 0 || T <= 0 || d <= 0 || d_ff <= 0 || H <= 0 || ksz <= 0 || pos_rows <= 0) return 0;
+    return prefix_ws(B, T, d, d_ff, H, ksz, pos_rows).sums;
+}
+
 extern "C" int ia_conformer_prefix_fwd(const ia_block_params* layers, int n_layers, float* x, const void* pos_emb,
                                        int pos_rows, const int64_t* lens, int B, int T, unsigned seed_base,
                                        unsigned seed_stride, int training, void* workspace, size_t workspace_bytes,
                                        ia_stream_t stream) {
+    return ia_conformer_prefix_fwd_seg(layers, n_layers, x, pos_emb, pos_rows, lens, B, T, seed_base, seed_stride, training, 0,
+                                       2 * n_layers, 0, workspace, workspace_bytes, stream);
+}
+
+// The same in segments of half blocks (unit 2k = block k up to and including GLU + depthwise conv + BatchNorm sums, unit
+// 2k+1 = BatchNorm + SiLU onwards): SyncBatchNorm over several ranks all-reduces the sums between the two halves of every
+// block (the caller does, through torch.distributed / RCCL), so a prefix of n blocks is n+1 native calls -- [0,1), [1,3),
+// ..., [2n-1,2n) -- instead of ~10 launches per block issued from Python.  bn_synced: the running statistics were updated
+// by ia_bn_sync_finish from the global batch (ia_bn_silu must not update them from the local one).  The workspace carries
+// the state between the calls and must not be touched in between (the sums live at ia_conformer_prefix_ws_sums_offset).
+extern "C" int ia_conformer_prefix_fwd_seg(const ia_block_params* layers, int n_layers, float* x, const void* pos_emb,
+                                           int pos_rows, const int64_t* lens, int B, int T, unsigned seed_base,
+                                           unsigned seed_stride, int training, int seg_begin, int seg_end, int bn_synced,
+                                           void* workspace, size_t workspace_bytes, ia_stream_t stream) {
+    if (seg_begin < 0 || seg_end > 2 * n_layers || seg_begin >= seg_end) return IA_INVALID_VALUE;
     if (!layers || n_layers <= 0 || !x || !pos_emb || !lens || !workspace || B <= 0 || T <= 0) return IA_INVALID_VALUE;
     const ia_block_params& l0 = layers[0];
     const int d = l0.d, d_ff = l0.d_ff, H = l0.n_heads, dk = d / (H > 0 ? H : 1), ksz = l0.ksz;
@@ -70,13 +90,15 @@ extern "C" int ia_conformer_prefix_fwd(const ia_block_params* layers, int n_laye
     const char* attn_env = getenv("IA_PREFIX_ATTN");
     const bool use_flash = ia_relpos_attention_flash_supported(T, dk) != 0 && !(attn_env && attn_env[0] == 'o');
     // LayerNorm in front of the first block's first feed-forward; later ones are chained behind the previous norm_out
-    if (!ffn_fused)
+    if (!ffn_fused && seg_begin == 0)
         IA_TRY(ia_layernorm(x, d, N, d, l0.ln_ff1_g, l0.ln_ff1_b, l0.ln_eps, nullptr, 0, nullptr, nullptr, y, d, stream));
-    for (int li = 0; li < n_layers; ++li) {
+    for (int li = seg_begin / 2; li < n_layers && 2 * li < seg_end; ++li) {
         const ia_block_params& L = layers[li];
         if (L.d != d || L.d_ff != d_ff || L.n_heads != H || L.ksz != ksz) return IA_INVALID_VALUE;
         const unsigned seed = seed_base + seed_stride * (unsigned)li;
         const float p = training ? L.p_drop : 0.f, pff = training ? L.p_ff : 0.f, patt = training ? L.p_att : 0.f;
+        const bool first_half = 2 * li >= seg_begin, second_half = 2 * li + 1 < seg_end;
+        if (first_half) {
         // 1/2 feed-forward
         if (ffn_fused) {
             // (... and norm_self_att of the updated residual straight into y: no separate LayerNorm launch)
@@ -104,8 +126,10 @@ extern "C" int ia_conformer_prefix_fwd(const ia_block_params* layers, int n_laye
         IA_TRY(ia_layernorm(x, d, N, d, L.ln_conv_g, L.ln_conv_b, L.ln_eps, nullptr, 0, nullptr, nullptr, y, d, stream));
         IA_TRY(ia_gemm_bf16(y, d, L.w_pw1, d, N, 2 * d, d, L.b_pw1, 0, 0.f, 0, 1.f, nullptr, 0, nullptr, 0, c2, 2 * d, stream));
         IA_TRY(ia_glu_dwconv(c2, lens, B, T, d, ksz, L.dw_w, L.dw_b, z, sums, sums + d, scr, stream));
-        IA_TRY(ia_bn_silu(z, N, d, sums, sums + d, L.bn_g, L.bn_b, L.bn_rm, L.bn_rv, L.bn_nbt, L.bn_momentum, L.bn_eps,
-                          training ? 1 : 0, c3, stream));
+        }
+        if (!second_half) break;
+        IA_TRY(ia_bn_silu(z, N, d, sums, sums + d, L.bn_g, L.bn_b, bn_synced ? nullptr : L.bn_rm, bn_synced ? nullptr : L.bn_rv,
+                          bn_synced ? nullptr : L.bn_nbt, L.bn_momentum, L.bn_eps, training ? 1 : 0, c3, stream));
         IA_TRY(ia_gemm_bf16(c3, d, L.w_pw2, d, N, d, d, L.b_pw2, 0, p, seed + 4, 1.f, x, d, x, d, nullptr, 0, stream));
         // 1/2 feed-forward
         if (ffn_fused) {   // ... + norm_out in the same launch (the next block's module applies its own first LayerNorm)

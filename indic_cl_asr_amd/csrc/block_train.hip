@@ -172,12 +172,23 @@ extern "C" int ia_conformer_block_supported(int d, int d_ff, int H, int ksz, int
 extern "C" int ia_conformer_block_fwd(const ia_block_params* Lp, const float* x0, const void* pos_emb, int pos_rows,
                                       const int64_t* lens, int B, int T, unsigned seed, const ia_block_saved* Sp, float* out,
                                       void* vt_scratch, float* dw_scratch, ia_stream_t stream) {
+    return ia_conformer_block_fwd_phase(Lp, x0, pos_emb, pos_rows, lens, B, T, seed, Sp, out, vt_scratch, dw_scratch, 0, stream);
+}
+
+// phase 0: the whole block.  SyncBatchNorm over several ranks: phase 1 = up to and including the BatchNorm sums (saved->sums =
+// [sum | sumsq], room for the row count behind them), the caller all-reduces them and calls ia_bn_sync_finish, phase 2 = BatchNorm
+// + SiLU onwards (running statistics untouched: ia_bn_sync_finish updated them from the global batch).
+extern "C" int ia_conformer_block_fwd_phase(const ia_block_params* Lp, const float* x0, const void* pos_emb, int pos_rows,
+                                            const int64_t* lens, int B, int T, unsigned seed, const ia_block_saved* Sp,
+                                            float* out, void* vt_scratch, float* dw_scratch, int phase, ia_stream_t stream) {
+    if (phase < 0 || phase > 2) return IA_INVALID_VALUE;
     if (!Lp || !x0 || !pos_emb || !lens || !Sp || !out || !vt_scratch || !dw_scratch || B <= 0 || T <= 0) return IA_INVALID_VALUE;
     const ia_block_params& L = *Lp;
     const ia_block_saved& S = *Sp;
     const int d = L.d, d_ff = L.d_ff, H = L.n_heads, dk = d / (H > 0 ? H : 1), ksz = L.ksz, N = B * T;
     if (!ia_conformer_block_supported(d, d_ff, H, ksz, T) || pos_rows < 2 * T - 1) return IA_UNSUPPORTED;
     const float p = L.p_drop, pff = L.p_ff, patt = L.p_att;
+    if (phase != 2) {
     // 1/2 feed-forward (pre-activation kept for the backward)
     IA_TRY(ia_layernorm(x0, d, N, d, L.ln_ff1_g, L.ln_ff1_b, L.ln_eps, nullptr, 0, nullptr, nullptr, S.y1, d, stream));
     IA_TRY(ia_gemm_bf16(S.y1, d, L.w_ff1a, d, N, d_ff, d, L.b_ff1a, 0, 0.f, 0, 1.f, nullptr, 0, nullptr, 0, S.h1p, d_ff, stream));
@@ -193,7 +204,11 @@ extern "C" int ia_conformer_block_fwd(const ia_block_params* Lp, const float* x0
     IA_TRY(ia_layernorm(S.x2, d, N, d, L.ln_conv_g, L.ln_conv_b, L.ln_eps, nullptr, 0, nullptr, nullptr, S.y3, d, stream));
     IA_TRY(ia_gemm_bf16(S.y3, d, L.w_pw1, d, N, 2 * d, d, L.b_pw1, 0, 0.f, 0, 1.f, nullptr, 0, nullptr, 0, S.c2, 2 * d, stream));
     IA_TRY(ia_glu_dwconv(S.c2, lens, B, T, d, ksz, L.dw_w, L.dw_b, S.z, S.sums, S.sums + d, dw_scratch, stream));
-    IA_TRY(ia_bn_silu(S.z, N, d, S.sums, S.sums + d, L.bn_g, L.bn_b, L.bn_rm, L.bn_rv, L.bn_nbt, L.bn_momentum, L.bn_eps, 1, S.c3, stream));
+    }
+    if (phase == 1) return IA_OK;
+    const bool synced = phase == 2;
+    IA_TRY(ia_bn_silu(S.z, N, d, S.sums, S.sums + d, L.bn_g, L.bn_b, synced ? nullptr : L.bn_rm, synced ? nullptr : L.bn_rv,
+                      synced ? nullptr : L.bn_nbt, L.bn_momentum, L.bn_eps, 1, S.c3, stream));
     IA_TRY(ia_gemm_bf16(S.c3, d, L.w_pw2, d, N, d, d, L.b_pw2, 0, p, seed + 4, 1.f, S.x2, d, S.x3, d, nullptr, 0, stream));
     // 1/2 feed-forward
     IA_TRY(ia_layernorm(S.x3, d, N, d, L.ln_ff2_g, L.ln_ff2_b, L.ln_eps, nullptr, 0, nullptr, nullptr, S.y4, d, stream));
@@ -210,6 +225,18 @@ extern "C" int ia_conformer_block_fwd(const ia_block_params* Lp, const float* x0
 extern "C" int ia_conformer_block_bwd_a(const ia_block_params* Lp, const ia_block_saved* Sp, const ia_block_grads* Gp,
                                         const float* dout, const int64_t* lens, int B, int T, unsigned seed, void* workspace,
                                         size_t workspace_bytes, float** dx2_out, void** dctx_out, ia_stream_t stream) {
+    return ia_conformer_block_bwd_a_phase(Lp, Sp, Gp, dout, lens, B, T, seed, workspace, workspace_bytes, dx2_out, dctx_out, 0, nullptr,
+                                          stream);
+}
+
+// phase 0: all of part 1.  SyncBatchNorm over several ranks: phase 1 = up to the BatchNorm backward's own reduction (leaves this
+// rank's S1 | S2 = d beta | d gamma in grads->bn_b / grads->bn_g), the caller all-reduces a copy [S1 | S2 | n] and rescales it by
+// n_local / n_global, phase 2 (bn_S12 = that copy, 2d floats) = dz from the global sums onwards.
+extern "C" int ia_conformer_block_bwd_a_phase(const ia_block_params* Lp, const ia_block_saved* Sp, const ia_block_grads* Gp,
+                                              const float* dout, const int64_t* lens, int B, int T, unsigned seed,
+                                              void* workspace, size_t workspace_bytes, float** dx2_out, void** dctx_out,
+                                              int phase, const float* bn_S12, ia_stream_t stream) {
+    if (phase < 0 || phase > 2 || (phase == 2 && !bn_S12)) return IA_INVALID_VALUE;
     if (!Lp || !Sp || !Gp || !dout || !lens || !workspace || !dx2_out || !dctx_out || B <= 0 || T <= 0) return IA_INVALID_VALUE;
     const ia_block_params& L = *Lp;
     const ia_block_saved& S = *Sp;
@@ -225,6 +252,7 @@ extern "C" int ia_conformer_block_bwd_a(const ia_block_params* Lp, const ia_bloc
     const float p = L.p_drop, pff = L.p_ff;
     ia_tn_problem grp[8];
     int ngrp = 0;
+    if (phase != 2) {
     // norm_out: d x4 -> dxa
     IA_TRY(ia_layernorm_bwd(S.x4, d, dout, nullptr, d, N, d, L.ln_out_g, L.ln_eps, nullptr, dxa, d, G.ln_out_g, G.ln_out_b, scr, stream));
     // feed_forward2
@@ -236,7 +264,17 @@ extern "C" int ia_conformer_block_bwd_a(const ia_block_params* Lp, const ia_bloc
     // convolution module
     IA_TRY(ia_scale_dropout_bf16(dxb, N, d, 1.f, p, seed + 4, dB1, stream));
     IA_TRY(linear_bwd_deferred(dB1, S.c3, L.w_pw2, N, d, d, dc3, G.w_pw2, G.b_pw2, wt, grp, &ngrp, stream));
-    IA_TRY(ia_bn_silu_bwd(S.z, dc3, N, d, S.sums, S.sums + d, L.bn_g, L.bn_b, L.bn_eps, G.bn_b, G.bn_g, dz, scr, stream));
+    if (phase == 0)
+        IA_TRY(ia_bn_silu_bwd(S.z, dc3, N, d, S.sums, S.sums + d, L.bn_g, L.bn_b, L.bn_eps, G.bn_b, G.bn_g, dz, scr, stream));
+    else
+        IA_TRY(ia_bn_silu_bwd_reduce(S.z, dc3, N, d, S.sums, S.sums + d, L.bn_g, L.bn_b, L.bn_eps, G.bn_b, G.bn_g, scr, stream));
+    }
+    if (phase == 1) {   // the weight gradients collected so far, then back to the caller for the exchange
+        IA_TRY(flush_group(grp, ngrp, scr, stream));
+        return IA_OK;
+    }
+    if (phase == 2)
+        IA_TRY(ia_bn_silu_bwd_apply(S.z, dc3, N, d, S.sums, S.sums + d, L.bn_g, L.bn_b, L.bn_eps, bn_S12, bn_S12 + d, dz, stream));
     IA_TRY(ia_dwconv_time(dz, B, T, d, ksz, L.dw_w, nullptr, 1, dG, stream));
     IA_TRY(ia_glu_mask(S.c2, lens, B, T, d, Gm, stream));
     IA_TRY(ia_dwconv_time_wgrad(Gm, dz, B, T, d, ksz, G.dw_w, G.dw_b, scr, stream));

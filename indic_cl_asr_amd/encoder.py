@@ -333,16 +333,13 @@ class ConformerEncoder(nn.Module):
         l0 = self.layers[0]
         bn_ok = all(l.conv.batch_norm.track_running_stats for l in self.layers[:n_fast])
         same_mode = all(l.training == l0.training for l in self.layers[:n_fast])
-        # (SyncBatchNorm across more than one rank exchanges the BatchNorm sums between two launches of every block: the
-        #  per-op path below does that; one rank, or plain BatchNorm: the native executor)
-        sync = any(fast.bn_sync_group(l.conv.batch_norm) is not None for l in self.layers[:n_fast])
         fp8 = bool(getattr(self.cfg, "fp8_frozen_prefix", False)) and d % 16 == 0
         for l in self.layers[:n_fast]:
             l.fp8_projections = fp8
-        if fp8:
-            sync = True   # (the native executor and the fused feed-forward kernel are bf16: per-op path below)
+        # native executor: one C call for the whole prefix; with SyncBatchNorm over several ranks one call per block boundary,
+        # the all-reduce of the BatchNorm sums in between (ops/fast.conformer_prefix).  fp8 projections: per-op path below.
         if ((fast.attention_flash_supported(T, l0.self_attn.d_k) or fast.attention_supported(T, l0.self_attn.d_k)) and bn_ok
-                and same_mode and not sync):
+                and same_mode and not fp8):
             # native executor: one C call enqueues the 14 kernels of every block (csrc/block_exec.hip)
             fast.conformer_prefix(list(self.layers[:n_fast]), xr, pe, length, B, T, base, 16, l0.training)
             return xr.view(B, T, d), n_fast

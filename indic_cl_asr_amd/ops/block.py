@@ -261,7 +261,7 @@ def pad_pos_emb(pos_emb, d):
 def conformer_block(x2d, layer, lens, pe_bf16, B, T, seed):
     """x2d [B*T, d] f32 residual stream -> [B*T, d] f32 (autograd-connected to x2d and the block's parameters).
     pe_bf16: pad_pos_emb(pos_emb) (>= 2T-1 rows)."""
-    if USE_NATIVE_BLOCKS and layer.training and fast.bn_sync_group(layer.conv.batch_norm) is None:
+    if USE_NATIVE_BLOCKS and layer.training:
         att = layer.self_attn
         if _lib.lib().ia_conformer_block_supported(x2d.shape[-1], layer.feed_forward1.linear1.weight.shape[0], att.h,
                                                    layer.conv.depthwise_conv.weight.shape[-1], T):
@@ -281,7 +281,7 @@ _SAVED_FIELDS = ("y1", "h1p", "h1", "x1", "y2", "qkv", "pl", "ctxv", "x2", "y3",
 def _saved_layout(N, d, dff, pos_rows, H):
     """(field -> (byte offset, bytes)), total bytes: every buffer 256-byte aligned."""
     sizes = dict(y1=N * d * 2, h1p=N * dff * 2, h1=N * dff * 2, x1=N * d * 4, y2=N * d * 2, qkv=N * 3 * d * 2, pl=pos_rows * d * 2,
-                 ctxv=N * d * 2, x2=N * d * 4, y3=N * d * 2, c2=N * 2 * d * 2, z=N * d * 4, sums=2 * d * 4, c3=N * d * 2,
+                 ctxv=N * d * 2, x2=N * d * 4, y3=N * d * 2, c2=N * 2 * d * 2, z=N * d * 4, sums=(2 * d + 64) * 4, c3=N * d * 2,
                  x3=N * d * 4, y4=N * d * 2, h4p=N * dff * 2, h4=N * dff * 2, x4=N * d * 4, lse=N * H * 4)
     lay, o = {}, 0
     for f in _SAVED_FIELDS:
@@ -391,9 +391,18 @@ class _ConformerBlockNativeFn(torch.autograd.Function):
         if vt is None:
             vt = fast._VT[(dev.index, nvt)] = torch.empty(nvt, dtype=torch.bfloat16, device=dev)
         dw_scr = fast.scratch(dev, L.ia_dwconv_scratch_elems(B, T, d, rt.ksz))
-        st = L.ia_conformer_block_fwd(ctypes.addressof(bp), _ptr(x0), _ptr(pe), pe.shape[0], _ptr(lens), B, T, int(seed) & 0xFFFFFFFF,
-                                      ctypes.addressof(saved), _ptr(out), _ptr(vt), _ptr(dw_scr), _lib.stream_ptr())
-        _lib.check(st, "ia_conformer_block_fwd")
+        bn = layer.conv.batch_norm
+        group = fast.bn_sync_group(bn)
+        fwd_args = (ctypes.addressof(bp), _ptr(x0), _ptr(pe), pe.shape[0], _ptr(lens), B, T, int(seed) & 0xFFFFFFFF,
+                    ctypes.addressof(saved), _ptr(out), _ptr(vt), _ptr(dw_scr))
+        if group is None:
+            _lib.check(L.ia_conformer_block_fwd(*fwd_args, _lib.stream_ptr()), "ia_conformer_block_fwd")
+        else:   # SyncBatchNorm over several ranks: split at the exchange of the BatchNorm sums
+            _lib.check(L.ia_conformer_block_fwd_phase(*fwd_args, 1, _lib.stream_ptr()), "ia_conformer_block_fwd_phase")
+            o = lay["sums"][0]
+            fast.bn_sync_sums(arena[o:o + (2 * d + 1) * 4].view(torch.float32), N, d, bn, group)
+            _lib.check(L.ia_conformer_block_fwd_phase(*fwd_args, 2, _lib.stream_ptr()), "ia_conformer_block_fwd_phase")
+        ctx.group = group
         ctx.keep = (x0, arena, saved, lay, pe, lens, bp)
         ctx.meta = (layer, B, T, seed, [q.requires_grad for q in params], params)
         return out
@@ -420,9 +429,18 @@ class _ConformerBlockNativeFn(torch.autograd.Function):
         dout = dout.float().contiguous()
         dx2_p, dctx_p = ctypes.c_void_p(), ctypes.c_void_p()
         sp = _lib.stream_ptr()
-        st = L.ia_conformer_block_bwd_a(ctypes.addressof(bp), ctypes.addressof(saved), ctypes.addressof(rt.grads), _ptr(dout), _ptr(lens), B, T,
-                                        int(seed) & 0xFFFFFFFF, _ptr(ws), n_ws, ctypes.addressof(dx2_p), ctypes.addressof(dctx_p), sp)
-        _lib.check(st, "ia_conformer_block_bwd_a")
+        a_args = (ctypes.addressof(bp), ctypes.addressof(saved), ctypes.addressof(rt.grads), _ptr(dout), _ptr(lens), B, T,
+                  int(seed) & 0xFFFFFFFF, _ptr(ws), n_ws, ctypes.addressof(dx2_p), ctypes.addressof(dctx_p))
+        if ctx.group is None:
+            _lib.check(L.ia_conformer_block_bwd_a(*a_args, sp), "ia_conformer_block_bwd_a")
+        else:   # SyncBatchNorm: the backward's own exchange (local S1 | S2 = this rank's d beta | d gamma stay in the gradient arena)
+            import torch.distributed as dist
+            _lib.check(L.ia_conformer_block_bwd_a_phase(*a_args, 1, None, sp), "ia_conformer_block_bwd_a_phase")
+            ob, og = rt.off["bn_b"][0], rt.off["bn_g"][0]
+            Sg = torch.cat([rt.arena[ob:ob + d], rt.arena[og:og + d], torch.full((1,), float(N), dtype=torch.float32, device=dev)])
+            dist.all_reduce(Sg, group=ctx.group)
+            Sg = (Sg[:2 * d] * (float(N) / Sg[2 * d])).contiguous()
+            _lib.check(L.ia_conformer_block_bwd_a_phase(*a_args, 2, _ptr(Sg), sp), "ia_conformer_block_bwd_a_phase")
         # attention core: key-tiled backward (ops/fast.relpos_attention_flash_bwd) on views of the saved arena / workspace
         def view(buf, off, shape, dtype):
             n = 1

@@ -616,8 +616,27 @@ def conformer_prefix(layers, xr, pos_emb_bf16, lens, B, T, seed_base, seed_strid
     if ws is None or ws.numel() < n:
         ws = _PREFIX_WS[key] = torch.empty(n, dtype=torch.uint8, device=xr.device)
     import ctypes
-    st = L.ia_conformer_prefix_fwd(ctypes.addressof(arr), len(layers), _lib.ptr(xr), _lib.ptr(pos_emb_bf16), pos_emb_bf16.shape[0],
-                                   _lib.ptr(lens), B, T, int(seed_base) & 0xFFFFFFFF, int(seed_stride), int(bool(training)),
-                                   _lib.ptr(ws), n, _lib.stream_ptr())
-    _lib.check(st, "ia_conformer_prefix_fwd")
+    groups = [bn_sync_group(l.conv.batch_norm) for l in layers]
+    if all(g is None for g in groups):
+        st = L.ia_conformer_prefix_fwd(ctypes.addressof(arr), len(layers), _lib.ptr(xr), _lib.ptr(pos_emb_bf16), pos_emb_bf16.shape[0],
+                                       _lib.ptr(lens), B, T, int(seed_base) & 0xFFFFFFFF, int(seed_stride), int(bool(training)),
+                                       _lib.ptr(ws), n, _lib.stream_ptr())
+        _lib.check(st, "ia_conformer_prefix_fwd")
+        return xr
+    # SyncBatchNorm over several ranks: n+1 native segments with the all-reduce of each block's [sum | sumsq | count] in between
+    d = p0.d
+    off = L.ia_conformer_prefix_ws_sums_offset(B, T, p0.d, p0.d_ff, p0.n_heads, p0.ksz, pos_emb_bf16.shape[0])
+    sums = ws[off:off + (2 * d + 1) * 4].view(torch.float32)
+    nl = len(layers)
+    for k in range(nl + 1):
+        a, b = max(0, 2 * k - 1), min(2 * nl, 2 * k + 1)
+        st = L.ia_conformer_prefix_fwd_seg(ctypes.addressof(arr), nl, _lib.ptr(xr), _lib.ptr(pos_emb_bf16), pos_emb_bf16.shape[0],
+                                           _lib.ptr(lens), B, T, int(seed_base) & 0xFFFFFFFF, int(seed_stride), int(bool(training)),
+                                           a, b, 1, _lib.ptr(ws), n, _lib.stream_ptr())
+        _lib.check(st, "ia_conformer_prefix_fwd_seg")
+        if k < nl:
+            g = groups[k]
+            if g is None:
+                raise RuntimeError("conformer_prefix: mixed BatchNorm / SyncBatchNorm layers in one prefix")
+            bn_sync_sums(sums, B * T, d, layers[k].conv.batch_norm, g)
     return xr
