@@ -92,6 +92,19 @@ __global__ __launch_bounds__(LS_THREADS, 1) void lstm_fwd_kernel(
 #pragma unroll
     for (int k = 0; k < EPT; ++k) cst[k] = 0.f;
     __syncthreads();
+    // The serial chain per step is: hand-off wait -> h_{t-1} from L2 -> MFMA -> gate math -> h_t exchange stores -> release +
+    // arrival.  Everything that does not depend on h_{t-1} is moved off it: the step's input-projection values Gx are
+    // requested BEFORE the wait (they used to be loaded, full latency, between the MFMA and the gate math), and the stores
+    // that only the backward reads (Hout, gates, Cs) are issued AFTER the arrival, so the release waits for the 16-unit
+    // exchange stores alone.
+    float gxp[EPT][4];
+#define LS_FETCH_GX(t_)                                                                                   \
+    _Pragma("unroll") for (int k = 0; k < EPT; ++k) {                                                     \
+        const int e_ = tid + LS_THREADS * k, b_ = e_ >> 4, ul_ = e_ & 15;                                 \
+        const size_t gx_ = ((size_t)(t_) * B + (b_ < B ? b_ : B - 1)) * (4 * H) + u0 + ul_;              \
+        gxp[k][0] = Gx[gx_]; gxp[k][1] = Gx[gx_ + H]; gxp[k][2] = Gx[gx_ + 2 * H]; gxp[k][3] = Gx[gx_ + 3 * H]; \
+    }
+    LS_FETCH_GX(0);
     for (int t = 0; t < U; ++t) {
         constexpr int NRT = LS_MAXB / 16;
         f4 acc[NRT];
@@ -124,28 +137,39 @@ __global__ __launch_bounds__(LS_THREADS, 1) void lstm_fwd_kernel(
                 for (int r = 0; r < 4; ++r) sG[(wave * LS_MAXB + rt * 16 + q4 * 4 + r) * 16 + c] = acc[rt][r];
         __syncthreads();
         __bf16* hdst = hx + (size_t)(t & 1) * B * H;
+        float kg[EPT][4], kh[EPT];
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const int e = tid + LS_THREADS * k, b = e >> 4, ul = e & 15;
+            if (b < B) {
+                const float gi = sigmoidf_(sG[(0 * LS_MAXB + b) * 16 + ul] + gxp[k][0]);
+                const float gf = sigmoidf_(sG[(1 * LS_MAXB + b) * 16 + ul] + gxp[k][1]);
+                const float gg = tanhf(sG[(2 * LS_MAXB + b) * 16 + ul] + gxp[k][2]);
+                const float go = sigmoidf_(sG[(3 * LS_MAXB + b) * 16 + ul] + gxp[k][3]);
+                cst[k] = gf * cst[k] + gi * gg;
+                const float h = go * tanhf(cst[k]);
+                hdst[(size_t)b * H + u0 + ul] = (__bf16)h;
+                kg[k][0] = gi; kg[k][1] = gf; kg[k][2] = gg; kg[k][3] = go; kh[k] = h;
+            }
+        }
+        if (t + 1 < U) grid_arrive(sync);
+        // off the chain: what only the caller / the backward reads, and the next step's input projections
 #pragma unroll
         for (int k = 0; k < EPT; ++k) {
             const int e = tid + LS_THREADS * k, b = e >> 4, ul = e & 15;
             if (b < B) {
                 const size_t gx = ((size_t)t * B + b) * (4 * H) + u0 + ul;
-                const float gi = sigmoidf_(sG[(0 * LS_MAXB + b) * 16 + ul] + Gx[gx]);
-                const float gf = sigmoidf_(sG[(1 * LS_MAXB + b) * 16 + ul] + Gx[gx + H]);
-                const float gg = tanhf(sG[(2 * LS_MAXB + b) * 16 + ul] + Gx[gx + 2 * H]);
-                const float go = sigmoidf_(sG[(3 * LS_MAXB + b) * 16 + ul] + Gx[gx + 3 * H]);
-                cst[k] = gf * cst[k] + gi * gg;
-                const float h = go * tanhf(cst[k]);
                 const size_t ho = ((size_t)t * B + b) * H + u0 + ul;
-                Hout[ho] = h;
-                hdst[(size_t)b * H + u0 + ul] = (__bf16)h;
+                Hout[ho] = kh[k];
                 if (gates) {
-                    gates[gx] = gi; gates[gx + H] = gf; gates[gx + 2 * H] = gg; gates[gx + 3 * H] = go;
+                    gates[gx] = kg[k][0]; gates[gx + H] = kg[k][1]; gates[gx + 2 * H] = kg[k][2]; gates[gx + 3 * H] = kg[k][3];
                     Cs[ho] = cst[k];
                 }
             }
         }
-        if (t + 1 < U) grid_arrive(sync);
+        if (t + 1 < U) LS_FETCH_GX(t + 1);
     }
+#undef LS_FETCH_GX
 }
 
 // ------------------------------------------------------------------------------------------------ backward
@@ -175,6 +199,19 @@ __global__ __launch_bounds__(LS_THREADS, 1) void lstm_bwd_kernel(
     for (int k = 0; k < EPT; ++k) dcc[k] = 0.f;
     __syncthreads();
     const int ksteps = H4 / 32, kper = (ksteps + 3) / 4;  // K split over the 4 waves
+    // As in the forward, what does not depend on the hand-off is taken off the serial chain: the step's saved activations
+    // (7 values per element) are requested before the wait, the dG stores (read by the caller's GEMMs only) follow the arrival.
+    float pv[EPT][7];   // dHout, i, f, g, o, c_t, c_{t-1}
+#define LS_FETCH_SAVED(t_)                                                                                \
+    _Pragma("unroll") for (int k = 0; k < EPT; ++k) {                                                     \
+        const int e_ = tid + LS_THREADS * k, b_ = e_ >> 4, ul_ = e_ & 15;                                 \
+        const int bc_ = b_ < B ? b_ : B - 1;                                                              \
+        const size_t ho_ = ((size_t)(t_) * B + bc_) * H + u0 + ul_;                                       \
+        const size_t gx_ = ((size_t)(t_) * B + bc_) * H4 + u0 + ul_;                                      \
+        pv[k][0] = dHout[ho_]; pv[k][1] = gates[gx_]; pv[k][2] = gates[gx_ + H]; pv[k][3] = gates[gx_ + 2 * H]; \
+        pv[k][4] = gates[gx_ + 3 * H]; pv[k][5] = Cs[ho_]; pv[k][6] = ((t_) > 0) ? Cs[ho_ - (size_t)B * H] : 0.f; \
+    }
+    LS_FETCH_SAVED(U - 1);
     for (int t = U - 1; t >= 0; --t) {
         const int phase = U - 1 - t;  // 0,1,2,...
         constexpr int NRT = LS_MAXB / 16;
@@ -205,18 +242,16 @@ __global__ __launch_bounds__(LS_THREADS, 1) void lstm_bwd_kernel(
                 for (int r = 0; r < 4; ++r) sP[(wave * LS_MAXB + rt * 16 + q4 * 4 + r) * 16 + c] = acc[rt][r];
         __syncthreads();
         __bf16* dst = dgx + (size_t)(phase & 1) * B * H4;
+        float kd[EPT][4];
 #pragma unroll
         for (int k = 0; k < EPT; ++k) {
             const int e = tid + LS_THREADS * k, b = e >> 4, ul = e & 15;
             if (b < B) {
                 const float dhrec = sP[(0 * LS_MAXB + b) * 16 + ul] + sP[(1 * LS_MAXB + b) * 16 + ul] +
                                     sP[(2 * LS_MAXB + b) * 16 + ul] + sP[(3 * LS_MAXB + b) * 16 + ul];
-                const size_t ho = ((size_t)t * B + b) * H + u0 + ul;
-                const size_t gx = ((size_t)t * B + b) * H4 + u0 + ul;
-                const float dh = dHout[ho] + dhrec;
-                const float gi = gates[gx], gf = gates[gx + H], gg = gates[gx + 2 * H], go = gates[gx + 3 * H];
-                const float ct = Cs[ho];
-                const float cprev = (t > 0) ? Cs[ho - (size_t)B * H] : 0.f;
+                const float dh = pv[k][0] + dhrec;
+                const float gi = pv[k][1], gf = pv[k][2], gg = pv[k][3], go = pv[k][4];
+                const float ct = pv[k][5], cprev = pv[k][6];
                 const float tc = tanhf(ct);
                 const float dct = dh * go * (1.f - tc * tc) + dcc[k];
                 const float di = dct * gg * gi * (1.f - gi);
@@ -224,14 +259,24 @@ __global__ __launch_bounds__(LS_THREADS, 1) void lstm_bwd_kernel(
                 const float dgg = dct * gi * (1.f - gg * gg);
                 const float dout = dh * tc * go * (1.f - go);
                 dcc[k] = dct * gf;
-                dG[gx] = di; dG[gx + H] = dfg; dG[gx + 2 * H] = dgg; dG[gx + 3 * H] = dout;
                 const size_t xo = (size_t)b * H4 + u0 + ul;
                 dst[xo] = (__bf16)di; dst[xo + H] = (__bf16)dfg; dst[xo + 2 * H] = (__bf16)dgg; dst[xo + 3 * H] = (__bf16)dout;
+                kd[k][0] = di; kd[k][1] = dfg; kd[k][2] = dgg; kd[k][3] = dout;
             }
         }
         if (t > 0) grid_arrive(sync);
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const int e = tid + LS_THREADS * k, b = e >> 4, ul = e & 15;
+            if (b < B) {
+                const size_t gx = ((size_t)t * B + b) * H4 + u0 + ul;
+                dG[gx] = kd[k][0]; dG[gx + H] = kd[k][1]; dG[gx + 2 * H] = kd[k][2]; dG[gx + 3 * H] = kd[k][3];
+            }
+        }
+        if (t > 0) LS_FETCH_SAVED(t - 1);
         __syncthreads();  // sP reused next step
     }
+#undef LS_FETCH_SAVED
 }
 
 }  // namespace
