@@ -221,6 +221,18 @@ int ia_gemm_bf16(const void* A, int lda, const void* W, int ldw, int M, int N, i
  *                       to [N,3,3,C]), out [B,T2,F2,N] bf16.  C % 64 == 0.
  *   The final Linear(C*F2 -> d) is ia_gemm_bf16 on the [B*T2, F2*N] view with the weight's columns permuted from the
  *   reference's (c,f) order to (f,c). */
+/* Device-resident greedy transducer decoding (csrc/greedy_decode.hip): the frame-synchronous loop of
+ * GreedyBatchedRNNTInfer (A/parts/submodules/rnnt_greedy_decoding.py:711-909) in one launch, one persistent workgroup per
+ * utterance, no host read per micro-step.  f_all [B,T,Hj] f32 = joint.enc(encoder output); out_len [B]; EW [(V+1), 4Hp] f32 =
+ * W_ih embedding[row] + b_ih + b_hh for rows 0..V-2 = the language's labels, row_blank = embedding[blank_idx], row_sos = zero
+ * input; Whh [4Hp,Hp], Wpred [Hj,Hp] + bpred, Whead [V,Hj] + bhead (the language's head), all f32.  tokens [B, cap] int32,
+ * counts [B]; *overflow set if an utterance emitted more than cap symbols.  Hp, Hj multiples of 4. */
+int ia_greedy_decode_lds_bytes(int Hp, int Hj, int V);
+int ia_greedy_rnnt_decode(const float* f_all, const int64_t* out_len, const float* EW, const float* Whh, const float* Wpred,
+                          const float* bpred, const float* Whead, const float* bhead, int B, int T, int Hp, int Hj, int V,
+                          int blank, int row_blank, int row_sos, int max_symbols, int* tokens, int cap, int* counts,
+                          int* overflow, ia_stream_t stream);
+
 /* fp8 (OCP e4m3) projections of the frozen prefix (csrc/gemm_fp8.hip; BASELINE configs[4] "fp8 MFMA"; no reference
  * semantics -- tolerance vs the fp32 oracle stated in tests/test_fp8_gpu.py):
  *   ia_quantize_fp8_rows   q [M, ldq] e4m3 = x / scale[m], scale[m] = amax(row m) / 448 (1 for a zero row); x bf16 or f32

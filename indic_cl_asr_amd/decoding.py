@@ -4,8 +4,10 @@
   (A/parts/submodules/rnnt_greedy_decoding.py:711-909): frame-synchronous over the batch, at most `max_symbols`
   prediction-net + joint micro-steps per frame, sticky per-frame blank mask, hidden state rolled back for utterances that
   emitted blank.  All tensors stay on the device and the loop makes ONE host read per micro-step (`blank_mask.all()`, as the
-  reference does); the encoder and prediction projections of the joint are hoisted out of the loop.  This is the
-  host-driven form; a device-resident persistent kernel (no host read per micro-step) is the planned MI355X form.
+  reference does); the encoder and prediction projections of the joint are hoisted out of the loop.  On the MI355X the
+  same decode runs DEVICE-RESIDENT (csrc/greedy_decode.hip: one launch, one persistent workgroup per utterance, no host
+  read per micro-step) -- greedy_rnnt_decode dispatches to it; the host-driven loop stays as greedy_rnnt_decode_host
+  (CPU tensors, and the cross-check of the kernel in tests).
 * greedy_ctc_decode   -- GreedyCTCInfer (ctc_greedy_decoding.py:145-229): argmax, collapse repeats, drop blanks.
 * word_error_rate / WER -- A/metrics/wer.py:293-360: sum of edit distances over sum of reference lengths.  Hypotheses
   and references are sequences of tokens here; pass `detokenize` (ids -> str) to score words as the reference does
@@ -65,6 +67,77 @@ class WER:
 @torch.no_grad()
 def greedy_rnnt_decode(model, encoded, encoded_len, language_ids, max_symbols: Optional[int] = 10) -> List[List[int]]:
     """encoded [B,d,T'] (encoder output), encoded_len [B] -> per-utterance language-local token ids."""
+    if encoded.is_cuda and device_decode_supported(model):
+        return greedy_rnnt_decode_device(model, encoded, encoded_len, language_ids, max_symbols)
+    return greedy_rnnt_decode_host(model, encoded, encoded_len, language_ids, max_symbols)
+
+
+def device_decode_supported(model) -> bool:
+    from . import _lib
+    c = model.cfg
+    return (c.pred_hidden % 4 == 0 and c.joint_hidden % 4 == 0
+            and _lib.lib().ia_greedy_decode_lds_bytes(c.pred_hidden, c.joint_hidden, c.vocab_per_lang + 1) <= 160 * 1024
+            and model.decoder.prediction["dec_rnn"].lstm.num_layers == 1)
+
+
+@torch.no_grad()
+def greedy_rnnt_decode_device(model, encoded, encoded_len, language_ids, max_symbols: Optional[int] = 10) -> List[List[int]]:
+    """The same decode in ONE launch (csrc/greedy_decode.hip).  Setup on the HIP fp32 GEMM: the joint's encoder projection of
+    all frames and the table EW = W_ih embedding[row] + b_ih + b_hh over the 257 rows the loop can feed the prediction
+    network (the language's labels by their ids as decoding.greedy_rnnt_decode_host feeds them, the blank / padding row, the
+    zero SOS input); one device->host copy of the token matrix at the end."""
+    from . import _lib
+    from . import cl
+    cl.flush_pending_updates()
+    if len(set(language_ids)) != 1:
+        raise NotImplementedError("greedy_rnnt_decode: one language per batch (as the CL scripts evaluate)")
+    L = _lib.lib()
+    dec, joint = model.decoder, model.joint
+    dev = encoded.device
+    B, d, T = encoded.shape
+    V = model.cfg.vocab_per_lang + 1
+    blank = V - 1
+    Hp, Hj = model.cfg.pred_hidden, model.cfg.joint_hidden
+    head = joint.joint_net[-1][language_ids[0]]
+    lstm = dec.prediction["dec_rnn"].lstm
+    emb = dec.prediction["embed"].weight
+
+    def gemm32(a, w):   # a [M,K] @ w[N,K]^T on csrc/gemm_f32.hip
+        a, w = a.float().contiguous(), w.float().contiguous()
+        if a.shape[1] % 16 != 0:
+            return a @ w.t()
+        out = torch.empty(a.shape[0], w.shape[0], dtype=torch.float32, device=dev)
+        _lib.check(L.ia_gemm_f32(_lib.ptr(a), a.shape[1], _lib.ptr(w), w.shape[1], a.shape[0], w.shape[0], a.shape[1], _lib.ptr(out),
+                                 w.shape[0], _lib.stream_ptr()), "ia_gemm_f32")
+        return out
+
+    f_all = (gemm32(encoded.transpose(1, 2).reshape(B * T, d), joint.enc.weight) + joint.enc.bias.float()).view(B, T, Hj).contiguous()
+    rows = torch.cat([emb[:blank].float(), emb[dec.blank_idx:dec.blank_idx + 1].float(),
+                      torch.zeros(1, Hp, dtype=torch.float32, device=dev)], 0)                      # [V + 1, Hp]
+    EW = (gemm32(rows, lstm.weight_ih_l0) + (lstm.bias_ih_l0 + lstm.bias_hh_l0).float()).contiguous()
+    ms = int(max_symbols) if max_symbols is not None else 1 << 30
+    cap = T * (int(max_symbols) if max_symbols is not None else 8)
+    tokens = torch.empty(B, cap, dtype=torch.int32, device=dev)
+    counts = torch.zeros(B, dtype=torch.int32, device=dev)
+    overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+    out_len = encoded_len.to(dev).long().contiguous()
+    Whh = lstm.weight_hh_l0.float().contiguous()
+    Wp, bp = joint.pred.weight.float().contiguous(), joint.pred.bias.float().contiguous()
+    Wh, bh = head.weight.float().contiguous(), head.bias.float().contiguous()
+    st = L.ia_greedy_rnnt_decode(_lib.ptr(f_all), _lib.ptr(out_len), _lib.ptr(EW), _lib.ptr(Whh), _lib.ptr(Wp), _lib.ptr(bp),
+                                 _lib.ptr(Wh), _lib.ptr(bh), B, T, Hp, Hj, V, blank, blank, V, ms, _lib.ptr(tokens), cap,
+                                 _lib.ptr(counts), _lib.ptr(overflow), _lib.stream_ptr())
+    _lib.check(st, "ia_greedy_rnnt_decode")
+    host_tok, host_n, ovf = tokens.cpu(), counts.cpu().tolist(), int(overflow.item())
+    if ovf:
+        raise RuntimeError("greedy_rnnt_decode: an utterance emitted more symbols than the output buffer holds "
+                           f"({cap} per utterance); pass a finite max_symbols")
+    return [host_tok[b, :host_n[b]].tolist() for b in range(B)]
+
+
+@torch.no_grad()
+def greedy_rnnt_decode_host(model, encoded, encoded_len, language_ids, max_symbols: Optional[int] = 10) -> List[List[int]]:
+    """Host-driven form (one host read per micro-step, as the reference)."""
     dec, joint = model.decoder, model.joint
     dev = encoded.device
     B = encoded.shape[0]
