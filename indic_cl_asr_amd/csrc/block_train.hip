@@ -165,7 +165,8 @@ extern "C" size_t ia_conformer_block_bwd_ws_bytes(int B, int T, int d, int d_ff,
 
 extern "C" int ia_conformer_block_supported(int d, int d_ff, int H, int ksz, int T) {
     if (d <= 0 || H <= 0 || d % H != 0) return 0;
-    return (d % 64 == 0 && d <= 1024 && 256 % (d / 4) == 0 && d_ff % 64 == 0 && ksz <= 31 && d / H == 64 && T >= 1) ? 1 : 0;
+    const int dk = d / H;
+    return (d % 8 == 0 && d <= 1024 && d_ff % 8 == 0 && ksz <= 31 && (ksz & 1) == 1 && dk <= 64 && dk % 4 == 0 && T >= 1) ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------ forward

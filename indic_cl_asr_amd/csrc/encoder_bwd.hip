@@ -170,8 +170,11 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_reduce_kernel(const float* __
                                                                  const float* __restrict__ bn_sumsq, const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, float eps,
                                                                  float* __restrict__ part, int rows_per_block) {
-    // thread = 4 channels x one of (256/(d/4)) row lanes; d % 4 == 0, (d/4) divides 256
-    const int cg = d / 4, c0 = (threadIdx.x % cg) * 4, rl = threadIdx.x / cg, nrl = 256 / cg;
+    // thread = 4 channels x one of floor(256/(d/4)) row lanes; d % 4 == 0, d <= 1024 (d = 144: 36 channel groups x 7 row
+    // lanes, the last 4 threads idle)
+    const int cg = d / 4, nrl = 256 / cg;
+    const bool active = (int)threadIdx.x < nrl * cg;
+    const int c0 = (active ? (int)threadIdx.x % cg : 0) * 4, rl = active ? (int)threadIdx.x / cg : nrl;
     const float inv_n = 1.f / (float)n_rows;
     float mean[4], rstd[4], gm[4], bt[4], a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -182,7 +185,7 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_reduce_kernel(const float* __
     }
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = (r0 + rows_per_block < n_rows) ? r0 + rows_per_block : n_rows;
-    for (int64_t r = r0 + rl; r < r1; r += nrl) {
+    for (int64_t r = r0 + rl; active && r < r1; r += nrl) {
         const float4 zz = *reinterpret_cast<const float4*>(z + r * d + c0);
         union { uint2 u; __bf16 h[4]; } g;
         g.u = *reinterpret_cast<const uint2*>(dc3 + r * d + c0);
@@ -389,7 +392,7 @@ extern "C" int ia_bn_silu_bwd(const float* z, const void* dc3, int64_t n_rows, i
                               float* scratch, ia_stream_t stream) {
     if (!z || !dc3 || !bn_sum || !bn_sumsq || !gamma || !beta || !S1 || !S2 || !dz || !scratch || n_rows <= 1 || d <= 0)
         return IA_INVALID_VALUE;
-    if (d % 4 != 0 || 256 % (d / 4) != 0) return IA_UNSUPPORTED;
+    if (d % 4 != 0 || d > 1024) return IA_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const int rpb = bnb_rows_per_block(n_rows);
     const int G = (int)((n_rows + rpb - 1) / rpb);
@@ -412,7 +415,7 @@ extern "C" int ia_bn_silu_bwd_reduce(const float* z, const void* dc3, int64_t n_
                                      float* scratch, ia_stream_t stream) {
     if (!z || !dc3 || !bn_sum || !bn_sumsq || !gamma || !beta || !S1 || !S2 || !scratch || n_rows <= 1 || d <= 0)
         return IA_INVALID_VALUE;
-    if (d % 4 != 0 || 256 % (d / 4) != 0) return IA_UNSUPPORTED;
+    if (d % 4 != 0 || d > 1024) return IA_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const int rpb = bnb_rows_per_block(n_rows);
     const int G = (int)((n_rows + rpb - 1) / rpb);

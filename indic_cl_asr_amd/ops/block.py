@@ -81,7 +81,7 @@ DIRECT_ACCUMULATE = True
 def block_supported(layer, x2d, T):
     d = x2d.shape[-1]
     bn = layer.conv.batch_norm
-    return (x2d.is_cuda and d % 64 == 0 and d <= 1024 and fast.bn_module_ok(bn) and 256 % (d // 4) == 0
+    return (x2d.is_cuda and d % 8 == 0 and d <= 1024 and fast.bn_module_ok(bn)
             and layer.conv.depthwise_conv.weight.shape[-1] <= 31 and fast.attention_flash_supported(T, layer.self_attn.d_k))
 
 
