@@ -45,11 +45,14 @@ __device__ __forceinline__ unsigned g_hash32(unsigned x) {
 struct ConvRow { int b, t2, f2; };  // output pixel of a tile row (t2 < 0: row past M)
 
 __device__ __forceinline__ uint4 conv_a_load(const GemmArgs& a, const ConvRow& r, int k0, int kv) {
-    const int tap = k0 / a.cC, c0 = k0 - tap * a.cC;
+    // the tap is taken per 16-byte vector (8 input channels), not per 64-wide k-tile: any channel count % 8 == 0 (144: tiles
+    // straddle taps); k beyond 9*C (the zero-padded tail of the last tile) reads as zero
+    const int k = k0 + kv * 8;
+    const int tap = k / a.cC, c0 = k - tap * a.cC;
     const int dt = tap / 3, df = tap - dt * 3;
     const int t1 = 2 * r.t2 + dt - 1, f1 = 2 * r.f2 + df - 1;
-    if (r.t2 < 0 || t1 < 0 || t1 >= a.cT1 || f1 < 0 || f1 >= a.cF1) return make_uint4(0, 0, 0, 0);
-    return *reinterpret_cast<const uint4*>(a.A + (((size_t)r.b * a.cT1 + t1) * a.cF1 + f1) * a.cC + c0 + kv * 8);
+    if (k >= a.K || r.t2 < 0 || t1 < 0 || t1 >= a.cT1 || f1 < 0 || f1 >= a.cF1) return make_uint4(0, 0, 0, 0);
+    return *reinterpret_cast<const uint4*>(a.A + (((size_t)r.b * a.cT1 + t1) * a.cF1 + f1) * a.cC + c0);
 }
 
 template <int BM, int BN, bool CONV = false>
@@ -267,6 +270,8 @@ __global__ __launch_bounds__(256) void conv1_relu_cl_kernel(const float* __restr
     // thread = 8 fixed output channels (weights in registers) x a strided set of output pixels; the C/8 threads that
     // share a pixel read the same 9 inputs (L1 broadcast) and write one contiguous C*2-byte row.
     const int cg = C / 8;
+    const int ppb = 256 / cg;  // pixel groups per workgroup pass; threads beyond ppb * cg idle (C = 144: 18 x 14 = 252)
+    if ((int)threadIdx.x >= ppb * cg) return;
     const int c0 = (threadIdx.x % cg) * 8;
     float wr[8][9], br[8];
 #pragma unroll
@@ -279,7 +284,6 @@ __global__ __launch_bounds__(256) void conv1_relu_cl_kernel(const float* __restr
     // up front (one exposed load latency per CP1 pixels; the one-pixel version was latency-bound at 15 dependent
     // iterations per thread: 260 us for a 0.5 GB write)
     constexpr int CP1 = 4;
-    const int ppb = 256 / cg;  // pixel groups per workgroup pass (blockDim is a multiple of cg)
     const int F1g = (F1 + CP1 - 1) / CP1;
     const int64_t ngrp = (int64_t)B * T1 * F1g;
     for (int64_t pg = (int64_t)blockIdx.x * ppb + threadIdx.x / cg; pg < ngrp; pg += (int64_t)gridDim.x * ppb) {
@@ -319,7 +323,7 @@ __global__ __launch_bounds__(256) void conv1_relu_cl_kernel(const float* __restr
 extern "C" int ia_subsample_conv1(const float* feats, int B, int Fm, int Tm, int C, const float* w1, const float* b1,
                                   void* out, ia_stream_t stream) {
     if (!feats || !w1 || !b1 || !out || B <= 0 || Fm <= 0 || Tm <= 0 || C <= 0 || C % 8 != 0) return IA_INVALID_VALUE;
-    if (256 % (C / 8) != 0) return IA_UNSUPPORTED;  // C in {8,16,...,2048} with C/8 dividing 256
+    if (C > 2048) return IA_UNSUPPORTED;
     const int T1 = (Tm - 1) / 2 + 1, F1 = (Fm - 1) / 2 + 1;
     const int64_t passes = ((int64_t)B * T1 * ((F1 + 3) / 4) + (256 / (C / 8)) - 1) / (256 / (C / 8));
     const int grid = (int)(passes < 8192 ? passes : 8192);
@@ -332,7 +336,7 @@ extern "C" int ia_subsample_conv1(const float* feats, int B, int Fm, int Tm, int
 extern "C" int ia_subsample_conv2(const void* in_cl, int B, int T1, int F1, int C, const void* w2r, const float* b2, int N,
                                   void* out, ia_stream_t stream) {
     if (!in_cl || !w2r || !b2 || !out || B <= 0 || T1 <= 0 || F1 <= 0) return IA_INVALID_VALUE;
-    if (C % G_BK != 0 || N % 8 != 0 || !ia_is_aligned(in_cl, 16) || !ia_is_aligned(w2r, 16) || !ia_is_aligned(out, 16))
+    if (C % 8 != 0 || N % 8 != 0 || !ia_is_aligned(in_cl, 16) || !ia_is_aligned(w2r, 16) || !ia_is_aligned(out, 16))
         return IA_UNSUPPORTED;
     GemmArgs a;
     a.A = (const __bf16*)in_cl; a.W = (const __bf16*)w2r; a.bias = b2; a.R = nullptr; a.outF = nullptr; a.outH = (__bf16*)out;

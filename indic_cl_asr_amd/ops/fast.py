@@ -499,8 +499,8 @@ def _cached(key, params, make):
 
 
 def subsample_supported(C, d, feat_in):
-    return (C % 64 == 0 and 256 % (C // 8) == 0 and d % 8 == 0
-            and (C * (((feat_in - 1) // 2 + 1 - 1) // 2 + 1)) % 64 == 0)
+    return (C % 8 == 0 and C <= 2048 and d % 8 == 0
+            and (C * (((feat_in - 1) // 2 + 1 - 1) // 2 + 1)) % 8 == 0)
 
 
 def conv_subsampling(feats_bft, conv1, conv2, lin):
