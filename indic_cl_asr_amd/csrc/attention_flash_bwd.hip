@@ -604,7 +604,12 @@ inline FbWs fb_ws_layout(int B, int T, int H, int dk) {
     w.D = up((int64_t)B * ((T + 63) / 64) * 2 * H * dk);
     w.dpos = w.D + up((int64_t)B * H * T);
     w.tn = w.dpos + up((int64_t)H * ((int64_t)rs * 64 + rs));
-    w.total = w.tn + up(ia_gemm_tn_scratch_elems(B * T, rs, 64));
+    {
+        ia_tn_problem pr[8];
+        const int nh = H < 8 ? H : 8;
+        for (int i = 0; i < nh; ++i) pr[i] = ia_tn_problem{nullptr, nullptr, nullptr, nullptr, rs, 64, B * T, rs, 64};
+        w.total = w.tn + up(ia_gemm_tn_grouped_scratch_elems(pr, nh));
+    }
     return w;
 }
 }  // namespace
@@ -666,10 +671,16 @@ extern "C" int ia_relpos_attention_flash_bwd(const void* qkv, const void* pos_pr
     // position-projection gradient: per head dpos_h [Rs, 64] = dBand_h^T (q+v)_h over the B*T rows (split-K TN GEMM), then
     // the band columns pad0 .. pad0 + 2T-2 go to dpl [pl_rows, d] bf16
     float* dpos = ws + w.dpos;
-    for (int h = 0; h < H; ++h) {
-        float* o = dpos + (size_t)h * ((size_t)rs * 64 + rs);
-        const int rc = ia_gemm_tn_bf16((const __bf16*)dBand + (size_t)h * B * T * rs, rs, (const __bf16*)QvHM + (size_t)h * B * T * 64, 64,
-                                       B * T, rs, 64, o, o + (size_t)rs * 64, ws + w.tn, stream);
+    for (int h0 = 0; h0 < H; h0 += 8) {   // the heads' TN GEMMs as grouped launches (one GEMM + one finishing pass per <= 8 heads)
+        ia_tn_problem pr[8];
+        const int nh = H - h0 < 8 ? H - h0 : 8;
+        for (int i = 0; i < nh; ++i) {
+            const int h = h0 + i;
+            float* o = dpos + (size_t)h * ((size_t)rs * 64 + rs);
+            pr[i] = ia_tn_problem{(const __bf16*)dBand + (size_t)h * B * T * rs, (const __bf16*)QvHM + (size_t)h * B * T * 64, o, nullptr,
+                                  rs, 64, B * T, rs, 64};
+        }
+        const int rc = ia_gemm_tn_bf16_grouped(pr, nh, ws + w.tn, stream);
         if (rc != IA_OK) return rc;
     }
     const int64_t items = (int64_t)pl_rows * H * (dk / 4);
