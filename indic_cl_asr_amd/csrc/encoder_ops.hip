@@ -111,6 +111,13 @@ __global__ __launch_bounds__(256) void bn_silu_kernel(const float* __restrict__ 
         const float sc = rsqrtf(var + eps) * gamma[cch];
         s_scale[cch] = sc;
         s_shift[cch] = beta[cch] - mean * sc;
+        // train-mode running statistics (unbiased variance), by the first workgroup: nobody reads them in this mode
+        if (training && running_mean && running_var && blockIdx.x == 0) {
+            const float unbiased = var * ((float)n_rows / (float)(n_rows - 1));
+            running_mean[cch] = (1.f - momentum) * running_mean[cch] + momentum * mean;
+            running_var[cch] = (1.f - momentum) * running_var[cch] + momentum * unbiased;
+            if (cch == 0 && num_batches) num_batches[0] += 1;
+        }
     }
     __syncthreads();
     const int64_t total8 = n_rows * d / 8;
@@ -126,22 +133,6 @@ __global__ __launch_bounds__(256) void bn_silu_kernel(const float* __restrict__ 
         }
         reinterpret_cast<uint4*>(out)[i] = o.u;
     }
-}
-
-__global__ void bn_running_update_kernel(const float* __restrict__ bn_sum, const float* __restrict__ bn_sumsq, int d,
-                                         int64_t n_rows, float* __restrict__ running_mean,
-                                         float* __restrict__ running_var, int64_t* __restrict__ num_batches,
-                                         float momentum) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c < d) {
-        const float inv_n = 1.f / (float)n_rows;
-        const float mean = bn_sum[c] * inv_n;
-        const float var = fmaxf(bn_sumsq[c] * inv_n - mean * mean, 0.f);
-        const float unbiased = var * ((float)n_rows / (float)(n_rows - 1));
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
-    }
-    if (c == 0 && num_batches) num_batches[0] += 1;
 }
 
 // SyncBatchNorm (torch.nn.SyncBatchNorm semantics, R/cl_baseline.py:133): `sums` = [sum(d) | sumsq(d) | count] already
@@ -241,11 +232,6 @@ extern "C" int ia_bn_silu(const float* z, int64_t n_rows, int d, const float* bn
     hipLaunchKernelGGL(bn_silu_kernel, dim3(grid), dim3(256), 0, st, z, n_rows, d, bn_sum, bn_sumsq, gamma, beta,
                        running_mean, running_var, num_batches_tracked, momentum, eps, training, (__bf16*)out);
     IA_RETURN_IF_LAUNCH_FAILED();
-    if (training && running_mean && running_var) {
-        hipLaunchKernelGGL(bn_running_update_kernel, dim3((d + 255) / 256), dim3(256), 0, st, bn_sum, bn_sumsq, d, n_rows,
-                           running_mean, running_var, num_batches_tracked, momentum);
-        IA_RETURN_IF_LAUNCH_FAILED();
-    }
     return IA_OK;
 }
 
