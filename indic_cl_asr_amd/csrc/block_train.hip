@@ -59,6 +59,51 @@ int transpose_bf16(const void* in, int rows, int cols, void* out, hipStream_t st
     return IA_OK;
 }
 
+// the same for up to 8 matrices in one launch (the weight images of a block's data-gradient GEMMs)
+struct TrJob { const unsigned short* in; unsigned short* out; int rows, cols, tile_begin, tiles_c; };
+struct TrJobs { TrJob j[8]; int count; };
+__global__ __launch_bounds__(256) void transpose_bf16_multi_kernel(TrJobs jobs) {
+    __shared__ unsigned short tile[64][72];
+    int ji = 0;
+#pragma unroll
+    for (int i = 1; i < 8; ++i)
+        if (i < jobs.count && (int)blockIdx.x >= jobs.j[i].tile_begin) ji = i;
+    const TrJob& J = jobs.j[ji];
+    const int local = blockIdx.x - J.tile_begin;
+    const int tr = local / J.tiles_c, tc = local - tr * J.tiles_c;
+    const int r0 = tr * 64, c0 = tc * 64, rows = J.rows, cols = J.cols;
+    for (int i = threadIdx.x; i < 64 * 8; i += 256) {
+        const int r = i >> 3, v = i & 7;
+        uint4 x = make_uint4(0, 0, 0, 0);
+        if (r0 + r < rows && c0 + v * 8 < cols) x = *reinterpret_cast<const uint4*>(J.in + (size_t)(r0 + r) * cols + c0 + v * 8);
+        *reinterpret_cast<uint4*>(&tile[r][v * 8]) = x;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 8; i += 256) {
+        const int c = i >> 3, v = i & 7;
+        if (c0 + c < cols && r0 + v * 8 < rows) {
+            union { uint4 u; unsigned short h[8]; } o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o.h[j] = tile[v * 8 + j][c];
+            *reinterpret_cast<uint4*>(J.out + (size_t)(c0 + c) * rows + r0 + v * 8) = o.u;
+        }
+    }
+}
+struct TrList { TrJobs jobs; int tiles; };
+inline void tr_add(TrList* l, const void* in, int rows, int cols, void* out) {
+    TrJob& J = l->jobs.j[l->jobs.count++];
+    J.in = (const unsigned short*)in; J.out = (unsigned short*)out; J.rows = rows; J.cols = cols;
+    J.tile_begin = l->tiles; J.tiles_c = (cols + 63) / 64;
+    l->tiles += ((rows + 63) / 64) * J.tiles_c;
+}
+int tr_launch(const TrList& l, hipStream_t st) {
+    for (int i = 0; i < l.jobs.count; ++i)
+        if (l.jobs.j[i].rows % 8 != 0 || l.jobs.j[i].cols % 8 != 0) return IA_UNSUPPORTED;
+    hipLaunchKernelGGL(transpose_bf16_multi_kernel, dim3(l.tiles), dim3(256), 0, st, l.jobs);
+    IA_RETURN_IF_LAUNCH_FAILED();
+    return IA_OK;
+}
+
 // dst[k][i] += src[k][i]: one launch for all parameter gradients of a block (table rows: dst, src, n)
 struct AddRow { float* dst; const float* src; int64_t n; };
 __global__ __launch_bounds__(256) void multi_add_kernel(const AddRow* __restrict__ table, int rows) {
@@ -99,7 +144,7 @@ BwdWs bwd_ws(int B, int T, int d, int d_ff, int ksz) {
     w.Gm = o;   o = up256(o + N * d * 4);
     w.dc2 = o;  o = up256(o + N * 2 * d * 2);
     w.dctx = o; o = up256(o + N * d * 2);
-    w.wt = o;   o = up256(o + (size_t)d_ff * d * 2);                                   // one transposed weight image at a time
+    w.wt = o;   o = up256(o + ((size_t)4 * d_ff * d + (size_t)7 * d * d) * 2);              // the block's eight transposed weight images
     size_t scr = (size_t)ia_layernorm_bwd_scratch_elems((int)N, d);
     const int shapes[5][2] = {{d, d_ff}, {d_ff, d}, {d, d}, {2 * d, d}, {3 * d, d}};   // (n, k) of every weight gradient
     for (int i = 0; i < 5; ++i) {
@@ -145,12 +190,11 @@ int flush_group(const ia_tn_problem* grp, int ngrp, float* scr, ia_stream_t stre
         IA_TRY(ia_gemm_tn_bf16(grp[i].dY, grp[i].ldy, grp[i].X, grp[i].ldx, grp[i].M, grp[i].n, grp[i].k, grp[i].dW, grp[i].db, scr, stream));
     return IA_OK;
 }
-int linear_bwd_deferred(const void* dY, const void* X, const void* W, int M, int n, int k, void* dX, float* dW, float* db, void* wt,
+// (wt = the transposed image [k, n] of W, made by the multi-matrix transpose at the head of the call)
+int linear_bwd_deferred(const void* dY, const void* X, const void* W, int M, int n, int k, void* dX, float* dW, float* db, const void* wt,
                         ia_tn_problem* grp, int* ngrp, ia_stream_t stream) {
-    if (dX) {
-        IA_TRY(transpose_bf16(W, n, k, wt, (hipStream_t)stream));
-        IA_TRY(ia_gemm_bf16(dY, n, wt, n, M, k, n, nullptr, 0, 0.f, 0, 1.f, nullptr, 0, nullptr, 0, dX, k, stream));
-    }
+    (void)W;
+    if (dX) IA_TRY(ia_gemm_bf16(dY, n, wt, n, M, k, n, nullptr, 0, 0.f, 0, 1.f, nullptr, 0, nullptr, 0, dX, k, stream));
     grp[*ngrp] = ia_tn_problem{dY, X, dW, db, n, k, M, n, k};
     ++*ngrp;
     return IA_OK;
@@ -253,18 +297,28 @@ extern "C" int ia_conformer_block_bwd_a_phase(const ia_block_params* Lp, const i
     const float p = L.p_drop, pff = L.p_ff;
     ia_tn_problem grp[8];
     int ngrp = 0;
+    // transposed weight images of this call's five data-gradient GEMMs, one launch (they persist in the workspace for phase 2)
+    char* wtb = (char*)wt;
+    void *wt_ff2b = wtb, *wt_ff2a = wtb + (size_t)d * d_ff * 2, *wt_pw2 = wtb + (size_t)2 * d * d_ff * 2,
+         *wt_pw1 = wtb + ((size_t)2 * d * d_ff + (size_t)d * d) * 2, *wt_out = wtb + ((size_t)2 * d * d_ff + (size_t)3 * d * d) * 2;
+    if (phase != 2) {
+        TrList tl{};
+        tr_add(&tl, L.w_ff2b, d, d_ff, wt_ff2b); tr_add(&tl, L.w_ff2a, d_ff, d, wt_ff2a); tr_add(&tl, L.w_pw2, d, d, wt_pw2);
+        tr_add(&tl, L.w_pw1, 2 * d, d, wt_pw1); tr_add(&tl, L.w_out, d, d, wt_out);
+        IA_TRY(tr_launch(tl, (hipStream_t)stream));
+    }
     if (phase != 2) {
     // norm_out: d x4 -> dxa
     IA_TRY(ia_layernorm_bwd(S.x4, d, dout, nullptr, d, N, d, L.ln_out_g, L.ln_eps, nullptr, dxa, d, G.ln_out_g, G.ln_out_b, scr, stream));
     // feed_forward2
     IA_TRY(ia_scale_dropout_bf16(dxa, N, d, L.fc_factor, p, seed + 6, dB, stream));
-    IA_TRY(linear_bwd_deferred(dB, S.h4, L.w_ff2b, N, d, d_ff, dh, G.w_ff2b, G.b_ff2b, wt, grp, &ngrp, stream));
+    IA_TRY(linear_bwd_deferred(dB, S.h4, L.w_ff2b, N, d, d_ff, dh, G.w_ff2b, G.b_ff2b, wt_ff2b, grp, &ngrp, stream));
     IA_TRY(ia_silu_dropout_bwd(S.h4p, dh, N, d_ff, pff, seed + 5, dhp, stream));
-    IA_TRY(linear_bwd_deferred(dhp, S.y4, L.w_ff2a, N, d_ff, d, dy, G.w_ff2a, G.b_ff2a, wt, grp, &ngrp, stream));
+    IA_TRY(linear_bwd_deferred(dhp, S.y4, L.w_ff2a, N, d_ff, d, dy, G.w_ff2a, G.b_ff2a, wt_ff2a, grp, &ngrp, stream));
     IA_TRY(ia_layernorm_bwd(S.x3, d, nullptr, dy, d, N, d, L.ln_ff2_g, L.ln_eps, dxa, dxb, d, G.ln_ff2_g, G.ln_ff2_b, scr, stream));   // d x3 -> dxb
     // convolution module
     IA_TRY(ia_scale_dropout_bf16(dxb, N, d, 1.f, p, seed + 4, dB1, stream));
-    IA_TRY(linear_bwd_deferred(dB1, S.c3, L.w_pw2, N, d, d, dc3, G.w_pw2, G.b_pw2, wt, grp, &ngrp, stream));
+    IA_TRY(linear_bwd_deferred(dB1, S.c3, L.w_pw2, N, d, d, dc3, G.w_pw2, G.b_pw2, wt_pw2, grp, &ngrp, stream));
     if (phase == 0)
         IA_TRY(ia_bn_silu_bwd(S.z, dc3, N, d, S.sums, S.sums + d, L.bn_g, L.bn_b, L.bn_eps, G.bn_b, G.bn_g, dz, scr, stream));
     else
@@ -280,11 +334,11 @@ extern "C" int ia_conformer_block_bwd_a_phase(const ia_block_params* Lp, const i
     IA_TRY(ia_glu_mask(S.c2, lens, B, T, d, Gm, stream));
     IA_TRY(ia_dwconv_time_wgrad(Gm, dz, B, T, d, ksz, G.dw_w, G.dw_b, scr, stream));
     IA_TRY(ia_glu_bwd(S.c2, dG, lens, B, T, d, dc2, stream));
-    IA_TRY(linear_bwd_deferred(dc2, S.y3, L.w_pw1, N, 2 * d, d, dy, G.w_pw1, G.b_pw1, wt, grp, &ngrp, stream));
+    IA_TRY(linear_bwd_deferred(dc2, S.y3, L.w_pw1, N, 2 * d, d, dy, G.w_pw1, G.b_pw1, wt_pw1, grp, &ngrp, stream));
     IA_TRY(ia_layernorm_bwd(S.x2, d, nullptr, dy, d, N, d, L.ln_conv_g, L.ln_eps, dxb, dxa, d, G.ln_conv_g, G.ln_conv_b, scr, stream));  // d x2 -> dxa
     // linear_out
     IA_TRY(ia_scale_dropout_bf16(dxa, N, d, 1.f, p, seed + 3, dB2, stream));
-    IA_TRY(linear_bwd_deferred(dB2, S.ctxv, L.w_out, N, d, d, dctx, G.w_out, G.b_out, wt, grp, &ngrp, stream));
+    IA_TRY(linear_bwd_deferred(dB2, S.ctxv, L.w_out, N, d, d, dctx, G.w_out, G.b_out, wt_out, grp, &ngrp, stream));
     // the five weight (+ bias) gradients of this half in one GEMM launch + one finishing launch
     IA_TRY(flush_group(grp, ngrp, scr, stream));
     *dx2_out = dxa;
@@ -313,15 +367,23 @@ extern "C" int ia_conformer_block_bwd_b(const ia_block_params* Lp, const ia_bloc
     const float p = L.p_drop, pff = L.p_ff;
     ia_tn_problem grp[8];
     int ngrp = 0;
+    // transposed weight images of this call's three data-gradient GEMMs (behind the five of part 1 in the workspace)
+    char* wtb = (char*)wt + ((size_t)2 * d * d_ff + (size_t)4 * d * d) * 2;
+    void *wt_qkv = wtb, *wt_ff1b = wtb + (size_t)3 * d * d * 2, *wt_ff1a = wtb + ((size_t)3 * d * d + (size_t)d * d_ff) * 2;
+    {
+        TrList tl{};
+        tr_add(&tl, L.w_qkv, 3 * d, d, wt_qkv); tr_add(&tl, L.w_ff1b, d, d_ff, wt_ff1b); tr_add(&tl, L.w_ff1a, d_ff, d, wt_ff1a);
+        IA_TRY(tr_launch(tl, (hipStream_t)stream));
+    }
     // q|k|v projection (dW rows q, k, v contiguous; bias likewise) and the bias-free position projection
-    IA_TRY(linear_bwd_deferred(dqkv, S.y2, L.w_qkv, N, 3 * d, d, dy, G.w_qkv, G.b_qkv, wt, grp, &ngrp, stream));
+    IA_TRY(linear_bwd_deferred(dqkv, S.y2, L.w_qkv, N, 3 * d, d, dy, G.w_qkv, G.b_qkv, wt_qkv, grp, &ngrp, stream));
     grp[ngrp++] = ia_tn_problem{dpl, pos_emb, G.w_pos, nullptr, d, d, pos_rows, d, d};
     IA_TRY(ia_layernorm_bwd(S.x1, d, nullptr, dy, d, N, d, L.ln_att_g, L.ln_eps, dxa, dxb, d, G.ln_att_g, G.ln_att_b, scr, stream));   // d x1 -> dxb
     // feed_forward1
     IA_TRY(ia_scale_dropout_bf16(dxb, N, d, L.fc_factor, p, seed + 2, dB, stream));
-    IA_TRY(linear_bwd_deferred(dB, S.h1, L.w_ff1b, N, d, d_ff, dh, G.w_ff1b, G.b_ff1b, wt, grp, &ngrp, stream));
+    IA_TRY(linear_bwd_deferred(dB, S.h1, L.w_ff1b, N, d, d_ff, dh, G.w_ff1b, G.b_ff1b, wt_ff1b, grp, &ngrp, stream));
     IA_TRY(ia_silu_dropout_bwd(S.h1p, dh, N, d_ff, pff, seed + 1, dhp, stream));
-    IA_TRY(linear_bwd_deferred(dhp, S.y1, L.w_ff1a, N, d_ff, d, dy, G.w_ff1a, G.b_ff1a, wt, grp, &ngrp, stream));
+    IA_TRY(linear_bwd_deferred(dhp, S.y1, L.w_ff1a, N, d_ff, d, dy, G.w_ff1a, G.b_ff1a, wt_ff1a, grp, &ngrp, stream));
     IA_TRY(ia_layernorm_bwd(x0, d, nullptr, dy, d, N, d, L.ln_ff1_g, L.ln_eps, dxb, dx0, d, G.ln_ff1_g, G.ln_ff1_b, scr, stream));
     IA_TRY(flush_group(grp, ngrp, scr, stream));   // the four weight gradients of this half, before the multi-tensor add
     if (add_table && n_add > 0) {
