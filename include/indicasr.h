@@ -212,6 +212,12 @@ int ia_joint_dw_fused(const void* G, const void* f, const void* g, int B, int T,
 int ia_gemm_bf16(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const float* bias, int act,
                  float dropout_p, unsigned seed, float alpha, const float* R, int ldr, float* outF, int ldof,
                  void* outH, int ldoh, ia_stream_t stream);
+/* The same with two more epilogue features (trainable blocks): out_pre [M,N] bf16 = the bias-added value before act /
+ * dropout (the activation is applied to that rounded value: one launch instead of GEMM + ia_silu_dropout); act = 3 with aux
+ * [M,N] bf16: out = bf16(acc) * SiLU'(aux), then the dropout mask (GEMM + ia_silu_dropout_bwd in one launch). */
+int ia_gemm_bf16_ex(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const float* bias, int act,
+                    float dropout_p, unsigned seed, float alpha, const float* R, int ldr, float* outF, int ldof, void* outH,
+                    int ldoh, void* out_pre, int ldpre, const void* aux, int ldaux, ia_stream_t stream);
 /* ConvSubsampling 'striding' x4 (A/parts/submodules/subsampling.py:217-253,385-437), channels-last, no transposes:
  *   ia_subsample_conv1: feats [B,Fm,Tm] f32 (preprocessor layout) -> relu(conv 1->C, 3x3, s2, p1) as [B,T1,F1,C] bf16
  *                       (w1 [C,9] f32 = conv.0.weight, b1 [C]); T1 = (Tm-1)/2+1, F1 = (Fm-1)/2+1.

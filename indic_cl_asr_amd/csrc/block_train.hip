@@ -236,8 +236,8 @@ extern "C" int ia_conformer_block_fwd_phase(const ia_block_params* Lp, const flo
     if (phase != 2) {
     // 1/2 feed-forward (pre-activation kept for the backward)
     IA_TRY(ia_layernorm(x0, d, N, d, L.ln_ff1_g, L.ln_ff1_b, L.ln_eps, nullptr, 0, nullptr, nullptr, S.y1, d, stream));
-    IA_TRY(ia_gemm_bf16(S.y1, d, L.w_ff1a, d, N, d_ff, d, L.b_ff1a, 0, 0.f, 0, 1.f, nullptr, 0, nullptr, 0, S.h1p, d_ff, stream));
-    IA_TRY(ia_silu_dropout(S.h1p, N, d_ff, pff, seed + 1, S.h1, stream));
+    IA_TRY(ia_gemm_bf16_ex(S.y1, d, L.w_ff1a, d, N, d_ff, d, L.b_ff1a, 1, pff, seed + 1, 1.f, nullptr, 0, nullptr, 0, S.h1, d_ff,
+                           S.h1p, d_ff, nullptr, 0, stream));   // h1p = pre-activation, h1 = dropout(SiLU(h1p)) in one launch
     IA_TRY(ia_gemm_bf16(S.h1, d_ff, L.w_ff1b, d_ff, N, d, d_ff, L.b_ff1b, 0, p, seed + 2, L.fc_factor, x0, d, S.x1, d, nullptr, 0, stream));
     // self-attention
     IA_TRY(ia_layernorm(S.x1, d, N, d, L.ln_att_g, L.ln_att_b, L.ln_eps, nullptr, 0, nullptr, nullptr, S.y2, d, stream));
@@ -257,8 +257,8 @@ extern "C" int ia_conformer_block_fwd_phase(const ia_block_params* Lp, const flo
     IA_TRY(ia_gemm_bf16(S.c3, d, L.w_pw2, d, N, d, d, L.b_pw2, 0, p, seed + 4, 1.f, S.x2, d, S.x3, d, nullptr, 0, stream));
     // 1/2 feed-forward
     IA_TRY(ia_layernorm(S.x3, d, N, d, L.ln_ff2_g, L.ln_ff2_b, L.ln_eps, nullptr, 0, nullptr, nullptr, S.y4, d, stream));
-    IA_TRY(ia_gemm_bf16(S.y4, d, L.w_ff2a, d, N, d_ff, d, L.b_ff2a, 0, 0.f, 0, 1.f, nullptr, 0, nullptr, 0, S.h4p, d_ff, stream));
-    IA_TRY(ia_silu_dropout(S.h4p, N, d_ff, pff, seed + 5, S.h4, stream));
+    IA_TRY(ia_gemm_bf16_ex(S.y4, d, L.w_ff2a, d, N, d_ff, d, L.b_ff2a, 1, pff, seed + 5, 1.f, nullptr, 0, nullptr, 0, S.h4, d_ff,
+                           S.h4p, d_ff, nullptr, 0, stream));
     IA_TRY(ia_gemm_bf16(S.h4, d_ff, L.w_ff2b, d_ff, N, d, d_ff, L.b_ff2b, 0, p, seed + 6, L.fc_factor, S.x3, d, S.x4, d, nullptr, 0, stream));
     return ia_layernorm(S.x4, d, N, d, L.ln_out_g, L.ln_out_b, L.ln_eps, out, d, nullptr, nullptr, nullptr, 0, stream);
 }
@@ -292,7 +292,7 @@ extern "C" int ia_conformer_block_bwd_a_phase(const ia_block_params* Lp, const i
     char* ws = (char*)workspace;
     float *dxa = (float*)(ws + w.dxa), *dxb = (float*)(ws + w.dxb), *dz = (float*)(ws + w.dz), *dG = (float*)(ws + w.dG),
           *Gm = (float*)(ws + w.Gm), *scr = (float*)(ws + w.scr);
-    void *dB = ws + w.dB, *dB1 = ws + w.dB1, *dB2 = ws + w.dB2, *dh = ws + w.dh, *dhp = ws + w.dhp, *dy = ws + w.dy, *dc3 = ws + w.dc3, *dc2 = ws + w.dc2,
+    void *dB = ws + w.dB, *dB1 = ws + w.dB1, *dB2 = ws + w.dB2, *dhp = ws + w.dhp, *dy = ws + w.dy, *dc3 = ws + w.dc3, *dc2 = ws + w.dc2,
          *dctx = ws + w.dctx, *wt = ws + w.wt;
     const float p = L.p_drop, pff = L.p_ff;
     ia_tn_problem grp[8];
@@ -312,8 +312,10 @@ extern "C" int ia_conformer_block_bwd_a_phase(const ia_block_params* Lp, const i
     IA_TRY(ia_layernorm_bwd(S.x4, d, dout, nullptr, d, N, d, L.ln_out_g, L.ln_eps, nullptr, dxa, d, G.ln_out_g, G.ln_out_b, scr, stream));
     // feed_forward2
     IA_TRY(ia_scale_dropout_bf16(dxa, N, d, L.fc_factor, p, seed + 6, dB, stream));
-    IA_TRY(linear_bwd_deferred(dB, S.h4, L.w_ff2b, N, d, d_ff, dh, G.w_ff2b, G.b_ff2b, wt_ff2b, grp, &ngrp, stream));
-    IA_TRY(ia_silu_dropout_bwd(S.h4p, dh, N, d_ff, pff, seed + 5, dhp, stream));
+    // d h4p = dropout'(SiLU'(h4p)) o (dB W_ff2b) in the data-gradient GEMM's epilogue (act 3 against the saved pre-activation)
+    IA_TRY(ia_gemm_bf16_ex(dB, d, wt_ff2b, d, N, d_ff, d, nullptr, 3, pff, seed + 5, 1.f, nullptr, 0, nullptr, 0, dhp, d_ff, nullptr, 0,
+                           S.h4p, d_ff, stream));
+    IA_TRY(linear_bwd_deferred(dB, S.h4, L.w_ff2b, N, d, d_ff, nullptr, G.w_ff2b, G.b_ff2b, wt_ff2b, grp, &ngrp, stream));
     IA_TRY(linear_bwd_deferred(dhp, S.y4, L.w_ff2a, N, d_ff, d, dy, G.w_ff2a, G.b_ff2a, wt_ff2a, grp, &ngrp, stream));
     IA_TRY(ia_layernorm_bwd(S.x3, d, nullptr, dy, d, N, d, L.ln_ff2_g, L.ln_eps, dxa, dxb, d, G.ln_ff2_g, G.ln_ff2_b, scr, stream));   // d x3 -> dxb
     // convolution module
@@ -363,7 +365,7 @@ extern "C" int ia_conformer_block_bwd_b(const ia_block_params* Lp, const ia_bloc
     if (workspace_bytes < w.total) return IA_WORKSPACE_TOO_SMALL;
     char* ws = (char*)workspace;
     float *dxa = (float*)(ws + w.dxa), *dxb = (float*)(ws + w.dxb), *scr = (float*)(ws + w.scr);
-    void *dB = ws + w.dB, *dh = ws + w.dh, *dhp = ws + w.dhp, *dy = ws + w.dy, *wt = ws + w.wt;
+    void *dB = ws + w.dB, *dhp = ws + w.dhp, *dy = ws + w.dy, *wt = ws + w.wt;
     const float p = L.p_drop, pff = L.p_ff;
     ia_tn_problem grp[8];
     int ngrp = 0;
@@ -381,8 +383,9 @@ extern "C" int ia_conformer_block_bwd_b(const ia_block_params* Lp, const ia_bloc
     IA_TRY(ia_layernorm_bwd(S.x1, d, nullptr, dy, d, N, d, L.ln_att_g, L.ln_eps, dxa, dxb, d, G.ln_att_g, G.ln_att_b, scr, stream));   // d x1 -> dxb
     // feed_forward1
     IA_TRY(ia_scale_dropout_bf16(dxb, N, d, L.fc_factor, p, seed + 2, dB, stream));
-    IA_TRY(linear_bwd_deferred(dB, S.h1, L.w_ff1b, N, d, d_ff, dh, G.w_ff1b, G.b_ff1b, wt_ff1b, grp, &ngrp, stream));
-    IA_TRY(ia_silu_dropout_bwd(S.h1p, dh, N, d_ff, pff, seed + 1, dhp, stream));
+    IA_TRY(ia_gemm_bf16_ex(dB, d, wt_ff1b, d, N, d_ff, d, nullptr, 3, pff, seed + 1, 1.f, nullptr, 0, nullptr, 0, dhp, d_ff, nullptr, 0,
+                           S.h1p, d_ff, stream));
+    IA_TRY(linear_bwd_deferred(dB, S.h1, L.w_ff1b, N, d, d_ff, nullptr, G.w_ff1b, G.b_ff1b, wt_ff1b, grp, &ngrp, stream));
     IA_TRY(linear_bwd_deferred(dhp, S.y1, L.w_ff1a, N, d_ff, d, dy, G.w_ff1a, G.b_ff1a, wt_ff1a, grp, &ngrp, stream));
     IA_TRY(ia_layernorm_bwd(x0, d, nullptr, dy, d, N, d, L.ln_ff1_g, L.ln_eps, dxb, dx0, d, G.ln_ff1_g, G.ln_ff1_b, scr, stream));
     IA_TRY(flush_group(grp, ngrp, scr, stream));   // the four weight gradients of this half, before the multi-tensor add

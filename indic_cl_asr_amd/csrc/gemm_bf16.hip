@@ -27,8 +27,11 @@ constexpr int G_THREADS = 256;
 struct GemmArgs {
     const __bf16* A; const __bf16* W; const float* bias; const float* R;
     float* outF; __bf16* outH;
-    int M, N, K, lda, ldw, ldr, ldof, ldoh;
-    int act;            // 0 none, 1 SiLU, 2 ReLU
+    __bf16* outPre;     // optional: the bias-added value BEFORE act / dropout, rounded to bf16 (the activation is then applied
+                        // to the rounded value: what a separate elementwise pass over outPre would compute)
+    const __bf16* aux;  // act == 3: out = bf16(acc) * SiLU'(aux) -- the data gradient through dropout(SiLU(.)) in one pass
+    int M, N, K, lda, ldw, ldr, ldof, ldoh, ldpre, ldaux;
+    int act;            // 0 none, 1 SiLU, 2 ReLU, 3 SiLU backward against aux
     float alpha;
     unsigned seed, thr; // dropout keep if byte >= thr (thr = round(256 p)); scale 1/(1-thr/256) folded in `alpha_keep`
     float keep_scale;
@@ -184,12 +187,26 @@ __global__ __launch_bounds__(G_THREADS, (BM == 128 ? 3 : 4)) void gemm_bf16_nt_k
             const float4 b0 = *reinterpret_cast<const float4*>(a.bias + gn), b1 = *reinterpret_cast<const float4*>(a.bias + gn + 4);
             v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
         }
+        if (a.outPre) {
+            union { uint4 u; __bf16 h[8]; } o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { o.h[j] = (__bf16)v[j]; v[j] = (float)o.h[j]; }
+            *reinterpret_cast<uint4*>(a.outPre + (size_t)gm * a.ldpre + gn) = o.u;
+        }
         if (a.act == 1) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = v[j] / (1.f + __expf(-v[j]));
         } else if (a.act == 2) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+        } else if (a.act == 3) {
+            union { uint4 u; __bf16 h[8]; } x;
+            x.u = *reinterpret_cast<const uint4*>(a.aux + (size_t)gm * a.ldaux + gn);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float t = (float)x.h[j], sg = 1.f / (1.f + __expf(-t));
+                v[j] = (float)(__bf16)v[j] * (sg * (1.f + t * (1.f - sg)));
+            }
         }
         float sc_all = a.alpha;
         if (a.thr > 0) {
@@ -239,15 +256,26 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
 extern "C" int ia_gemm_bf16(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const float* bias,
                             int act, float dropout_p, unsigned seed, float alpha, const float* R, int ldr, float* outF,
                             int ldof, void* outH, int ldoh, ia_stream_t stream) {
+    return ia_gemm_bf16_ex(A, lda, W, ldw, M, N, K, bias, act, dropout_p, seed, alpha, R, ldr, outF, ldof, outH, ldoh, nullptr, 0,
+                           nullptr, 0, stream);
+}
+
+extern "C" int ia_gemm_bf16_ex(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const float* bias,
+                               int act, float dropout_p, unsigned seed, float alpha, const float* R, int ldr, float* outF,
+                               int ldof, void* outH, int ldoh, void* outPre, int ldpre, const void* aux, int ldaux,
+                               ia_stream_t stream) {
     if (!A || !W || (!outF && !outH) || M <= 0 || N <= 0 || K <= 0) return IA_INVALID_VALUE;
+    if ((act == 3) != (aux != nullptr)) return IA_INVALID_VALUE;
+    if ((outPre && (ldpre % 8 != 0 || !ia_is_aligned(outPre, 16))) || (aux && (ldaux % 8 != 0 || !ia_is_aligned(aux, 16)))) return IA_UNSUPPORTED;
     if (K % 8 != 0 || N % 8 != 0 || lda % 8 != 0 || ldw % 8 != 0) return IA_UNSUPPORTED;
     if ((R && ldr % 4 != 0) || (outF && ldof % 4 != 0) || (outH && ldoh % 8 != 0)) return IA_UNSUPPORTED;
     if (!ia_is_aligned(A, 16) || !ia_is_aligned(W, 16) || (bias && !ia_is_aligned(bias, 16)) || (R && !ia_is_aligned(R, 16)) ||
         (outF && !ia_is_aligned(outF, 16)) || (outH && !ia_is_aligned(outH, 16)))
         return IA_INVALID_VALUE;
-    if (act < 0 || act > 2 || dropout_p < 0.f || dropout_p >= 1.f) return IA_INVALID_VALUE;
+    if (act < 0 || act > 3 || dropout_p < 0.f || dropout_p >= 1.f) return IA_INVALID_VALUE;
     GemmArgs a;
     a.A = (const __bf16*)A; a.W = (const __bf16*)W; a.bias = bias; a.R = R; a.outF = outF; a.outH = (__bf16*)outH;
+    a.outPre = (__bf16*)outPre; a.aux = (const __bf16*)aux; a.ldpre = ldpre; a.ldaux = ldaux;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldr = ldr; a.ldof = ldof; a.ldoh = ldoh;
     a.act = act; a.alpha = alpha; a.seed = seed;
     a.thr = (unsigned)(dropout_p * 256.f + 0.5f);
@@ -340,6 +368,7 @@ extern "C" int ia_subsample_conv2(const void* in_cl, int B, int T1, int F1, int 
         return IA_UNSUPPORTED;
     GemmArgs a;
     a.A = (const __bf16*)in_cl; a.W = (const __bf16*)w2r; a.bias = b2; a.R = nullptr; a.outF = nullptr; a.outH = (__bf16*)out;
+    a.outPre = nullptr; a.aux = nullptr; a.ldpre = 0; a.ldaux = 0;
     a.cT1 = T1; a.cF1 = F1; a.cC = C; a.cT2 = (T1 - 1) / 2 + 1; a.cF2 = (F1 - 1) / 2 + 1;
     a.M = B * a.cT2 * a.cF2; a.N = N; a.K = 9 * C; a.lda = 0; a.ldw = 9 * C; a.ldr = 0; a.ldof = 0; a.ldoh = N;
     a.act = 2; a.alpha = 1.f; a.seed = 0; a.thr = 0; a.keep_scale = 1.f;
