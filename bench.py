@@ -174,6 +174,9 @@ def main():
     ap.add_argument("--preset", default="medium")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--freeze", type=int, default=12, help="config.yaml model.freeze_encoder_till (-1: train everything)")
+    ap.add_argument("--cl", default="ewc", choices=["ewc", "mas_importance", "lwf"],
+                    help="step recipe: EWC step (the headline, BASELINE configs[1]); MAS importance pass (configs[2], "
+                         "R/cl_baseline_mas.py:258-270); LwF teacher + student step (configs[3], R/cl_baseline_lwf.py:212-264)")
     ap.add_argument("--fp8-prefix", action="store_true", help="e4m3 projections in the frozen prefix (BASELINE configs[4]; never the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-bs", type=int, default=4)
@@ -227,12 +230,29 @@ def main():
         return a, b
     joint_mod.MFMA_PROFILE_HOOK = mfma_hook
 
+    omega = cl.get_zero_params(model) if args.cl == "mas_importance" else None
+    teacher = cl.get_params_clone(model) if args.cl == "lwf" else None
+    m_ = getattr(model, "module", model)
+
     def step():
         opt.zero_grad()
-        loss, monitor = model.training_step(batch, langs, host_lengths=host_lens)
-        monitor['ewc_penalty'] = cl.ewc_penalty_into_grads(flat, fisher, checkpoint, e_lambda=10.0)
-        loss.backward()
-        opt.step()
+        if args.cl == "ewc":
+            loss, monitor = model.training_step(batch, langs, host_lengths=host_lens)
+            monitor['ewc_penalty'] = cl.ewc_penalty_into_grads(flat, fisher, checkpoint, e_lambda=10.0)
+            loss.backward()
+            opt.step()
+        elif args.cl == "mas_importance":   # the importance pass after a task: |d (logit L2 norms) / d theta| accumulated into omega
+            m_.joint.store_sub_logits = True; m_.ctc_decoder.return_logits_ = True
+            loss, monitor = model.training_step(batch, langs, host_lengths=host_lens)
+            cl.mas_importance_loss(model, 0.3).backward()
+            cl.importance_accumulate(flat, omega)
+        else:                                # LwF: teacher pass with the previous task's weights, student step with the KD terms
+            prob_, store = cl.lwf_teacher_forward(model, flat, teacher, batch, langs, host_lengths=host_lens)
+            m_.joint.store_sub_enc, m_.joint.detach_sub_enc = True, False
+            loss, monitor, prob = model.training_step(batch, langs, return_probs=True, host_lengths=host_lens)
+            loss, _, _ = cl.lwf_kd_loss(loss, prob, prob_, m_.joint.store_list, store, 0.1, 0.3)
+            loss.backward()
+            opt.step()
         return loss
 
     for _ in range(args.warmup):
@@ -254,7 +274,7 @@ def main():
     timing["on"] = False
     # ---- the same step fed from pinned host memory (one batch ahead on a copy stream): PCIe-inclusive rate, never `value`
     h2d = None
-    if world == 1:
+    if world == 1 and args.cl == "ewc":
         host_batch = tuple(t.cpu().pin_memory() for t in batch)
         copy = torch.cuda.Stream(device=dev)
 
@@ -290,11 +310,12 @@ def main():
         ms = dt / args.steps * 1e3
         value = world * args.batch * args.steps / dt
         out = {
-            "metric": "utterances/sec (15 s @16 kHz) Conformer-M RNNT-CTC+EWC train step",
+            "metric": ("utterances/sec (15 s @16 kHz) Conformer-M RNNT-CTC+EWC train step" if args.cl == "ewc" else
+                       f"utterances/sec, {args.cl} step (not the headline metric)"),
             "value": round(value, 3), "unit": "utterances/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype + ("+fp8 frozen prefix" if args.fp8_prefix else ""), "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: Conformer-{args.preset} (d={cfg.d_model}, {cfg.n_layers}L, "
+            "config": {"workload": f"{'BASELINE configs[1]' if (args.cl == 'ewc' and args.preset == 'medium' and args.seconds == 15.0 and args.batch == 32) else 'non-headline configuration (' + args.cl + ')'}: Conformer-{args.preset} (d={cfg.d_model}, {cfg.n_layers}L, "
                                    f"H={cfg.joint_hidden}) hybrid RNNT-CTC + EWC, bs={args.batch}/GPU x {args.seconds:g} s, "
                                    f"{args.dtype} projections, freeze_encoder_till={args.freeze}, 22x257 heads, "
                                    f"fused_batch_size={cfg.fused_batch_size}",
