@@ -188,10 +188,17 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal of the multi-rank path on a one-GPU box (developer switch, never the measured configuration): every rank on
+    # device 0, gloo instead of RCCL
+    rehearsal = os.environ.get("IA_BENCH_REHEARSAL") == "1"
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)  # nccl == RCCL on ROCm
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)  # nccl == RCCL on ROCm
 
     from indic_cl_asr_amd import cl
     from indic_cl_asr_amd.config import model_config
