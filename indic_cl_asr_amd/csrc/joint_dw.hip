@@ -79,7 +79,9 @@ struct DwArgs {
     unsigned seed, thr, mU1, mV, mSpu;   // magic reciprocals of U1, LD/8 and spu
 };
 
-template <bool DROPOUT>
+// GRES: the utterance's prediction rows stay resident in LDS (U+1 <= 128: the bench shapes); otherwise (30 s utterances:
+// U+1 = 211) each step fetches the g rows of its 64 cells next to the f rows -- more L2 traffic, same arithmetic.
+template <bool DROPOUT, bool GRES>
 __global__ __launch_bounds__(DW_THREADS, 1) void joint_dw_fused_kernel(DwArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 x [G tile | hidden tile] | g rows of one utterance
     const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(DW_THREADS, 1) void joint_dw_fused_kernel(DwArgs a)
     const int xoff0 = dw_off(xrow0, xch, DW_XROW), xoff1 = dw_off(xrow0 + 32, xch, DW_XROW);
     // two register sets: the loads of step n+2 and n+3 are in flight while step n is multiplied (a step is ~1.7 us, the
     // loaded-HBM latency is of the same order: one step of distance left the staging phase waiting)
-    uint4 py[2][DW_NY], pf[2][DW_NX];
+    uint4 py[2][DW_NY], pf[2][DW_NX], pg[2][DW_NX];
     unsigned pu[2][DW_NX];                                         // label index u of the hidden rows in flight
     const unsigned nfull = (unsigned)(DW_MS * vpr);                // 16-byte chunks of a full G tile
     const h2 zero2 = {(_Float16)0, (_Float16)0};
@@ -155,6 +157,7 @@ __global__ __launch_bounds__(DW_THREADS, 1) void joint_dw_fused_kernel(DwArgs a)
             unsigned t_;                                                                                       \
             dw_divmod(ci_, (unsigned)U1, a.mU1, &t_, &pu[R][k]);                                                  \
             pf[R][k] = *reinterpret_cast<const uint4*>(fb_ + (size_t)t_ * H);                                     \
+            if (!GRES) pg[R][k] = *reinterpret_cast<const uint4*>(a.g + ((size_t)(b_) * U1 + pu[R][k]) * H + hcol); \
         }                                                                                                      \
     } while (0)
     // chunks beyond the 64 rows of a tile are stored unconditionally too (yoff = a never-read slot of the tile)
@@ -177,7 +180,8 @@ __global__ __launch_bounds__(DW_THREADS, 1) void joint_dw_fused_kernel(DwArgs a)
             const unsigned r_ = xrow0 + 32 * k;                                                                \
             union { uint4 u; h8 v; h2 p[4]; } x_, y_, z_;                                                      \
             x_.u = pf[R][k];                                                                                      \
-            y_.u = *reinterpret_cast<const uint4*>(gtile + pu[R][k] * DW_XROW + xch * 16);                        \
+            if (GRES) y_.u = *reinterpret_cast<const uint4*>(gtile + pu[R][k] * DW_XROW + xch * 16);              \
+            else y_.u = pg[R][k];                                                                              \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) z_.p[j] = __builtin_elementwise_max(x_.p[j] + y_.p[j], zero2); \
             if (DROPOUT) z_.v = dropout_apply8(z_.v, a.seed, cellb_ + r_, (unsigned)((h0 >> 3) + xch), a.thr); \
             const bool in_ = r_ < rows_;                                                                       \
@@ -188,6 +192,7 @@ __global__ __launch_bounds__(DW_THREADS, 1) void joint_dw_fused_kernel(DwArgs a)
     // the utterance's prediction rows g[b, u, h0 : h0+128] -> LDS (row-major, 256 B per row); all threads, then a barrier
 #define DW_GTILE(b_)                                                                                           \
     do {                                                                                                       \
+        if (!GRES) break;                                                                                      \
         const _Float16* gb_ = a.g + (size_t)(b_) * U1 * H + hcol;                                              \
         for (int i_ = tid; i_ < U1 * 16; i_ += DW_THREADS)   /* (i_ & 15) == xch for every i_ of this thread */ \
             *reinterpret_cast<uint4*>(gtile + i_ * 16) = *reinterpret_cast<const uint4*>(gb_ + (size_t)(i_ >> 4) * H); \
@@ -326,7 +331,7 @@ inline int64_t dw_nsteps(int B, int T, int U1) { return (int64_t)B * (((int64_t)
 }  // namespace
 
 extern "C" int ia_joint_dw_fused_supported(int U1, int H, int LD) {
-    return (U1 >= 1 && U1 <= DW_MAX_U1 && H >= 8 && H % 8 == 0 && LD % 8 == 0 && LD >= 8 && LD <= DW_VP &&
+    return (U1 >= 1 && H >= 8 && H % 8 == 0 && LD % 8 == 0 && LD >= 8 && LD <= DW_VP &&
             64 * (LD / 8) <= DW_THREADS * DW_NY) ? 1 : 0;
 }
 
@@ -359,13 +364,15 @@ extern "C" int ia_joint_dw_fused(const void* G, const void* f, const void* g, in
     a.ntiles = (H + DW_BH - 1) / DW_BH; a.nsplit = Seff;
     const dim3 grid(8 * ((Seff + 7) / 8) * a.ntiles), blk(DW_THREADS);
     const int lds = 2 * DW_STAGE + DW_MAX_U1 * DW_XROW;
-    if (a.thr > 0) {
-        IA_SET_MAX_LDS_ONCE((joint_dw_fused_kernel<true>), lds);
-        hipLaunchKernelGGL((joint_dw_fused_kernel<true>), grid, blk, lds, st, a);
-    } else {
-        IA_SET_MAX_LDS_ONCE((joint_dw_fused_kernel<false>), lds);
-        hipLaunchKernelGGL((joint_dw_fused_kernel<false>), grid, blk, lds, st, a);
-    }
+    const bool gres = U1 <= DW_MAX_U1;
+#define IA_DW_LAUNCH(D_, G_)                                                        \
+    do {                                                                            \
+        IA_SET_MAX_LDS_ONCE((joint_dw_fused_kernel<D_, G_>), lds);                  \
+        hipLaunchKernelGGL((joint_dw_fused_kernel<D_, G_>), grid, blk, lds, st, a); \
+    } while (0)
+    if (a.thr > 0) { if (gres) IA_DW_LAUNCH(true, true); else IA_DW_LAUNCH(true, false); }
+    else { if (gres) IA_DW_LAUNCH(false, true); else IA_DW_LAUNCH(false, false); }
+#undef IA_DW_LAUNCH
     IA_RETURN_IF_LAUNCH_FAILED();
     ia_partials_finish_wide(scratch, Seff, (int64_t)a.row_stride, dW, st);
     IA_RETURN_IF_LAUNCH_FAILED();

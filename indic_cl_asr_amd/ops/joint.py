@@ -260,7 +260,7 @@ class _FusedJointRNNT(torch.autograd.Function):
             stash.pending_E = None
             if not (fused_dw and USE_FUSED_DH and L.ia_joint_dh_fused_supported(U1, H, LD)):
                 raise RuntimeError("fused joint: the continual-learning terms need the fused hidden- and weight-gradient "
-                                   "kernels (U1 <= 128, H % 320 == 0); set joint.use_fused = False for this shape")
+                                   "kernels (H % 320 == 0); set joint.use_fused = False for this shape")
         have_rnnt = gcosts is not None
         dbk = None
         if not have_rnnt:

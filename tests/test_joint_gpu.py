@@ -106,11 +106,12 @@ def test_fused_hidden_gradient_kernel_matches_gemm_plus_reduce_path(B, T, U1, H,
 
 
 @pytest.mark.parametrize("B,T,U1,H,V,p", [(3, 45, 21, 320, 257, 0.25), (2, 33, 17, 64, 100, 0.0), (4, 70, 100, 640, 257, 0.2),
-                                         (2, 19, 5, 200, 130, 0.1), (1, 7, 3, 128, 272, 0.0), (2, 9, 140, 128, 64, 0.1)])
+                                         (2, 19, 5, 200, 130, 0.1), (1, 7, 3, 128, 272, 0.0), (2, 9, 140, 128, 64, 0.1),
+                                         (2, 40, 211, 640, 257, 0.2)])
 def test_fused_weight_gradient_kernel_matches_library_gemm_path(B, T, U1, H, V, p):
     """csrc/joint_dw.hip (hidden tile regenerated in LDS, transposing LDS reads, split-K) against hidden^T + the batched
     library GEMM on identical inputs: ragged lengths, dropout on and off, hidden sizes that are not tile multiples.
-    (U+1 = 140 > 128 exercises the automatic fallback: both runs then take the library path and must agree exactly.)"""
+    (U+1 = 140 / 211 > 128: the kernel variant that fetches the prediction rows per step instead of keeping them in LDS.)"""
     from indic_cl_asr_amd.ops import joint as J
     if not J.fused_joint_supported(H, V, torch.device("cuda")):
         pytest.skip("forward kernel needs H % 64 == 0")
