@@ -176,6 +176,10 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: the HIP extension is the product path and has no fallback. "
                 "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C indic_cl_asr_amd/csrc`.")
+        # torch first: its wheel bundles a libamdhip64; if this library were loaded before it, its kernels would register
+        # with the system HIP runtime while torch's streams and allocations live in the bundled one (every launch on a
+        # torch stream then fails: seen as IA_LAUNCH_FAILED when build() and smoke() ran in one process)
+        import torch  # noqa: F401
         l = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)  # AttributeError if the symbol is absent
