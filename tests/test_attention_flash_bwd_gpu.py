@@ -117,3 +117,19 @@ def test_flash_backward_agrees_with_the_row_pass_backward():
     for x, y, nm in zip(a, b, ("dqkv", "dpl", "du", "dv")):
         err = (x.float() - y.float()).abs().max().item()
         assert err <= 3e-2 * y.float().abs().max().item() + 1e-4, (nm, err)
+
+
+def test_flash_backward_with_an_empty_utterance_gives_zero_gradients_for_it():
+    from indic_cl_asr_amd.ops import fast
+    B, T, H, dk = 3, 70, 2, 64
+    qkv, pl, bu, bv, ln = _inputs(B, T, H, dk, seed=2, lens=[70, 0, 33])
+    dctx = (torch.randn(B * T, H * dk, device="cuda") * 0.5).bfloat16()
+    ctx, lse = fast.relpos_attention_flash(qkv, pl, bu, bv, ln, B, T, H, dk, want_lse=True)
+    dqkv, dpl, du, dv = fast.relpos_attention_flash_bwd(qkv, pl, bu, bv, ln, ctx, dctx, lse, B, T, H, dk)
+    assert ctx.view(B, T, -1)[1].abs().max().item() == 0.0
+    assert dqkv.view(B, T, -1)[1].abs().max().item() == 0.0
+    r_qkv, r_pl, r_u, r_v = _grads64(qkv, pl, bu, bv, ln.clamp(min=0), dctx, B, T, H, dk)
+    keep = torch.tensor([0, 2], device="cuda")
+    got = dqkv.view(B, T, -1)[keep].double(); ref = torch.nan_to_num(r_qkv.view(B, T, -1)[keep])
+    assert (got - ref).abs().max().item() <= 3e-2 * ref.abs().max().item() + 1e-4
+    assert torch.isfinite(dpl.float()).all() and torch.isfinite(du).all()

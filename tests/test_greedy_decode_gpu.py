@@ -57,3 +57,13 @@ def test_device_decode_uses_the_label_state_after_the_first_blank():
     enc = torch.randn(4, 64, 35, generator=torch.Generator().manual_seed(1)).cuda()
     lens = torch.tensor([35, 20, 35, 9]).cuda()
     assert D.greedy_rnnt_decode_device(m, enc, lens, [lang] * 4, 10) == D.greedy_rnnt_decode_host(m, enc, lens, [lang] * 4, 10)
+
+
+def test_device_decode_of_an_empty_utterance_emits_nothing():
+    from indic_cl_asr_amd import decoding as D
+    m = _model(d_model=64, n_layers=1, n_heads=1, pred_hidden=64, joint_hidden=64, vocab_per_lang=32)
+    lang = m.cfg.languages[0]
+    enc = torch.randn(3, 64, 20).cuda()
+    lens = torch.tensor([20, 0, 7]).cuda()
+    out = D.greedy_rnnt_decode_device(m, enc, lens, [lang] * 3, 5)
+    assert out[1] == [] and out == D.greedy_rnnt_decode_host(m, enc, lens, [lang] * 3, 5)
