@@ -202,7 +202,7 @@ class _FusedJointRNNT(torch.autograd.Function):
             ctx.meta = (B, T, U1, H, V, LD, int(blank), p, int(seed) & 0xFFFFFFFF, float(fastemit),
                         _kappa_for(scale_hint), f.dtype, g.dtype, W.dtype, bias.dtype, nbytes)
         # the second output is the autograd handle of the lattice: the CL terms hang their nodes on it (_LatticeTerm)
-        return costs, torch.zeros((), dtype=torch.float32, device=dev)
+        return costs, (torch.zeros((), dtype=torch.float32, device=dev) if stash is not None else None)
 
     @staticmethod
     def _rnnt_gradient(ctx, L, rl, gcosts, logits, ws, labels, act_lens, label_lens, fused_dw, kappa):
@@ -356,6 +356,6 @@ def fused_joint_rnnt(f, g, W, bias, labels, act_lens, label_lens, blank, dropout
     sub-batch box and leaves a LatticeStash in stash_req["out"]."""
     costs, token = _FusedJointRNNT.apply(f, g, W, bias, labels.contiguous(), act_lens.contiguous(), label_lens.contiguous(),
                                          blank, dropout_p, seed, fastemit_lambda, scale_hint, stash_req)
-    if stash_req is not None and not stash_req.get("detach") and token.requires_grad:
+    if stash_req is not None and not stash_req.get("detach") and token is not None and token.requires_grad:
         stash_req["out"].token = token
     return costs
