@@ -425,9 +425,7 @@ extern "C" int ia_gemm_bf16_ex(const void* A, int lda, const void* W, int ldw, i
     hipStream_t st = (hipStream_t)stream;
     // K <= 256: the operand-resident kernel (one load round trip per workgroup); IA_GEMM_RESIDENT=0 disables it (A/B runs)
     static const bool use_resident = [] { const char* e = getenv("IA_GEMM_RESIDENT"); return !(e && e[0] == '0'); }();
-    // (measured: 6-7 us against 15 us for the N = 256 projections -- out-projection, pointwise_conv2 and their data gradients,
-    //  one workgroup round; at N >= 512 the 512-thread one-per-CU workgroups lose to the k-tiled kernel's 3-4 per CU)
-    if (use_resident && K <= R_KMAX && N <= 256 && M >= 256 && !outPre && !aux) return launch_gemm_resident(a, st);
+    if (use_resident && K <= R_KMAX && M >= 256) return launch_gemm_resident(a, st);
     // tile choice: 128x128 tiles when they already give every CU work, else 64-row tiles (twice the workgroups)
     const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     if (tiles128 >= 256) return launch_gemm<128, 128>(a, st);
