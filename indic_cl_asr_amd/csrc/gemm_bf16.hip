@@ -12,8 +12,6 @@
 // residual updates of ConformerLayer.forward (:141-214).
 #include <hip/hip_bf16.h>
 
-#include <cstdlib>
-
 #include "ia_common.h"
 #include "dropout_mask.h"
 
@@ -239,145 +237,6 @@ __global__ __launch_bounds__(G_THREADS, (BM == 128 ? 3 : 4)) void gemm_bf16_nt_k
     }
 }
 
-// ---- K <= 256 (every d_model = 256 projection): the whole K extent of the tile resident, ONE load round trip ------------
-// The k-tiled kernel above pays an exposed global-load latency per 64-wide k-tile (4 per workgroup at K = 256) and another one
-// for the residual in the epilogue: 12-15 us for GEMMs whose operands fit the chip several times over.  Here every operand
-// vector of the 128 x 128 x K tile AND the residual rows the epilogue will add are requested up front (16 + 8 vectors per
-// thread in flight), then one LDS store, one barrier, 8 k-steps of MFMA, the epilogue through LDS.  512 threads (4 x 2 waves of
-// 32 x 64 outputs), 528-byte LDS rows (conflict-free 16-byte fragment reads), one workgroup per CU.
-constexpr int R_BM = 128, R_BN = 128, R_KMAX = 256, R_THREADS = 512;
-constexpr int R_ROWB = R_KMAX * 2 + 16;
-constexpr int R_LDC = R_BN + 4;
-constexpr int R_LDS = (R_BM + R_BN) * R_ROWB;   // 135 168 B (the fp32 epilogue tile, 67 584 B, reuses it)
-
-__global__ __launch_bounds__(R_THREADS, 1) void gemm_bf16_resident_kernel(GemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c = lane & 15, q = lane >> 4;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int ntn = (a.N + R_BN - 1) / R_BN;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int mt = xcd + 8 * (slot / ntn);
-    if (mt * R_BM >= a.M) return;
-    const int m0 = mt * R_BM, n0 = (slot % ntn) * R_BN;
-    constexpr int VPR = R_KMAX / 8;                       // 32 vectors per row
-    constexpr int NV = R_BM * VPR / R_THREADS;            // 8 per thread per operand
-    uint4 ra[NV], rb[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int idx = tid + i * R_THREADS, row = idx / VPR, kv = idx - row * VPR;
-        const int gm = (m0 + row < a.M) ? (m0 + row) : (a.M - 1);
-        const int gn = (n0 + row < a.N) ? (n0 + row) : (a.N - 1);
-        const int k = kv * 8;
-        const uint4 va = *reinterpret_cast<const uint4*>(a.A + (size_t)gm * a.lda + (k < a.K ? k : 0));
-        const uint4 vb = *reinterpret_cast<const uint4*>(a.W + (size_t)gn * a.ldw + (k < a.K ? k : 0));
-        ra[i] = k < a.K ? va : make_uint4(0, 0, 0, 0);
-        rb[i] = k < a.K ? vb : make_uint4(0, 0, 0, 0);
-    }
-    // the epilogue's residual vectors, requested now: item it = tid + 512 k -> (row, 8-column vector)
-    constexpr int VEC_PER_ROW = R_BN / 8, EPI_ITEMS = R_BM * VEC_PER_ROW / R_THREADS;   // 4
-    float4 rr[EPI_ITEMS][2];
-    if (a.R) {
-#pragma unroll
-        for (int k = 0; k < EPI_ITEMS; ++k) {
-            const int it = tid + k * R_THREADS, row = it / VEC_PER_ROW, cv = it - row * VEC_PER_ROW;
-            int gm = m0 + row, gn = n0 + cv * 8;
-            gm = gm < a.M ? gm : a.M - 1; gn = gn + 8 <= a.N ? gn : 0;
-            rr[k][0] = *reinterpret_cast<const float4*>(a.R + (size_t)gm * a.ldr + gn);
-            rr[k][1] = *reinterpret_cast<const float4*>(a.R + (size_t)gm * a.ldr + gn + 4);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int idx = tid + i * R_THREADS, row = idx / VPR, kv = idx - row * VPR;
-        *reinterpret_cast<uint4*>(smem + row * R_ROWB + kv * 16) = ra[i];
-        *reinterpret_cast<uint4*>(smem + R_BM * R_ROWB + row * R_ROWB + kv * 16) = rb[i];
-    }
-    __syncthreads();
-    f4 acc[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
-    const unsigned char* sa = smem + (wm * 32 + c) * R_ROWB + q * 16;
-    const unsigned char* sb = smem + R_BM * R_ROWB + (wn * 64 + c) * R_ROWB + q * 16;
-    const int nks = (a.K + 31) / 32;
-    for (int ks = 0; ks < nks; ++ks) {
-        bf8 af[2], bfr[4];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf8*>(sa + i * 16 * R_ROWB + ks * 64);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf8*>(sb + j * 16 * R_ROWB + ks * 64);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-    }
-    __syncthreads();
-    float* sc = reinterpret_cast<float*>(smem);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sc[(wm * 32 + i * 16 + q * 4 + r) * R_LDC + wn * 64 + j * 16 + c] = acc[i][j][r];
-    __syncthreads();
-#pragma unroll
-    for (int kk = 0; kk < EPI_ITEMS; ++kk) {
-        const int it = tid + kk * R_THREADS, row = it / VEC_PER_ROW, cv = it - row * VEC_PER_ROW;
-        const int gm = m0 + row, gn = n0 + cv * 8;
-        if (gm >= a.M || gn >= a.N) continue;
-        float v[8];
-        const float4 x0 = *reinterpret_cast<const float4*>(sc + row * R_LDC + cv * 8);
-        const float4 x1 = *reinterpret_cast<const float4*>(sc + row * R_LDC + cv * 8 + 4);
-        v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
-        if (a.bias) {
-            const float4 b0 = *reinterpret_cast<const float4*>(a.bias + gn), b1 = *reinterpret_cast<const float4*>(a.bias + gn + 4);
-            v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-        }
-        if (a.act == 1) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = v[j] / (1.f + __expf(-v[j]));
-        } else if (a.act == 2) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
-        }
-        float sc_all = a.alpha;
-        if (a.thr > 0) {
-            const unsigned m = ia_keep8(a.seed, (unsigned)gm, (unsigned)a.N, (unsigned)gn, a.thr);
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (!((m >> j) & 1u)) v[j] = 0.f;
-            sc_all *= a.keep_scale;
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] *= sc_all;
-        if (a.R) {
-            v[0] += rr[kk][0].x; v[1] += rr[kk][0].y; v[2] += rr[kk][0].z; v[3] += rr[kk][0].w;
-            v[4] += rr[kk][1].x; v[5] += rr[kk][1].y; v[6] += rr[kk][1].z; v[7] += rr[kk][1].w;
-        }
-        if (a.outF) {
-            *reinterpret_cast<float4*>(a.outF + (size_t)gm * a.ldof + gn) = make_float4(v[0], v[1], v[2], v[3]);
-            *reinterpret_cast<float4*>(a.outF + (size_t)gm * a.ldof + gn + 4) = make_float4(v[4], v[5], v[6], v[7]);
-        }
-        if (a.outH) {
-            union { uint4 u; __bf16 h[8]; } o;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o.h[j] = (__bf16)v[j];
-            *reinterpret_cast<uint4*>(a.outH + (size_t)gm * a.ldoh + gn) = o.u;
-        }
-    }
-}
-
-int launch_gemm_resident(const GemmArgs& a, hipStream_t st) {
-    const int ntm = (a.M + R_BM - 1) / R_BM, ntn = (a.N + R_BN - 1) / R_BN;
-    const int grid = 8 * ((ntm + 7) / 8) * ntn;
-    IA_SET_MAX_LDS_ONCE(gemm_bf16_resident_kernel, R_LDS);
-    hipLaunchKernelGGL(gemm_bf16_resident_kernel, dim3(grid), dim3(R_THREADS), R_LDS, st, a);
-    IA_RETURN_IF_LAUNCH_FAILED();
-    return IA_OK;
-}
-
 template <int BM, int BN, bool CONV = false>
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
     constexpr int STAGE = (BM + BN) * G_ROWB, EPI = 64 * (BN + 4) * 4;
@@ -423,9 +282,6 @@ extern "C" int ia_gemm_bf16_ex(const void* A, int lda, const void* W, int ldw, i
     a.keep_scale = a.thr > 0 ? 256.f / (256.f - (float)a.thr) : 1.f;
     a.cT1 = a.cF1 = a.cC = a.cT2 = a.cF2 = 0;
     hipStream_t st = (hipStream_t)stream;
-    // K <= 256: the operand-resident kernel (one load round trip per workgroup); IA_GEMM_RESIDENT=0 disables it (A/B runs)
-    static const bool use_resident = [] { const char* e = getenv("IA_GEMM_RESIDENT"); return !(e && e[0] == '0'); }();
-    if (use_resident && K <= R_KMAX && M >= 256) return launch_gemm_resident(a, st);
     // tile choice: 128x128 tiles when they already give every CU work, else 64-row tiles (twice the workgroups)
     const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     if (tiles128 >= 256) return launch_gemm<128, 128>(a, st);
