@@ -227,6 +227,16 @@ int ia_gemm_bf16_ex(const void* A, int lda, const void* W, int ldw, int M, int N
  *                       to [N,3,3,C]), out [B,T2,F2,N] bf16.  C % 64 == 0.
  *   The final Linear(C*F2 -> d) is ia_gemm_bf16 on the [B*T2, F2*N] view with the weight's columns permuted from the
  *   reference's (c,f) order to (f,c). */
+/* Block-scaled fp8 (MX: e4m3 elements, one e8m0 scale byte per 32 consecutive k) on v_mfma_scale_f32_16x16x128_f8f6f4, the
+ * instruction that issues fp8 at twice the bf16 rate (csrc/gemm_mxfp8.hip):
+ *   ia_quantize_mxfp8   q [M, ldq] e4m3, scales [M, lds] e8m0 (K / 32 bytes per row used): x ~ q * 2^(scale - 127) per block;
+ *                       x bf16 or f32 [M, K], K % 32 == 0, ldq % 16 == 0, lds % 4 == 0
+ *   ia_gemm_mxfp8       the operator of ia_gemm_bf16 on such operands; K % 128 == 0, N % 8 == 0. */
+int ia_quantize_mxfp8(const void* x, int is_f32, int ld, int64_t M, int K, void* q, int ldq, void* scales, int lds, ia_stream_t stream);
+int ia_gemm_mxfp8(const void* Aq, int lda, const void* a_scales, int ldsa, const void* Wq, int ldw, const void* w_scales, int ldsw,
+                  int M, int N, int K, const float* bias, int act, float dropout_p, unsigned seed, float alpha, const float* R, int ldr,
+                  float* outF, int ldof, void* outH, int ldoh, ia_stream_t stream);
+
 /* Device-resident greedy transducer decoding (csrc/greedy_decode.hip): the frame-synchronous loop of
  * GreedyBatchedRNNTInfer (A/parts/submodules/rnnt_greedy_decoding.py:711-909) in one launch, one persistent workgroup per
  * utterance, no host read per micro-step.  f_all [B,T,Hj] f32 = joint.enc(encoder output); out_len [B]; EW [(V+1), 4Hp] f32 =

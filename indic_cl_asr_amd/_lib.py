@@ -77,6 +77,8 @@ SIGNATURES = {
     "ia_gemm_tn_bf16_grouped": (_i, [_vp, _i, _vp, _vp]),
     "ia_greedy_decode_lds_bytes": (_i, [_i, _i, _i]),
     "ia_greedy_rnnt_decode": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
+    "ia_quantize_mxfp8": (_i, [_vp, _i, _i, _i64, _i, _vp, _i, _vp, _i, _vp]),
+    "ia_gemm_mxfp8": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _f, _c.c_uint, _f, _vp, _i, _vp, _i, _vp, _i, _vp]),
     "ia_cast_pad_bf16": (_i, [_vp, _i, _i64, _i, _vp, _i, _vp]),
     "ia_rnnt_lattice": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _sz, _vp]),
     "ia_joint_backward_g": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _f, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp,

@@ -160,6 +160,47 @@ def gemm_fp8(a, wq_ws, bias=None, act=0, dropout_p=0.0, seed=0, alpha=1.0, resid
     return out_f32, outH
 
 
+def quantize_mxfp8(x):
+    """x [M,K] bf16 or f32 (K % 32 == 0) -> (q [M,K] e4m3 bytes, scales [M, K/32 rounded to 4] e8m0 bytes): MX blocks of 32
+    consecutive k (csrc/gemm_mxfp8.hip)."""
+    M, K = x.shape
+    q = torch.empty(M, K, dtype=torch.uint8, device=x.device)
+    lds = (K // 32 + 3) // 4 * 4
+    sc = torch.empty(M, lds, dtype=torch.uint8, device=x.device)
+    st = _lib.lib().ia_quantize_mxfp8(_lib.ptr(x), int(x.dtype == torch.float32), x.stride(0), M, K, _lib.ptr(q), K, _lib.ptr(sc), lds,
+                                      _lib.stream_ptr())
+    _lib.check(st, "ia_quantize_mxfp8")
+    return q, sc
+
+
+def mxfp8_supported(K, N):
+    return K % 128 == 0 and N % 8 == 0
+
+
+def mxfp8_shadow(*params):
+    """MX-quantised image of the concatenated weights, cached per parameter version."""
+    def make():
+        w = torch.cat([p.detach().reshape(p.shape[0], -1).float() for p in params], 0).contiguous()
+        return quantize_mxfp8(w)
+    return _cached(("mxfp8",) + tuple(id(p) for p in params), params, make)
+
+
+def gemm_mxfp8(a, wq_ws, bias=None, act=0, dropout_p=0.0, seed=0, alpha=1.0, residual=None, out_f32=None, want_bf16=True):
+    """gemm() on block-scaled fp8 operands (the 2x-rate MFMA): `a` [M,K] bf16 / f32 is MX-quantised on the fly."""
+    wq, ws = wq_ws
+    M, K = a.shape
+    N = wq.shape[0]
+    aq, asc = quantize_mxfp8(a)
+    outH = torch.empty(M, N, dtype=torch.bfloat16, device=a.device) if want_bf16 else None
+    st = _lib.lib().ia_gemm_mxfp8(_lib.ptr(aq), K, _lib.ptr(asc), asc.stride(0), _lib.ptr(wq), K, _lib.ptr(ws), ws.stride(0), M, N, K,
+                                  _lib.ptr(bias), int(act), float(dropout_p), int(seed) & 0xFFFFFFFF, float(alpha),
+                                  _lib.ptr(residual), residual.stride(0) if residual is not None else 0,
+                                  _lib.ptr(out_f32), out_f32.stride(0) if out_f32 is not None else 0, _lib.ptr(outH), N,
+                                  _lib.stream_ptr())
+    _lib.check(st, "ia_gemm_mxfp8")
+    return out_f32, outH
+
+
 def layernorm(x_f32, g1, b1, eps=1e-5, out_f32=None, g2=None, b2=None, want_bf16=True):
     N, d = x_f32.shape
     outH = torch.empty(N, d, dtype=torch.bfloat16, device=x_f32.device) if want_bf16 else None

@@ -92,3 +92,52 @@ def test_frozen_prefix_in_fp8_tracks_the_fp32_oracle():
     for k, v in errs.items():
         assert v <= 5e-3, (k, v)
     assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+
+
+# ------------------------------------------------------------------------------------------------ block-scaled (MX) fp8
+def _deq_mx(q, sc, K):
+    e = sc[:, :K // 32].to(torch.int32) - 127
+    scale = torch.pow(2.0, e.double()).repeat_interleave(32, dim=1)
+    return q[:, :K].contiguous().view(torch.float8_e4m3fn).double() * scale
+
+
+@pytest.mark.parametrize("M,K,dtype", [(300, 256, torch.bfloat16), (77, 512, torch.float32), (1000, 2048, torch.bfloat16)])
+def test_mx_quantiser_block_scales_and_elements(M, K, dtype):
+    from indic_cl_asr_amd.ops import fast
+    g = torch.Generator().manual_seed(M + K)
+    x = (torch.randn(M, K, generator=g) * torch.rand(M, 1, generator=g) * 3).to(dtype).cuda()
+    x[3, 32:64] = 0                                                             # an all-zero block
+    q, sc = fast.quantize_mxfp8(x)
+    blocks = x.float().view(M, K // 32, 32)
+    amax = blocks.abs().amax(-1)
+    e = sc[:, :K // 32].to(torch.int32) - 127
+    scaled = amax / torch.pow(2.0, e.float())
+    live = amax > 0
+    assert (scaled[live] <= 448.0).all() and (scaled[live] > 224.0).all()      # the smallest power of two that fits e4m3's range
+    assert (e[~live] == 0).all()
+    deq = _deq_mx(q, sc, K)
+    rel = ((deq - x.double()).abs() / (amax.double().repeat_interleave(32, dim=1) + 1e-30)).max().item()
+    assert rel <= 2 ** -4 + 1e-6, rel                                           # half a step of a 3-bit mantissa at the block's top binade
+
+
+@pytest.mark.parametrize("M,N,K", [(1504, 768, 256), (500, 1024, 512), (333, 512, 2048), (128, 8, 128)])
+def test_mx_gemm_is_exact_on_its_quantised_operands(M, N, K):
+    from indic_cl_asr_amd.ops import fast
+    g = torch.Generator().manual_seed(N + K + 1)
+    a = (torch.randn(M, K, generator=g) * 0.7).bfloat16().cuda()
+    w = torch.nn.Parameter((torch.randn(N, K, generator=g) * 0.1).cuda())
+    bias = (torch.randn(N, generator=g) * 0.1).cuda()
+    res = torch.randn(M, N, generator=g).cuda()
+    aq, asc = fast.quantize_mxfp8(a)
+    wq, wsc = fast.mxfp8_shadow(w)
+    ref = _deq_mx(aq, asc, K) @ _deq_mx(wq, wsc, K).t() + bias.double()
+    out = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    fast.gemm_mxfp8(a, (wq, wsc), bias, out_f32=out, want_bf16=False)
+    assert (out.double() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item() + 1e-5
+    ref2 = 0.5 * torch.nn.functional.silu(ref) + res.double()
+    out2 = torch.empty_like(out)
+    _, h = fast.gemm_mxfp8(a, (wq, wsc), bias, act=1, alpha=0.5, residual=res, out_f32=out2)
+    assert (out2.double() - ref2).abs().max().item() <= 1e-4 * ref2.abs().max().item() + 1e-5
+    full = a.double() @ w.detach().double().t() + bias.double()
+    rel = ((out.double() - full).norm() / full.norm()).item()
+    assert rel <= 0.05, rel
