@@ -173,17 +173,9 @@ class ConformerLayer(nn.Module):
         fp8 = bool(getattr(self, "fp8_projections", False))
         # projections: bf16 MFMA GEMM, or e4m3 operands with per-row scales (activations quantised per call)
         # (fp8: block-scaled MX operands on the 2x-rate MFMA where K % 128 == 0 -- d_model = 256 / 512, d_ff -- else e4m3 with
-        #  per-row scales on the bf16-rate instruction)
-        def G(a_, w_, *args, **kw):
-            if not fp8:
-                return fast.gemm(a_, w_, *args, **kw)
-            return (fast.gemm_mxfp8 if w_[0].shape[1] % 128 == 0 and w_[1].dtype == torch.uint8 and w_[1].dim() == 2 else fast.gemm_fp8)(a_, w_, *args, **kw)
-
-        def Wt(*ps):
-            if not fp8:
-                return fast.bf16_shadow(*ps)
-            K_ = ps[0].reshape(ps[0].shape[0], -1).shape[1]
-            return fast.mxfp8_shadow(*ps) if K_ % 128 == 0 else fast.fp8_shadow(*ps)
+        #  per-row scales on the bf16-rate instruction: fast.fp8_weights / fast.gemm_fp8_any)
+        G = fast.gemm_fp8_any if fp8 else fast.gemm
+        Wt = fast.fp8_weights if fp8 else fast.bf16_shadow
         ffn_fused = (not fp8) and fast.ffn_fused_supported(d, ff1.linear1.weight.shape[0])
         # 1/2 FFN
         if ffn_fused:   # LayerNorm + both projections + residual in one row-resident launch (csrc/ffn_fused.hip)

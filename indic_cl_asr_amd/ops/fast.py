@@ -201,6 +201,20 @@ def gemm_mxfp8(a, wq_ws, bias=None, act=0, dropout_p=0.0, seed=0, alpha=1.0, res
     return out_f32, outH
 
 
+def fp8_weights(*params):
+    """("mx" | "row", q, scales): the fp8 image of the concatenated weights for gemm_fp8_any -- MX blocks where the kernel of
+    the block-scaled MFMA applies (K % 128 == 0), per-row scales otherwise."""
+    K = params[0].reshape(params[0].shape[0], -1).shape[1]
+    if K % 128 == 0:
+        return ("mx",) + tuple(mxfp8_shadow(*params))
+    return ("row",) + tuple(fp8_shadow(*params))
+
+
+def gemm_fp8_any(a, w3, *args, **kw):
+    kind, q, sc = w3
+    return (gemm_mxfp8 if kind == "mx" else gemm_fp8)(a, (q, sc), *args, **kw)
+
+
 def layernorm(x_f32, g1, b1, eps=1e-5, out_f32=None, g2=None, b2=None, want_bf16=True):
     N, d = x_f32.shape
     outH = torch.empty(N, d, dtype=torch.bfloat16, device=x_f32.device) if want_bf16 else None
