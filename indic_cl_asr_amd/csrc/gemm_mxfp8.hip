@@ -54,42 +54,53 @@ __global__ __launch_bounds__(MX_THREADS, 2) void gemm_mxfp8_nt_kernel(MxArgs a) 
     const int m0 = mt * MX_BM, n0 = (slot % ntn) * MX_BN;
     const int bsh = 8 * (2 * (kg & 1) + (kg >> 1));           // this lane's 32-block inside a k-tile -> byte of the scale word
 
-    uint4 ra[4], rb[4];
-    auto load = [&](int k0) {
+    // staging (named scalars / fully unrolled arrays only: pointer arrays captured by lambdas end up in scratch memory)
+    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    const int row_l = tid >> 3, kv_l = (tid & 7) * 16;     // rows row_l + 32 i, i = 0..3
+    size_t a_off[4], w_off[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + i * MX_THREADS, row = idx >> 3, kv = idx & 7;
-            const int gm = (m0 + row < a.M) ? (m0 + row) : (a.M - 1);
-            const int gn = (n0 + row < a.N) ? (n0 + row) : (a.N - 1);
-            ra[i] = *reinterpret_cast<const uint4*>(a.A + (size_t)gm * a.lda + k0 + kv * 16);
-            rb[i] = *reinterpret_cast<const uint4*>(a.W + (size_t)gn * a.ldw + k0 + kv * 16);
-        }
-    };
-    auto store = [&]() {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + i * MX_THREADS, row = idx >> 3, kv = idx & 7;
-            *reinterpret_cast<uint4*>(smem + row * MX_ROWB + kv * 16) = ra[i];
-            *reinterpret_cast<uint4*>(smem + MX_BM * MX_ROWB + row * MX_ROWB + kv * 16) = rb[i];
-        }
-    };
-    // scale words (4 e8m0 bytes = the 4 blocks of one k-tile) of this lane's 4 + 4 fragment rows
-    const unsigned char* sarow[4]; const unsigned char* swrow[4];
+    for (int i = 0; i < 4; ++i) {
+        const int row = row_l + 32 * i;
+        const int gm = (m0 + row < a.M) ? (m0 + row) : (a.M - 1);
+        const int gn = (n0 + row < a.N) ? (n0 + row) : (a.N - 1);
+        a_off[i] = (size_t)gm * a.lda + kv_l;
+        w_off[i] = (size_t)gn * a.ldw + kv_l;
+    }
+#define MX_LOAD(k0_)                                                                   \
+    do {                                                                               \
+        ra0 = *reinterpret_cast<const uint4*>(a.A + a_off[0] + (k0_));                 \
+        ra1 = *reinterpret_cast<const uint4*>(a.A + a_off[1] + (k0_));                 \
+        ra2 = *reinterpret_cast<const uint4*>(a.A + a_off[2] + (k0_));                 \
+        ra3 = *reinterpret_cast<const uint4*>(a.A + a_off[3] + (k0_));                 \
+        rb0 = *reinterpret_cast<const uint4*>(a.W + w_off[0] + (k0_));                 \
+        rb1 = *reinterpret_cast<const uint4*>(a.W + w_off[1] + (k0_));                 \
+        rb2 = *reinterpret_cast<const uint4*>(a.W + w_off[2] + (k0_));                 \
+        rb3 = *reinterpret_cast<const uint4*>(a.W + w_off[3] + (k0_));                 \
+    } while (0)
+#define MX_STORE()                                                                                     \
+    do {                                                                                               \
+        unsigned char* sa2_ = smem + row_l * MX_ROWB + kv_l;                                           \
+        unsigned char* sb2_ = sa2_ + MX_BM * MX_ROWB;                                                  \
+        *reinterpret_cast<uint4*>(sa2_) = ra0; *reinterpret_cast<uint4*>(sa2_ + 32 * MX_ROWB) = ra1;   \
+        *reinterpret_cast<uint4*>(sa2_ + 64 * MX_ROWB) = ra2; *reinterpret_cast<uint4*>(sa2_ + 96 * MX_ROWB) = ra3; \
+        *reinterpret_cast<uint4*>(sb2_) = rb0; *reinterpret_cast<uint4*>(sb2_ + 32 * MX_ROWB) = rb1;   \
+        *reinterpret_cast<uint4*>(sb2_ + 64 * MX_ROWB) = rb2; *reinterpret_cast<uint4*>(sb2_ + 96 * MX_ROWB) = rb3; \
+    } while (0)
+    // scale words (4 e8m0 bytes = the 4 blocks of one k-tile) of this lane's 4 + 4 fragment rows: byte offsets of the rows
+    unsigned sa_off[4], sw_off[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int gm = m0 + wm * 64 + i * 16 + c; gm = gm < a.M ? gm : a.M - 1;
         int gn = n0 + wn * 64 + i * 16 + c; gn = gn < a.N ? gn : a.N - 1;
-        sarow[i] = a.sa + (size_t)gm * a.ldsa;
-        swrow[i] = a.sw + (size_t)gn * a.ldsw;
+        sa_off[i] = (unsigned)gm * (unsigned)a.ldsa;
+        sw_off[i] = (unsigned)gn * (unsigned)a.ldsw;
     }
     unsigned sca[4], scw[4];
-    auto load_scales = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            sca[i] = *reinterpret_cast<const unsigned*>(sarow[i] + 4 * kt);
-            scw[i] = *reinterpret_cast<const unsigned*>(swrow[i] + 4 * kt);
-        }
-    };
+#define MX_LOAD_SCALES(kt_)                                                                            \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                    \
+        sca[i] = *reinterpret_cast<const unsigned*>(a.sa + sa_off[i] + 4 * (kt_));                     \
+        scw[i] = *reinterpret_cast<const unsigned*>(a.sw + sw_off[i] + 4 * (kt_));                     \
+    }
     f4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -97,18 +108,18 @@ __global__ __launch_bounds__(MX_THREADS, 2) void gemm_mxfp8_nt_kernel(MxArgs a) 
         for (int j = 0; j < 4; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
 
     const int nk = a.K / MX_BK;
-    load(0);
-    load_scales(0);
-    store();
+    MX_LOAD(0);
+    MX_LOAD_SCALES(0);
+    MX_STORE();
     __syncthreads();
+    const int koff = 64 * (kg >> 1) + 16 * (kg & 1);
+    const unsigned char* sa_ = smem + (wm * 64 + c) * MX_ROWB + koff;
+    const unsigned char* sb_ = smem + MX_BM * MX_ROWB + (wn * 64 + c) * MX_ROWB + koff;
     for (int kt = 0; kt < nk; ++kt) {
         unsigned cur_a[4], cur_w[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { cur_a[i] = (sca[i] >> bsh) & 0xFFu; cur_w[i] = (scw[i] >> bsh) & 0xFFu; }
-        if (kt + 1 < nk) { load((kt + 1) * MX_BK); load_scales(kt + 1); }
-        const int koff = 64 * (kg >> 1) + 16 * (kg & 1);
-        const unsigned char* sa_ = smem + (wm * 64 + c) * MX_ROWB + koff;
-        const unsigned char* sb_ = smem + MX_BM * MX_ROWB + (wn * 64 + c) * MX_ROWB + koff;
+        if (kt + 1 < nk) { MX_LOAD((kt + 1) * MX_BK); MX_LOAD_SCALES(kt + 1); }
         v8i af[4], wf[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -124,10 +135,13 @@ __global__ __launch_bounds__(MX_THREADS, 2) void gemm_mxfp8_nt_kernel(MxArgs a) 
                 acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[j], af[i], acc[i][j], 0, 0, 0, (int)cur_w[j], 0, (int)cur_a[i]);
         __syncthreads();
         if (kt + 1 < nk) {
-            store();
+            MX_STORE();
             __syncthreads();
         }
     }
+#undef MX_LOAD
+#undef MX_STORE
+#undef MX_LOAD_SCALES
     // ---- epilogue through LDS, 64 tile rows per pass (the bf16 GEMM's epilogue; no operand scales left to apply)
     float* sc = reinterpret_cast<float*>(smem);
     constexpr int VEC_PER_ROW = MX_BN / 8;
