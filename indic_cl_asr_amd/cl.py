@@ -321,6 +321,12 @@ class FusedAdamW:
         self.seg_step = torch.zeros(nseg, dtype=torch.int32, device=self.flat.theta.device)
         self.seg_active = torch.zeros(nseg, dtype=torch.int32, device=self.flat.theta.device)
         self.group = group
+        if (group is None and defer_update and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            # A communicator executes its collectives in issue order: on the default group the deferred 160 MB gradient
+            # all-reduce (launched at step(), meant to run under the NEXT forward's frozen prefix) would sit in front of
+            # that prefix's small SyncBatchNorm all-reduces and stall the first block until it has finished.  Its own
+            # communicator (every rank constructs its optimizer at the same point of the program) lets both run side by side.
+            self.group = dist.new_group()
         if bf16_shadow is None:  # the HIP GEMM paths consume bf16 weights: let the optimizer kernel emit them (one launch)
             bf16_shadow = self.flat.theta.is_cuda
         self.shadow = self.flat.theta.to(torch.bfloat16) if bf16_shadow else None
