@@ -19,6 +19,8 @@
 //   O^T += V^T P^T         [64 dv x 16 queries]             8 MFMAs   (A = V^T fragments by ds_read_b64_tr_b16 from the
 //   row-major V tile: no pre-transposed V copy, no probability round trip through LDS).
 // Key tiles at or beyond the utterance's length are skipped.
+#include <type_traits>
+
 #include "attention_flash.h"
 
 namespace {
@@ -88,44 +90,48 @@ __global__ __launch_bounds__(FA_THREADS, 2) void relpos_flash_fwd_kernel(FaArgs 
     }
 
     // ---- staging: tile t -> registers (8 x 16 B per thread), registers -> LDS stage
-    uint4 rk[2], rv[2], rp[4];
+    // TWO register sets: the loads of tile t + 2 are issued at the top of iteration t and committed at the bottom of
+    // iteration t + 1 -- two iterations to land (with one set the kernel waited about a full memory latency per tile: 40 us
+    // for 7 GFLOP, the tile's own arithmetic is ~1000 cycles)
+    uint4 rk[2][2], rv[2][2], rp[2][4];
     const __bf16* kbase = a.qkv + (size_t)b * T * (3 * d) + d + h * dk;
     const __bf16* vbase = kbase + d;
     const __bf16* pbase = a.pl + h * dk;
-#define FA_FETCH(t_)                                                                                          \
+#define FA_FETCH(S_, t_)                                                                                        \
     do {                                                                                                      \
         const int j0_ = (t_) * FA_KT;                                                                         \
         _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                    \
             const int idx_ = tid + i_ * FA_THREADS, row_ = idx_ >> 3, sl_ = idx_ & 7;                         \
             int j_ = j0_ + row_; j_ = j_ < T ? j_ : T - 1;                                                    \
-            rk[i_] = fa_load_slot<DK64>(kbase + (size_t)j_ * (3 * d), sl_, dk);                               \
-            rv[i_] = fa_load_slot<DK64>(vbase + (size_t)j_ * (3 * d), sl_, dk);                               \
+            rk[S_][i_] = fa_load_slot<DK64>(kbase + (size_t)j_ * (3 * d), sl_, dk);                               \
+            rv[S_][i_] = fa_load_slot<DK64>(vbase + (size_t)j_ * (3 * d), sl_, dk);                               \
         }                                                                                                     \
         const int R0_ = T - 1 - I0 - 63 + j0_;                                                                \
         _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                    \
             const int idx_ = tid + i_ * FA_THREADS, row_ = idx_ >> 3, sl_ = idx_ & 7;                         \
             int r_ = R0_ + row_; r_ = r_ < 0 ? 0 : (r_ > 2 * T - 2 ? 2 * T - 2 : r_);                         \
-            rp[i_] = fa_load_slot<DK64>(pbase + (size_t)r_ * d, sl_, dk);                                     \
+            rp[S_][i_] = fa_load_slot<DK64>(pbase + (size_t)r_ * d, sl_, dk);                                     \
         }                                                                                                     \
     } while (0)
-#define FA_COMMIT(buf_)                                                                                       \
+#define FA_COMMIT(S_, buf_)                                                                                       \
     do {                                                                                                      \
         unsigned char* st_ = smem + (buf_) * FA_STAGE;                                                        \
         _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                    \
             const int idx_ = tid + i_ * FA_THREADS, row_ = idx_ >> 3, sl_ = idx_ & 7;                         \
             const int off_ = row_ * FA_ROWB + ((sl_ ^ (row_ & 7)) * 16);                                      \
-            *reinterpret_cast<uint4*>(st_ + off_) = rk[i_];                                                   \
-            *reinterpret_cast<uint4*>(st_ + FA_KBUF + off_) = rv[i_];                                         \
+            *reinterpret_cast<uint4*>(st_ + off_) = rk[S_][i_];                                                   \
+            *reinterpret_cast<uint4*>(st_ + FA_KBUF + off_) = rv[S_][i_];                                         \
         }                                                                                                     \
         _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                    \
             const int idx_ = tid + i_ * FA_THREADS, row_ = idx_ >> 3, sl_ = idx_ & 7;                         \
-            *reinterpret_cast<uint4*>(st_ + 2 * FA_KBUF + row_ * FA_ROWB + ((sl_ ^ (row_ & 7)) * 16)) = rp[i_]; \
+            *reinterpret_cast<uint4*>(st_ + 2 * FA_KBUF + row_ * FA_ROWB + ((sl_ ^ (row_ & 7)) * 16)) = rp[S_][i_]; \
         }                                                                                                     \
     } while (0)
 
     const int nkt = (len + FA_KT - 1) / FA_KT;   // key tiles with at least one valid key
-    FA_FETCH(0);
-    FA_COMMIT(0);
+    FA_FETCH(0, 0);
+    if (nkt > 1) FA_FETCH(1, 1);
+    FA_COMMIT(0, 0);
     __syncthreads();
 
     f4 O[4];
@@ -133,11 +139,13 @@ __global__ __launch_bounds__(FA_THREADS, 2) void relpos_flash_fwd_kernel(FaArgs 
     for (int mt = 0; mt < 4; ++mt) O[mt] = (f4){0.f, 0.f, 0.f, 0.f};
     float m_run = IA_NEG_INF, l_run = 0.f;      // running maximum of this lane's query, this lane's share of the sum
 
-    for (int t = 0; t < nkt; ++t) {
+    // one key tile; SA = the register set that held tile t (free: refilled with tile t + 2), SB = the set holding tile t + 1
+    auto tile = [&](auto SA, auto SB, const int t) {
+        constexpr int SA_ = decltype(SA)::value, SB_ = decltype(SB)::value;
         const unsigned char* sK = smem + (t & 1) * FA_STAGE;
         const unsigned char* sV = sK + FA_KBUF;
         const unsigned char* sP = sK + 2 * FA_KBUF;
-        if (t + 1 < nkt) FA_FETCH(t + 1);
+        if (t + 2 < nkt) FA_FETCH(SA_, t + 2);
         const int j0 = t * FA_KT;
         // ---- band R^T: rows = positions 16 (3 - wave + rt) + 4 q4 + r of the staged 128, columns = queries
         f4 R[5];
@@ -225,8 +233,12 @@ __global__ __launch_bounds__(FA_THREADS, 2) void relpos_flash_fwd_kernel(FaArgs 
                 vf.s[0] = lo; vf.s[1] = hi;
                 O[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, Pf[kk], O[mt], 0, 0, 0);
             }
-        if (t + 1 < nkt) FA_COMMIT((t + 1) & 1);
+        if (t + 1 < nkt) FA_COMMIT(SB_, (t + 1) & 1);
         __syncthreads();
+    };
+    for (int t = 0; t < nkt; t += 2) {
+        tile(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, t);
+        if (t + 1 < nkt) tile(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, t + 1);
     }
 #undef FA_FETCH
 #undef FA_COMMIT
