@@ -390,6 +390,20 @@ int ia_gemm_f32(const float* A, int lda, const float* W, int ldw, int M, int N, 
                 ia_stream_t stream);
 int ia_feat_power(const float* spec, int64_t M, int lds, int half, int nbins, float* power, int ldp, ia_stream_t stream);
 int ia_feat_logmel_t(const float* mel, int B, int Tm, int F, int ldm, float guard, float* out, ia_stream_t stream);
+/* The same features in one pass over the frames (csrc/frontend_fft.hip; n_fft = 512, n_mels <= 128): nothing between the
+ * pre-emphasised signal and the log-mel tensor touches HBM.
+ *   ia_feat_preemph     y [B,L] = x' - preemph x'(n-1), x' = x + dither randn(seed, b, n)            (:408-414)
+ *   ia_feat_logmel_fft  centred reflect-padded frames of y (:415-423 torch.stft), window [win] centred in n_fft, FFT (two
+ *                       frames per complex transform; twiddle [n_fft][2] = cos, -sin of 2 pi j / n_fft), |X|^2, the
+ *                       filterbank given as chunks of 8 consecutive bins (chunk_start [128], chunk_vals [128][8] zero
+ *                       padded, every start + 7 < 272; filt_chunks [n_mels][2] = first chunk, number of chunks: a
+ *                       filter's chunks are consecutive and summed in order), log(mel + guard), out [B, n_mels, Tm]. */
+int ia_feat_preemph(const float* audio, int B, int L, float preemph, float dither, unsigned seed, float* y,
+                    ia_stream_t stream);
+int ia_feat_logmel_fft_supported(int n_fft, int win, int n_mels, int n_chunks);
+int ia_feat_logmel_fft(const float* y, int B, int L, int Tm, const float* window, int win, int n_fft, int hop,
+                       const float* twiddle, const int* chunk_start, const float* chunk_vals, const int* filt_chunks,
+                       int n_mels, int n_chunks, float guard, float* out, ia_stream_t stream);
 int ia_feat_normalize(const float* x, const int64_t* seq_len, int B, int F, int T, float eps, const int* freq_starts,
                       const int* freq_widths, int n_freq_masks, const int* time_starts, const int* time_widths,
                       int n_time_masks, float mask_value, float* y, ia_stream_t stream);

@@ -123,6 +123,9 @@ SIGNATURES = {
     "ia_gemm_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "ia_feat_power": (_i, [_vp, _i64, _i, _i, _i, _vp, _i, _vp]),
     "ia_feat_logmel_t": (_i, [_vp, _i, _i, _i, _i, _f, _vp, _vp]),
+    "ia_feat_preemph": (_i, [_vp, _i, _i, _f, _f, _c.c_uint, _vp, _vp]),
+    "ia_feat_logmel_fft_supported": (_i, [_i, _i, _i, _i]),
+    "ia_feat_logmel_fft": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp]),
     "ia_feat_normalize": (_i, [_vp, _vp, _i, _i, _i, _f, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp]),
     "ia_ctc_workspace_bytes": (_sz, [_i, _i, _i]),
     "ia_ctc_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),

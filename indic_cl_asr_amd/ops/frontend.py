@@ -1,5 +1,6 @@
 """Front-end ops: log-mel features, per-feature normalisation + length masking + SpecAugment fill."""
 import math
+import os
 
 import torch
 
@@ -30,10 +31,57 @@ def _dft_basis(window, n_fft, ldf, device):
     return out
 
 
+_FB_CHUNK = 8          # bins per filterbank chunk (csrc/frontend_fft.hip FF_CH)
+_FB_MAXCHUNKS = 128
+
+
+def _fft_tables(window, fb, n_fft, device):
+    """Tables of the one-pass front end (csrc/frontend_fft.hip): twiddles exp(-2 pi i j / n_fft) rounded from fp64, and the
+    filterbank cut into chunks of 8 consecutive bins over each filter's non-zero span.  None when the filterbank does not fit
+    128 chunks (then the GEMM front end runs)."""
+    key = ("fft", fb.data_ptr(), fb._version, n_fft, str(device))
+    hit = _BASIS.get(key)
+    if hit is not None:
+        return hit[0]
+    nb = n_fft // 2 + 1
+    f = fb.detach().float().cpu()
+    nm = f.shape[0]
+    starts, vals, filt = [], [], []
+    for m in range(nm):
+        nz = torch.nonzero(f[m, :nb]).flatten()
+        first = len(starts)
+        if nz.numel():
+            lo, hi = int(nz[0]), int(nz[-1]) + 1
+            for s in range(lo, hi, _FB_CHUNK):
+                row = torch.zeros(_FB_CHUNK)
+                e = min(s + _FB_CHUNK, hi)
+                row[:e - s] = f[m, s:e]
+                starts.append(s)
+                vals.append(row)
+        filt.append((first, len(starts) - first))
+    n_chunks = len(starts)
+    tables = None
+    if n_chunks <= _FB_MAXCHUNKS and nm <= 128 and f.shape[1] >= nb:
+        cs = torch.zeros(_FB_MAXCHUNKS, dtype=torch.int32)
+        cv = torch.zeros(_FB_MAXCHUNKS, _FB_CHUNK)
+        if n_chunks:
+            cs[:n_chunks] = torch.tensor(starts, dtype=torch.int32)
+            cv[:n_chunks] = torch.stack(vals)
+        j = torch.arange(n_fft, dtype=torch.float64)
+        ang = 2.0 * math.pi * j / n_fft
+        tw = torch.stack([torch.cos(ang), -torch.sin(ang)], dim=1).float()
+        tables = (tw.to(device).contiguous(), cs.to(device), cv.to(device).contiguous(),
+                  torch.tensor(filt, dtype=torch.int32).to(device).contiguous(), n_chunks)
+    _BASIS[key] = (tables, fb)     # fb kept alive: the key is its data pointer
+    return tables
+
+
 def log_mel(signal, window, fb, n_fft=512, hop=160, preemph=0.97, dither=0.0, seed=0, log_guard=2 ** -24):
-    """[B,L] f32 audio -> [B,n_mels,Tm] f32 log-mel power (features.py:408-444) on the HIP front end
-    (csrc/frontend.hip + csrc/gemm_f32.hip): framing kernel, exact-fp32 MFMA DFT, power, exact-fp32 MFMA mel
-    projection, log + transpose."""
+    """[B,L] f32 audio -> [B,n_mels,Tm] f32 log-mel power (features.py:408-444) on the HIP front end.  n_fft = 512 (every
+    recipe of the reference): csrc/frontend_fft.hip -- pre-emphasis pass, then ONE kernel from frames to log-mel (window,
+    FFT, power, sparse mel projection, log; nothing in HBM in between).  Other sizes (or IA_FRONTEND=gemm):
+    csrc/frontend.hip + csrc/gemm_f32.hip -- framing kernel, exact-fp32 MFMA DFT, power, exact-fp32 MFMA mel projection,
+    log + transpose."""
     from .. import _lib
     L_ = _lib.lib()
     if not signal.is_cuda:
@@ -42,6 +90,20 @@ def log_mel(signal, window, fb, n_fft=512, hop=160, preemph=0.97, dither=0.0, se
     B, L = x.shape
     win = window.numel()
     Tm = (L + (n_fft // 2) * 2 - n_fft) // hop + 1
+    nm = fb.shape[0]
+    if (os.environ.get("IA_FRONTEND", "fft") != "gemm" and L_.ia_feat_logmel_fft_supported(n_fft, win, nm, 0)):
+        tables = _fft_tables(window, fb, n_fft, x.device)
+        if tables is not None:
+            tw, cs, cv, filt, n_chunks = tables
+            y = torch.empty_like(x)
+            _lib.check(L_.ia_feat_preemph(_lib.ptr(x), B, L, float(preemph), float(dither), int(seed) & 0xFFFFFFFF,
+                                          _lib.ptr(y), _lib.stream_ptr()), "ia_feat_preemph")
+            w = window.detach().to(device=x.device, dtype=torch.float32).contiguous()
+            out = torch.empty(B, nm, Tm, dtype=torch.float32, device=x.device)
+            _lib.check(L_.ia_feat_logmel_fft(_lib.ptr(y), B, L, Tm, _lib.ptr(w), win, n_fft, hop, _lib.ptr(tw), _lib.ptr(cs),
+                                             _lib.ptr(cv), _lib.ptr(filt), nm, n_chunks, float(log_guard), _lib.ptr(out),
+                                             _lib.stream_ptr()), "ia_feat_logmel_fft")
+            return out
     ldf = (win + 15) // 16 * 16
     basis, half, nb = _dft_basis(window, n_fft, ldf, x.device)
     M = B * Tm
