@@ -33,7 +33,7 @@ constexpr int FA_PBUF = 128 * FA_ROWB;     // 16 KB of position rows
 constexpr int FA_STAGE = 2 * FA_KBUF + FA_PBUF;   // K | V | P = 32 KB per stage
 constexpr int FA_SR_LD = 104;              // bf16 elements per band-strip row (208 B: conflict-free 8-byte reads)
 constexpr int FA_SR_BYTES = 16 * FA_SR_LD * 2;
-constexpr int FA_LDS = 2 * FA_STAGE + 4 * FA_SR_BYTES;   // 78 848 B
+constexpr int FA_LDS = FA_STAGE + 4 * FA_SR_BYTES;       // 46 080 B: three workgroups per CU
 
 struct FaArgs {
     const __bf16* qkv; const __bf16* pl; const float* bias_u; const float* bias_v; const int64_t* lens;
@@ -42,7 +42,7 @@ struct FaArgs {
 };
 
 template <bool DK64>
-__global__ __launch_bounds__(FA_THREADS, 2) void relpos_flash_fwd_kernel(FaArgs a) {
+__global__ __launch_bounds__(FA_THREADS, 3) void relpos_flash_fwd_kernel(FaArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, q4 = lane >> 4;
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(FA_THREADS, 2) void relpos_flash_fwd_kernel(FaArgs 
         }
         return;
     }
-    unsigned char* sR = smem + 2 * FA_STAGE + wave * FA_SR_BYTES;
+    unsigned char* sR = smem + FA_STAGE + wave * FA_SR_BYTES;
 
     // ---- B fragments (q+u)^T and (q+v)^T: lane (query c, q4) holds dk elements 32 ks + 8 q4 .. +7 of its query
     bf8 Qu[2], Qv[2];
@@ -89,49 +89,47 @@ __global__ __launch_bounds__(FA_THREADS, 2) void relpos_flash_fwd_kernel(FaArgs 
         }
     }
 
-    // ---- staging: tile t -> registers (8 x 16 B per thread), registers -> LDS stage
-    // TWO register sets: the loads of tile t + 2 are issued at the top of iteration t and committed at the bottom of
-    // iteration t + 1 -- two iterations to land (with one set the kernel waited about a full memory latency per tile: 40 us
-    // for 7 GFLOP, the tile's own arithmetic is ~1000 cycles)
-    uint4 rk[2][2], rv[2][2], rp[2][4];
+    // ---- staging: tile t + 1 -> registers (8 x 16 B per thread) while tile t is computed from the ONE LDS stage, then
+    // barrier, registers -> LDS, barrier.  One stage (45 KB with the strips) keeps three workgroups on a CU: the 768
+    // workgroups of a 32 x 376-frame batch are all resident (two stages = 512 slots = a second, half-empty round: 41 us;
+    // measured per-workgroup cost 5 us + 3.3 us per key tile), and three waves per SIMD hide each other's LDS round trips.
+    uint4 rk[2], rv[2], rp[4];
     const __bf16* kbase = a.qkv + (size_t)b * T * (3 * d) + d + h * dk;
     const __bf16* vbase = kbase + d;
     const __bf16* pbase = a.pl + h * dk;
-#define FA_FETCH(S_, t_)                                                                                        \
+#define FA_FETCH(t_)                                                                                          \
     do {                                                                                                      \
         const int j0_ = (t_) * FA_KT;                                                                         \
         _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                    \
             const int idx_ = tid + i_ * FA_THREADS, row_ = idx_ >> 3, sl_ = idx_ & 7;                         \
             int j_ = j0_ + row_; j_ = j_ < T ? j_ : T - 1;                                                    \
-            rk[S_][i_] = fa_load_slot<DK64>(kbase + (size_t)j_ * (3 * d), sl_, dk);                               \
-            rv[S_][i_] = fa_load_slot<DK64>(vbase + (size_t)j_ * (3 * d), sl_, dk);                               \
+            rk[i_] = fa_load_slot<DK64>(kbase + (size_t)j_ * (3 * d), sl_, dk);                               \
+            rv[i_] = fa_load_slot<DK64>(vbase + (size_t)j_ * (3 * d), sl_, dk);                               \
         }                                                                                                     \
         const int R0_ = T - 1 - I0 - 63 + j0_;                                                                \
         _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                    \
             const int idx_ = tid + i_ * FA_THREADS, row_ = idx_ >> 3, sl_ = idx_ & 7;                         \
             int r_ = R0_ + row_; r_ = r_ < 0 ? 0 : (r_ > 2 * T - 2 ? 2 * T - 2 : r_);                         \
-            rp[S_][i_] = fa_load_slot<DK64>(pbase + (size_t)r_ * d, sl_, dk);                                     \
+            rp[i_] = fa_load_slot<DK64>(pbase + (size_t)r_ * d, sl_, dk);                                     \
         }                                                                                                     \
     } while (0)
-#define FA_COMMIT(S_, buf_)                                                                                       \
+#define FA_COMMIT()                                                                                           \
     do {                                                                                                      \
-        unsigned char* st_ = smem + (buf_) * FA_STAGE;                                                        \
         _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                    \
             const int idx_ = tid + i_ * FA_THREADS, row_ = idx_ >> 3, sl_ = idx_ & 7;                         \
             const int off_ = row_ * FA_ROWB + ((sl_ ^ (row_ & 7)) * 16);                                      \
-            *reinterpret_cast<uint4*>(st_ + off_) = rk[S_][i_];                                                   \
-            *reinterpret_cast<uint4*>(st_ + FA_KBUF + off_) = rv[S_][i_];                                         \
+            *reinterpret_cast<uint4*>(smem + off_) = rk[i_];                                                  \
+            *reinterpret_cast<uint4*>(smem + FA_KBUF + off_) = rv[i_];                                        \
         }                                                                                                     \
         _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                    \
             const int idx_ = tid + i_ * FA_THREADS, row_ = idx_ >> 3, sl_ = idx_ & 7;                         \
-            *reinterpret_cast<uint4*>(st_ + 2 * FA_KBUF + row_ * FA_ROWB + ((sl_ ^ (row_ & 7)) * 16)) = rp[S_][i_]; \
+            *reinterpret_cast<uint4*>(smem + 2 * FA_KBUF + row_ * FA_ROWB + ((sl_ ^ (row_ & 7)) * 16)) = rp[i_]; \
         }                                                                                                     \
     } while (0)
 
     const int nkt = (len + FA_KT - 1) / FA_KT;   // key tiles with at least one valid key
-    FA_FETCH(0, 0);
-    if (nkt > 1) FA_FETCH(1, 1);
-    FA_COMMIT(0, 0);
+    FA_FETCH(0);
+    FA_COMMIT();
     __syncthreads();
 
     f4 O[4];
@@ -139,13 +137,11 @@ __global__ __launch_bounds__(FA_THREADS, 2) void relpos_flash_fwd_kernel(FaArgs 
     for (int mt = 0; mt < 4; ++mt) O[mt] = (f4){0.f, 0.f, 0.f, 0.f};
     float m_run = IA_NEG_INF, l_run = 0.f;      // running maximum of this lane's query, this lane's share of the sum
 
-    // one key tile; SA = the register set that held tile t (free: refilled with tile t + 2), SB = the set holding tile t + 1
-    auto tile = [&](auto SA, auto SB, const int t) {
-        constexpr int SA_ = decltype(SA)::value, SB_ = decltype(SB)::value;
-        const unsigned char* sK = smem + (t & 1) * FA_STAGE;
+    for (int t = 0; t < nkt; ++t) {
+        const unsigned char* sK = smem;
         const unsigned char* sV = sK + FA_KBUF;
         const unsigned char* sP = sK + 2 * FA_KBUF;
-        if (t + 2 < nkt) FA_FETCH(SA_, t + 2);
+        if (t + 1 < nkt) FA_FETCH(t + 1);
         const int j0 = t * FA_KT;
         // ---- band R^T: rows = positions 16 (3 - wave + rt) + 4 q4 + r of the staged 128, columns = queries
         f4 R[5];
@@ -233,12 +229,11 @@ __global__ __launch_bounds__(FA_THREADS, 2) void relpos_flash_fwd_kernel(FaArgs 
                 vf.s[0] = lo; vf.s[1] = hi;
                 O[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, Pf[kk], O[mt], 0, 0, 0);
             }
-        if (t + 1 < nkt) FA_COMMIT(SB_, (t + 1) & 1);
-        __syncthreads();
-    };
-    for (int t = 0; t < nkt; t += 2) {
-        tile(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, t);
-        if (t + 1 < nkt) tile(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, t + 1);
+        __syncthreads();                      // every wave is done with the stage
+        if (t + 1 < nkt) {
+            FA_COMMIT();
+            __syncthreads();
+        }
     }
 #undef FA_FETCH
 #undef FA_COMMIT
