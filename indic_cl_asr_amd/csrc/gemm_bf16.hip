@@ -12,6 +12,8 @@
 // residual updates of ConformerLayer.forward (:141-214).
 #include <hip/hip_bf16.h>
 
+#include <stdlib.h>
+
 #include "ia_common.h"
 #include "dropout_mask.h"
 
@@ -60,11 +62,12 @@ __device__ __forceinline__ uint4 conv_a_load(const GemmArgs& a, const ConvRow& r
 
 template <int BM, int BN, bool CONV = false>
 __global__ __launch_bounds__(G_THREADS, (BM == 128 ? 3 : 4)) void gemm_bf16_nt_kernel(GemmArgs a) {
+    static_assert(BM == 64 || BM == 96 || BM == 128, "row tiles of 64, 96 or 128");
     constexpr int WM = BM / 2, WN = BN / 2, TI = WM / 16, TJ = WN / 16;
     constexpr int A_BYTES = BM * G_ROWB;
     constexpr int AV = BM * 8 / G_THREADS, BV = BN * 8 / G_THREADS;  // 16-byte vectors per thread per stage
     constexpr int LDC = BN + 4;                                        // fp32 epilogue row stride (floats)
-    constexpr int EP_ROWS = 64;                                        // tile rows per epilogue pass through LDS
+    constexpr int EP_ROWS = (BM == 96) ? 48 : 64;                      // tile rows per epilogue pass through LDS
     static_assert(BM % EP_ROWS == 0 && (EP_ROWS % WM == 0 || WM % EP_ROWS == 0), "epilogue passes cover whole wave rows");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -79,7 +82,7 @@ __global__ __launch_bounds__(G_THREADS, (BM == 128 ? 3 : 4)) void gemm_bf16_nt_k
     if (mt * BM >= a.M) return;  // padding workgroups of the last group of 8 row tiles (uniform)
     const int m0 = mt * BM, n0 = (slot % ntn) * BN;
 
-    static_assert(BV == 4 && (AV == 2 || AV == 4), "staging registers are named (arrays end up in scratch)");
+    static_assert(BV == 4 && (AV == 2 || AV == 3 || AV == 4), "staging registers are named (arrays end up in scratch)");
     ConvRow crow[4];
     if constexpr (CONV) {
 #pragma unroll
@@ -98,8 +101,10 @@ __global__ __launch_bounds__(G_THREADS, (BM == 128 ? 3 : 4)) void gemm_bf16_nt_k
     do { \
         { const int idx_ = tid + 0 * G_THREADS, kv_ = idx_ & 7; if constexpr (CONV) { ra0 = conv_a_load(a, crow[0], (k0_), kv_); } else { const int row_ = idx_ >> 3; const int gr_ = (m0 + row_ < a.M) ? (m0 + row_) : (a.M - 1); ra0 = G_LDK(a.A + (size_t)gr_ * a.lda, (k0_) + kv_ * 8); } } \
         { const int idx_ = tid + 1 * G_THREADS, kv_ = idx_ & 7; if constexpr (CONV) { ra1 = conv_a_load(a, crow[1], (k0_), kv_); } else { const int row_ = idx_ >> 3; const int gr_ = (m0 + row_ < a.M) ? (m0 + row_) : (a.M - 1); ra1 = G_LDK(a.A + (size_t)gr_ * a.lda, (k0_) + kv_ * 8); } } \
-        if constexpr (AV == 4) { \
+        if constexpr (AV >= 3) { \
         { const int idx_ = tid + 2 * G_THREADS, kv_ = idx_ & 7; if constexpr (CONV) { ra2 = conv_a_load(a, crow[2], (k0_), kv_); } else { const int row_ = idx_ >> 3; const int gr_ = (m0 + row_ < a.M) ? (m0 + row_) : (a.M - 1); ra2 = G_LDK(a.A + (size_t)gr_ * a.lda, (k0_) + kv_ * 8); } } \
+        } \
+        if constexpr (AV == 4) { \
         { const int idx_ = tid + 3 * G_THREADS, kv_ = idx_ & 7; if constexpr (CONV) { ra3 = conv_a_load(a, crow[3], (k0_), kv_); } else { const int row_ = idx_ >> 3; const int gr_ = (m0 + row_ < a.M) ? (m0 + row_) : (a.M - 1); ra3 = G_LDK(a.A + (size_t)gr_ * a.lda, (k0_) + kv_ * 8); } } \
         } \
         { const int idx_ = tid + 0 * G_THREADS, row_ = idx_ >> 3, kv_ = idx_ & 7; const int gr_ = (n0 + row_ < a.N) ? (n0 + row_) : (a.N - 1); rb0 = G_LDK(a.W + (size_t)gr_ * a.ldw, (k0_) + kv_ * 8); } \
@@ -113,8 +118,10 @@ __global__ __launch_bounds__(G_THREADS, (BM == 128 ? 3 : 4)) void gemm_bf16_nt_k
         unsigned char* sb_ = sa_ + A_BYTES; \
         { const int idx_ = tid + 0 * G_THREADS; *reinterpret_cast<uint4*>(sa_ + (idx_ >> 3) * G_ROWB + (idx_ & 7) * 16) = ra0; } \
         { const int idx_ = tid + 1 * G_THREADS; *reinterpret_cast<uint4*>(sa_ + (idx_ >> 3) * G_ROWB + (idx_ & 7) * 16) = ra1; } \
-        if constexpr (AV == 4) { \
+        if constexpr (AV >= 3) { \
         { const int idx_ = tid + 2 * G_THREADS; *reinterpret_cast<uint4*>(sa_ + (idx_ >> 3) * G_ROWB + (idx_ & 7) * 16) = ra2; } \
+        } \
+        if constexpr (AV == 4) { \
         { const int idx_ = tid + 3 * G_THREADS; *reinterpret_cast<uint4*>(sa_ + (idx_ >> 3) * G_ROWB + (idx_ & 7) * 16) = ra3; } \
         } \
         { const int idx_ = tid + 0 * G_THREADS; *reinterpret_cast<uint4*>(sb_ + (idx_ >> 3) * G_ROWB + (idx_ & 7) * 16) = rb0; } \
@@ -239,7 +246,7 @@ __global__ __launch_bounds__(G_THREADS, (BM == 128 ? 3 : 4)) void gemm_bf16_nt_k
 
 template <int BM, int BN, bool CONV = false>
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
-    constexpr int STAGE = (BM + BN) * G_ROWB, EPI = 64 * (BN + 4) * 4;
+    constexpr int STAGE = (BM + BN) * G_ROWB, EPI = (BM == 96 ? 48 : 64) * (BN + 4) * 4;
     const size_t lds = STAGE > EPI ? STAGE : EPI;
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
     const int grid = 8 * ((ntm + 7) / 8) * ntn;  // row tiles padded to a multiple of the 8 XCDs (see the kernel's tile order)
@@ -282,9 +289,24 @@ extern "C" int ia_gemm_bf16_ex(const void* A, int lda, const void* W, int ldw, i
     a.keep_scale = a.thr > 0 ? 256.f / (256.f - (float)a.thr) : 1.f;
     a.cT1 = a.cF1 = a.cC = a.cT2 = a.cF2 = 0;
     hipStream_t st = (hipStream_t)stream;
-    // tile choice: 128x128 tiles when they already give every CU work, else 64-row tiles (twice the workgroups)
-    const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-    if (tiles128 >= 256) return launch_gemm<128, 128>(a, st);
+    // Row-tile choice (128, 96 or 64 rows x 128 columns).  The result does not depend on it: every output element sums its
+    // k-steps in the same order.  In isolation the tile sizes are within ~10 % of each other at the encoder's shapes
+    // (tools/bench_gemm_tiles.py: K <= 1024 launches are 10-20 us, mostly fixed latency), but INSIDE the training step the
+    // persistent prediction-network workgroups hold ~40 CUs while the encoder runs: many small workgroups then balance over the
+    // CUs that are left, fat ones queue behind the slow CUs (step at 32 x 15 s: 64 rows 10.47 ms, 96 rows 10.52, 128 rows
+    // 10.68, A/B on one box).  Large problems (long K or thousands of tiles) keep the 128-row tiles' operand reuse.
+    const char* forced_env = getenv("IA_GEMM_BM");   // diagnostics (tools/bench_gemm_tiles.py)
+    const int forced = forced_env ? atoi(forced_env) : 0;
+    const long ntn = (N + 127) / 128;
+    const long tiles128 = (long)((M + 127) / 128) * ntn, tiles96 = (long)((M + 95) / 96) * ntn, tiles64 = (long)((M + 63) / 64) * ntn;
+    int best = 64;
+    if (!(K <= 1024 && tiles64 <= 2048)) {
+        if (tiles128 >= 256) best = 128;
+        else if (tiles96 >= 240) best = 96;
+    }
+    if (forced == 128 || forced == 96 || forced == 64) best = forced;
+    if (best == 128) return launch_gemm<128, 128>(a, st);
+    if (best == 96) return launch_gemm<96, 128>(a, st);
     return launch_gemm<64, 128>(a, st);
 }
 
