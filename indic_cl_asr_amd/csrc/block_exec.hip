@@ -85,7 +85,8 @@ extern "C" int ia_conformer_prefix_fwd_seg(const ia_block_params* layers, int n_
     const int N = B * T;
     // feed-forward modules: one row-resident launch each (csrc/ffn_fused.hip: LayerNorm, both projections, SiLU, dropouts,
     // residual and -- for the second module -- norm_out) where the shape allows, else LayerNorm + two GEMM launches
-    const bool ffn_fused = ia_ffn_fused_supported(d, d_ff) != 0;
+    const char* ffn_env = getenv("IA_PREFIX_FFN");   // "gemm": LayerNorm + two GEMM launches (A/B switch)
+    const bool ffn_fused = ia_ffn_fused_supported(d, d_ff) != 0 && !(ffn_env && ffn_env[0] == 'g');
     // attention: key-tile loop kernel (any T, head dim <= 64); IA_PREFIX_ATTN=old selects the all-keys-in-registers kernel
     const char* attn_env = getenv("IA_PREFIX_ATTN");
     const bool use_flash = ia_relpos_attention_flash_supported(T, dk) != 0 && !(attn_env && attn_env[0] == 'o');
