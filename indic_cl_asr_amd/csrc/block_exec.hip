@@ -87,6 +87,8 @@ extern "C" int ia_conformer_prefix_fwd_seg(const ia_block_params* layers, int n_
     // residual and -- for the second module -- norm_out) where the shape allows, else LayerNorm + two GEMM launches
     const char* ffn_env = getenv("IA_PREFIX_FFN");   // "gemm": LayerNorm + two GEMM launches (A/B switch)
     const bool ffn_fused = ia_ffn_fused_supported(d, d_ff) != 0 && !(ffn_env && ffn_env[0] == 'g');
+    const char* bns_env = getenv("IA_PREFIX_BNSILU");   // "split": separate BatchNorm + SiLU launch (A/B switch)
+    const bool bnsilu_fused = ia_gemm_bnsilu_supported(d) != 0 && !(bns_env && bns_env[0] == 's');
     // attention: key-tile loop kernel (any T, head dim <= 64); IA_PREFIX_ATTN=old selects the all-keys-in-registers kernel
     const char* attn_env = getenv("IA_PREFIX_ATTN");
     const bool use_flash = ia_relpos_attention_flash_supported(T, dk) != 0 && !(attn_env && attn_env[0] == 'o');
@@ -129,9 +131,16 @@ extern "C" int ia_conformer_prefix_fwd_seg(const ia_block_params* layers, int n_
         IA_TRY(ia_glu_dwconv(c2, lens, B, T, d, ksz, L.dw_w, L.dw_b, z, sums, sums + d, scr, stream));
         }
         if (!second_half) break;
-        IA_TRY(ia_bn_silu(z, N, d, sums, sums + d, L.bn_g, L.bn_b, bn_synced ? nullptr : L.bn_rm, bn_synced ? nullptr : L.bn_rv,
-                          bn_synced ? nullptr : L.bn_nbt, L.bn_momentum, L.bn_eps, training ? 1 : 0, c3, stream));
-        IA_TRY(ia_gemm_bf16(c3, d, L.w_pw2, d, N, d, d, L.b_pw2, 0, p, seed + 4, 1.f, x, d, x, d, nullptr, 0, stream));
+        if (bnsilu_fused) {   // BatchNorm + SiLU while the A tile of the pointwise convolution is staged: one launch, no c3 tensor
+            IA_TRY(ia_gemm_bnsilu_bf16(z, d, N, sums, sums + d, L.bn_g, L.bn_b, bn_synced ? nullptr : L.bn_rm,
+                                       bn_synced ? nullptr : L.bn_rv, bn_synced ? nullptr : L.bn_nbt, L.bn_momentum, L.bn_eps,
+                                       training ? 1 : 0, L.w_pw2, d, (int)N, d, d, L.b_pw2, p, seed + 4, 1.f, x, d, x, d, nullptr, 0,
+                                       stream));
+        } else {
+            IA_TRY(ia_bn_silu(z, N, d, sums, sums + d, L.bn_g, L.bn_b, bn_synced ? nullptr : L.bn_rm, bn_synced ? nullptr : L.bn_rv,
+                              bn_synced ? nullptr : L.bn_nbt, L.bn_momentum, L.bn_eps, training ? 1 : 0, c3, stream));
+            IA_TRY(ia_gemm_bf16(c3, d, L.w_pw2, d, N, d, d, L.b_pw2, 0, p, seed + 4, 1.f, x, d, x, d, nullptr, 0, stream));
+        }
         // 1/2 feed-forward
         if (ffn_fused) {   // ... + norm_out in the same launch (the next block's module applies its own first LayerNorm)
             IA_TRY(ia_ffn_fused(x, N, d, d_ff, L.ln_ff2_g, L.ln_ff2_b, L.ln_eps, L.w_ff2a, L.b_ff2a, L.w_ff2b, L.b_ff2b, L.fc_factor,
