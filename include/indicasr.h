@@ -580,6 +580,12 @@ int ia_conformer_block_bwd_b(const struct ia_block_params* layer, const ia_block
 int ia_layernorm_bwd(const float* x, int ldx, const float* dy_f32, const void* dy_bf16, int ldy, int N, int d,
                      const float* gamma, float eps, const float* dx_in, float* dx_out, int lddx, float* dgamma,
                      float* dbeta, float* scratch, ia_stream_t stream);
+/* ... and, in the same pass, dx_bf16 = bf16(alpha * keep*scale * dx_out): the ia_scale_dropout_bf16 of the result (the operand of
+ * the data- and weight-gradient GEMMs of the residual branch in front of this LayerNorm); d % 8 == 0. */
+int ia_layernorm_bwd_drop(const float* x, int ldx, const float* dy_f32, const void* dy_bf16, int ldy, int N, int d,
+                          const float* gamma, float eps, const float* dx_in, float* dx_out, int lddx, float* dgamma,
+                          float* dbeta, float alpha, float dropout_p, unsigned seed, void* dx_bf16, int lddxh, float* scratch,
+                          ia_stream_t stream);
 int64_t ia_layernorm_bwd_scratch_elems(int N, int d);
 int ia_silu_dropout(const void* h_pre, int64_t M, int N, float dropout_p, unsigned seed, void* out, ia_stream_t stream);
 int ia_silu_dropout_bwd(const void* h_pre, const void* dh, int64_t M, int N, float dropout_p, unsigned seed, void* out,

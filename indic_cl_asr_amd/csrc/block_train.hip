@@ -309,17 +309,19 @@ extern "C" int ia_conformer_block_bwd_a_phase(const ia_block_params* Lp, const i
     }
     if (phase != 2) {
     // norm_out: d x4 -> dxa
-    IA_TRY(ia_layernorm_bwd(S.x4, d, dout, nullptr, d, N, d, L.ln_out_g, L.ln_eps, nullptr, dxa, d, G.ln_out_g, G.ln_out_b, scr, stream));
+    // (each LayerNorm backward below also emits the dropout-scaled bf16 copy of its result: the gradient entering the residual
+    //  branch in front of it, operand of that branch's data- and weight-gradient GEMMs -- no separate elementwise launch)
+    IA_TRY(ia_layernorm_bwd_drop(S.x4, d, dout, nullptr, d, N, d, L.ln_out_g, L.ln_eps, nullptr, dxa, d, G.ln_out_g, G.ln_out_b,
+                                 L.fc_factor, p, seed + 6, dB, d, scr, stream));
     // feed_forward2
-    IA_TRY(ia_scale_dropout_bf16(dxa, N, d, L.fc_factor, p, seed + 6, dB, stream));
     // d h4p = dropout'(SiLU'(h4p)) o (dB W_ff2b) in the data-gradient GEMM's epilogue (act 3 against the saved pre-activation)
     IA_TRY(ia_gemm_bf16_ex(dB, d, wt_ff2b, d, N, d_ff, d, nullptr, 3, pff, seed + 5, 1.f, nullptr, 0, nullptr, 0, dhp, d_ff, nullptr, 0,
                            S.h4p, d_ff, stream));
     IA_TRY(linear_bwd_deferred(dB, S.h4, L.w_ff2b, N, d, d_ff, nullptr, G.w_ff2b, G.b_ff2b, wt_ff2b, grp, &ngrp, stream));
     IA_TRY(linear_bwd_deferred(dhp, S.y4, L.w_ff2a, N, d_ff, d, dy, G.w_ff2a, G.b_ff2a, wt_ff2a, grp, &ngrp, stream));
-    IA_TRY(ia_layernorm_bwd(S.x3, d, nullptr, dy, d, N, d, L.ln_ff2_g, L.ln_eps, dxa, dxb, d, G.ln_ff2_g, G.ln_ff2_b, scr, stream));   // d x3 -> dxb
+    IA_TRY(ia_layernorm_bwd_drop(S.x3, d, nullptr, dy, d, N, d, L.ln_ff2_g, L.ln_eps, dxa, dxb, d, G.ln_ff2_g, G.ln_ff2_b, 1.f, p,
+                                 seed + 4, dB1, d, scr, stream));   // d x3 -> dxb
     // convolution module
-    IA_TRY(ia_scale_dropout_bf16(dxb, N, d, 1.f, p, seed + 4, dB1, stream));
     IA_TRY(linear_bwd_deferred(dB1, S.c3, L.w_pw2, N, d, d, dc3, G.w_pw2, G.b_pw2, wt_pw2, grp, &ngrp, stream));
     if (phase == 0)
         IA_TRY(ia_bn_silu_bwd(S.z, dc3, N, d, S.sums, S.sums + d, L.bn_g, L.bn_b, L.bn_eps, G.bn_b, G.bn_g, dz, scr, stream));
@@ -337,9 +339,9 @@ extern "C" int ia_conformer_block_bwd_a_phase(const ia_block_params* Lp, const i
     IA_TRY(ia_dwconv_time_wgrad(Gm, dz, B, T, d, ksz, G.dw_w, G.dw_b, scr, stream));
     IA_TRY(ia_glu_bwd(S.c2, dG, lens, B, T, d, dc2, stream));
     IA_TRY(linear_bwd_deferred(dc2, S.y3, L.w_pw1, N, 2 * d, d, dy, G.w_pw1, G.b_pw1, wt_pw1, grp, &ngrp, stream));
-    IA_TRY(ia_layernorm_bwd(S.x2, d, nullptr, dy, d, N, d, L.ln_conv_g, L.ln_eps, dxb, dxa, d, G.ln_conv_g, G.ln_conv_b, scr, stream));  // d x2 -> dxa
+    IA_TRY(ia_layernorm_bwd_drop(S.x2, d, nullptr, dy, d, N, d, L.ln_conv_g, L.ln_eps, dxb, dxa, d, G.ln_conv_g, G.ln_conv_b, 1.f, p,
+                                 seed + 3, dB2, d, scr, stream));  // d x2 -> dxa
     // linear_out
-    IA_TRY(ia_scale_dropout_bf16(dxa, N, d, 1.f, p, seed + 3, dB2, stream));
     IA_TRY(linear_bwd_deferred(dB2, S.ctxv, L.w_out, N, d, d, dctx, G.w_out, G.b_out, wt_out, grp, &ngrp, stream));
     // the five weight (+ bias) gradients of this half in one GEMM launch + one finishing launch
     IA_TRY(flush_group(grp, ngrp, scr, stream));
@@ -380,9 +382,9 @@ extern "C" int ia_conformer_block_bwd_b(const ia_block_params* Lp, const ia_bloc
     // q|k|v projection (dW rows q, k, v contiguous; bias likewise) and the bias-free position projection
     IA_TRY(linear_bwd_deferred(dqkv, S.y2, L.w_qkv, N, 3 * d, d, dy, G.w_qkv, G.b_qkv, wt_qkv, grp, &ngrp, stream));
     grp[ngrp++] = ia_tn_problem{dpl, pos_emb, G.w_pos, nullptr, d, d, pos_rows, d, d};
-    IA_TRY(ia_layernorm_bwd(S.x1, d, nullptr, dy, d, N, d, L.ln_att_g, L.ln_eps, dxa, dxb, d, G.ln_att_g, G.ln_att_b, scr, stream));   // d x1 -> dxb
+    IA_TRY(ia_layernorm_bwd_drop(S.x1, d, nullptr, dy, d, N, d, L.ln_att_g, L.ln_eps, dxa, dxb, d, G.ln_att_g, G.ln_att_b, L.fc_factor,
+                                 p, seed + 2, dB, d, scr, stream));   // d x1 -> dxb
     // feed_forward1
-    IA_TRY(ia_scale_dropout_bf16(dxb, N, d, L.fc_factor, p, seed + 2, dB, stream));
     IA_TRY(ia_gemm_bf16_ex(dB, d, wt_ff1b, d, N, d_ff, d, nullptr, 3, pff, seed + 1, 1.f, nullptr, 0, nullptr, 0, dhp, d_ff, nullptr, 0,
                            S.h1p, d_ff, stream));
     IA_TRY(linear_bwd_deferred(dB, S.h1, L.w_ff1b, N, d, d_ff, nullptr, G.w_ff1b, G.b_ff1b, wt_ff1b, grp, &ngrp, stream));

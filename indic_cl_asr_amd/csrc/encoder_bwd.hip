@@ -10,6 +10,8 @@
 #include <hip/hip_bf16.h>
 
 #include "dropout_mask.h"
+#include <stdlib.h>
+
 #include "ia_common.h"
 #include "partials.h"
 
@@ -26,7 +28,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const __bf16* __restrict__ dyH, int ldy, int N, int d,
                                                             const float* __restrict__ gamma, float eps,
                                                             const float* __restrict__ dx_in, float* __restrict__ dx_out,
-                                                            int lddx, float* __restrict__ part) {
+                                                            int lddx, float* __restrict__ part, __bf16* __restrict__ dxh,
+                                                            int lddxh, float hscale, unsigned hseed, unsigned hthr, float hks) {
     const int lane = threadIdx.x & 63;
     const int wave0 = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
     const float inv_d = 1.f / (float)d;
@@ -87,6 +90,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                     o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
                 }
                 *reinterpret_cast<float4*>(dx_out + (size_t)row * lddx + col) = o;
+                if (dxh) {   // bf16(alpha * keep * scale * dx): what ia_scale_dropout_bf16 would make of dx_out, same mask bits
+                    const unsigned m = hthr > 0 ? (ia_keep8(hseed, (unsigned)row, (unsigned)d, (unsigned)(col & ~7), hthr) >> (col & 4)) : 0xFu;
+                    union { uint2 u; __bf16 h[4]; } t;
+                    t.h[0] = (__bf16)((m & 1u) ? o.x * hscale * hks : 0.f);
+                    t.h[1] = (__bf16)((m & 2u) ? o.y * hscale * hks : 0.f);
+                    t.h[2] = (__bf16)((m & 4u) ? o.z * hscale * hks : 0.f);
+                    t.h[3] = (__bf16)((m & 8u) ? o.w * hscale * hks : 0.f);
+                    *reinterpret_cast<uint2*>(dxh + (size_t)row * lddxh + col) = t.u;
+                }
             }
         }
     }
@@ -292,14 +304,33 @@ extern "C" int64_t ia_layernorm_bwd_scratch_elems(int N, int d) { return (N <= 0
 extern "C" int ia_layernorm_bwd(const float* x, int ldx, const float* dy_f32, const void* dy_bf16, int ldy, int N, int d,
                                 const float* gamma, float eps, const float* dx_in, float* dx_out, int lddx, float* dgamma,
                                 float* dbeta, float* scratch, ia_stream_t stream) {
+    return ia_layernorm_bwd_drop(x, ldx, dy_f32, dy_bf16, ldy, N, d, gamma, eps, dx_in, dx_out, lddx, dgamma, dbeta, 1.f, 0.f, 0,
+                                 nullptr, 0, scratch, stream);
+}
+
+extern "C" int ia_layernorm_bwd_drop(const float* x, int ldx, const float* dy_f32, const void* dy_bf16, int ldy, int N, int d,
+                                     const float* gamma, float eps, const float* dx_in, float* dx_out, int lddx, float* dgamma,
+                                     float* dbeta, float alpha, float dropout_p, unsigned seed, void* dx_bf16, int lddxh,
+                                     float* scratch, ia_stream_t stream) {
     if (!x || (!dy_f32 && !dy_bf16) || !gamma || !dx_out || !dgamma || !dbeta || !scratch || N <= 0 || d <= 0)
         return IA_INVALID_VALUE;
     if (d % 4 != 0 || d > 1024 || ldx % 4 != 0 || ldy % 4 != 0 || lddx % 4 != 0) return IA_UNSUPPORTED;
+    if (dx_bf16 && (d % 8 != 0 || lddxh % 4 != 0 || dropout_p < 0.f || dropout_p >= 1.f)) return IA_INVALID_VALUE;
+    static const bool split = [] { const char* e = getenv("IA_LN_DROP"); return e && e[0] == '0'; }();   // A/B switch: two launches
+    if (split && dx_bf16) {
+        const int st0 = ia_layernorm_bwd_drop(x, ldx, dy_f32, dy_bf16, ldy, N, d, gamma, eps, dx_in, dx_out, lddx, dgamma, dbeta, 1.f, 0.f,
+                                              0, nullptr, 0, scratch, stream);
+        if (st0 != IA_OK) return st0;
+        if (lddx != d || lddxh != d) return IA_UNSUPPORTED;
+        return ia_scale_dropout_bf16(dx_out, N, d, alpha, dropout_p, seed, dx_bf16, stream);
+    }
+    unsigned hthr = (unsigned)(dropout_p * 256.f + 0.5f);
+    const float hks = hthr > 0 ? 256.f / (256.f - (float)hthr) : 1.f;
     const int G = lnb_blocks(N);
     const dim3 grid(G), blk(256);
     hipStream_t st = (hipStream_t)stream;
     const int nv = (d + 255) / 256;
-#define IA_LNB(NV) hipLaunchKernelGGL((layernorm_bwd_kernel<NV>), grid, blk, 0, st, x, ldx, dy_f32, (const __bf16*)dy_bf16, ldy, N, d, gamma, eps, dx_in, dx_out, lddx, scratch)
+#define IA_LNB(NV) hipLaunchKernelGGL((layernorm_bwd_kernel<NV>), grid, blk, 0, st, x, ldx, dy_f32, (const __bf16*)dy_bf16, ldy, N, d, gamma, eps, dx_in, dx_out, lddx, scratch, (__bf16*)dx_bf16, lddxh, alpha, seed, hthr, hks)
     switch (nv) {
         case 1: IA_LNB(1); break;
         case 2: IA_LNB(2); break;

@@ -63,3 +63,29 @@ def test_native_block_refuses_a_second_backward():
     out.backward(retain_graph=True)
     with pytest.raises(RuntimeError, match="second time"):
         out.backward()
+
+
+def test_layernorm_bwd_emits_the_dropout_scaled_bf16_gradient():
+    """ia_layernorm_bwd_drop == ia_layernorm_bwd followed by ia_scale_dropout_bf16 on its result (same mask bits)."""
+    from indic_cl_asr_amd import _lib
+    L = _lib.lib()
+    for N, d, p, alpha in ((777, 256, 0.1, 0.5), (130, 144, 0.0, 1.0), (64, 512, 0.25, 0.5)):
+        g = torch.Generator().manual_seed(N + d)
+        x = torch.randn(N, d, generator=g).cuda()
+        dy = torch.randn(N, d, generator=g).cuda()
+        dx_in = torch.randn(N, d, generator=g).cuda()
+        gamma = (1 + 0.1 * torch.randn(d, generator=g)).cuda()
+        scr = torch.empty(L.ia_layernorm_bwd_scratch_elems(N, d), device="cuda")
+        dxa, dga, dba = torch.empty(N, d, device="cuda"), torch.empty(d, device="cuda"), torch.empty(d, device="cuda")
+        _lib.check(L.ia_layernorm_bwd(_lib.ptr(x), d, _lib.ptr(dy), None, d, N, d, _lib.ptr(gamma), 1e-5, _lib.ptr(dx_in), _lib.ptr(dxa), d,
+                                      _lib.ptr(dga), _lib.ptr(dba), _lib.ptr(scr), _lib.stream_ptr()), "ia_layernorm_bwd")
+        ha = torch.empty(N, d, dtype=torch.bfloat16, device="cuda")
+        _lib.check(L.ia_scale_dropout_bf16(_lib.ptr(dxa), N, d, alpha, p, 77, _lib.ptr(ha), _lib.stream_ptr()), "ia_scale_dropout_bf16")
+        dxb, dgb, dbb = torch.empty(N, d, device="cuda"), torch.empty(d, device="cuda"), torch.empty(d, device="cuda")
+        hb = torch.empty(N, d, dtype=torch.bfloat16, device="cuda")
+        _lib.check(L.ia_layernorm_bwd_drop(_lib.ptr(x), d, _lib.ptr(dy), None, d, N, d, _lib.ptr(gamma), 1e-5, _lib.ptr(dx_in), _lib.ptr(dxb), d,
+                                           _lib.ptr(dgb), _lib.ptr(dbb), alpha, p, 77, _lib.ptr(hb), d, _lib.ptr(scr), _lib.stream_ptr()),
+                   "ia_layernorm_bwd_drop")
+        torch.cuda.synchronize()
+        assert torch.equal(dxa, dxb) and torch.equal(dga, dgb) and torch.equal(dba, dbb)
+        assert torch.equal(ha, hb)
