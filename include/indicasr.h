@@ -282,14 +282,20 @@ int ia_bn_silu(const float* z, int64_t n_rows, int d, const float* bn_sum, const
                float momentum, float eps, int training, void* out, ia_stream_t stream);
 
 /* ia_bn_silu + the pointwise convolution behind it in ONE launch (csrc/gemm_bnsilu.hip; conformer_modules.py:354-366):
- * out = alpha * dropout(SiLU(BN(z))[M,K] @ W[N,K]^T + bias) + R, BN over the K channels from the batch sums (training) or
+ * out = alpha * dropout(SiLU(BN(z))[M,K] @ W[N,K]^T + bias) + R, BN over the K channels from the batch sums (training; fp32
+ * bn_sum / bn_sumsq, or the fixed-point accumulators of ia_glu_dwconv_fixed when bn_sums_fixed != NULL) or
  * the running statistics; bit-identical to ia_bn_silu followed by ia_gemm_bf16.  K <= 1024, K % 8 == 0. */
 int ia_gemm_bnsilu_supported(int K);
 int ia_gemm_bnsilu_bf16(const float* z, int ldz, int64_t n_rows, const float* bn_sum, const float* bn_sumsq,
                         const float* gamma, const float* beta, float* running_mean, float* running_var,
                         int64_t* num_batches_tracked, float momentum, float eps, int training, const void* W, int ldw, int M,
                         int N, int K, const float* bias, float dropout_p, unsigned seed, float alpha, const float* R, int ldr,
-                        float* outF, int ldof, void* outH, int ldoh, ia_stream_t stream);
+                        float* outF, int ldof, void* outH, int ldoh, const long long* bn_sums_fixed, ia_stream_t stream);
+/* ia_glu_dwconv with the BatchNorm sums accumulated into 64-bit fixed-point integers (units of 2^-24; [sum(d) | sumsq(d)],
+ * zeroed by the caller): deterministic without partial rows and a finishing launch.  ia_gemm_bnsilu_bf16 reads them through
+ * `bn_sums_fixed` (then bn_sum / bn_sumsq may be NULL). */
+int ia_glu_dwconv_fixed(const void* x2, const int64_t* lens, int B, int T, int d, int ksz, const float* w, const float* bias,
+                        float* z, long long* bn_sums_fixed, ia_stream_t stream);
 
 /* ia_relpos_attention: RelPositionMultiHeadAttention.forward core (A/parts/submodules/multi_head_attention.py:197-250,
  * rel_shift :184-195, masking :108-111) without materialising any [B,h,T,T] / [B,h,T,2T-1] tensor.

@@ -37,7 +37,7 @@ template <int KMAX, bool GLU>
 __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const void* __restrict__ xin, const int64_t* __restrict__ lens, int B,
                                                          int T, int d, int ksz, const float* __restrict__ w,
                                                          const float* __restrict__ bias, int flip, float* __restrict__ y,
-                                                         float* __restrict__ part) {
+                                                         float* __restrict__ part, long long* __restrict__ acc) {
     constexpr int HM = (KMAX - 1) / 2, WIN = DW_TT + KMAX - 1;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int ntb = (T + DW_TB - 1) / DW_TB;
@@ -83,8 +83,18 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const void* __restrict_
         red[wv][0][lane] = s; red[wv][1][lane] = s2;
         __syncthreads();
         if (wv == 0 && cok) {
-            part[(size_t)blockIdx.x * 2 * d + c] = (red[0][0][lane] + red[1][0][lane]) + (red[2][0][lane] + red[3][0][lane]);
-            part[(size_t)blockIdx.x * 2 * d + d + c] = (red[0][1][lane] + red[1][1][lane]) + (red[2][1][lane] + red[3][1][lane]);
+            const float t1 = (red[0][0][lane] + red[1][0][lane]) + (red[2][0][lane] + red[3][0][lane]);
+            const float t2 = (red[0][1][lane] + red[1][1][lane]) + (red[2][1][lane] + red[3][1][lane]);
+            if (acc) {
+                // fixed-point (2^-24) 64-bit integer accumulators, zeroed by the caller: integer adds commute, so the sums are
+                // deterministic without partial rows and a finishing launch (a workgroup's share is |t| < 2^20: no overflow
+                // for any batch, rounding 6e-8 per workgroup against sums of 1e3..1e6)
+                atomicAdd(reinterpret_cast<unsigned long long*>(acc + c), (unsigned long long)__float2ll_rn(t1 * 16777216.f));
+                atomicAdd(reinterpret_cast<unsigned long long*>(acc + d + c), (unsigned long long)__float2ll_rn(t2 * 16777216.f));
+            } else {
+                part[(size_t)blockIdx.x * 2 * d + c] = t1;
+                part[(size_t)blockIdx.x * 2 * d + d + c] = t2;
+            }
         }
     }
 }
@@ -193,7 +203,7 @@ extern "C" int ia_glu_dwconv(const void* x2, const int64_t* lens, int B, int T, 
     if (!dw_shape_ok(d, ksz)) return IA_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(B * ((T + DW_TB - 1) / DW_TB), (d + 63) / 64), blk(256);
-#define IA_DWF(K) hipLaunchKernelGGL((dwconv_fwd_kernel<K, true>), grid, blk, 0, st, x2, lens, B, T, d, ksz, w, bias, 0, z, scratch)
+#define IA_DWF(K) hipLaunchKernelGGL((dwconv_fwd_kernel<K, true>), grid, blk, 0, st, x2, lens, B, T, d, ksz, w, bias, 0, z, scratch, (long long*)nullptr)
     switch (kmax_for(ksz)) {
         case 9: IA_DWF(9); break;
         case 15: IA_DWF(15); break;
@@ -206,13 +216,30 @@ extern "C" int ia_glu_dwconv(const void* x2, const int64_t* lens, int B, int T, 
     return IA_OK;
 }
 
+extern "C" int ia_glu_dwconv_fixed(const void* x2, const int64_t* lens, int B, int T, int d, int ksz, const float* w,
+                                   const float* bias, float* z, long long* bn_sums_fixed, ia_stream_t stream) {
+    if (!x2 || !lens || !w || !bias || !z || !bn_sums_fixed || B <= 0 || T <= 0) return IA_INVALID_VALUE;
+    if (!dw_shape_ok(d, ksz)) return IA_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(B * ((T + DW_TB - 1) / DW_TB), (d + 63) / 64), blk(256);
+#define IA_DWF(K) hipLaunchKernelGGL((dwconv_fwd_kernel<K, true>), grid, blk, 0, st, x2, lens, B, T, d, ksz, w, bias, 0, z, (float*)nullptr, bn_sums_fixed)
+    switch (kmax_for(ksz)) {
+        case 9: IA_DWF(9); break;
+        case 15: IA_DWF(15); break;
+        default: IA_DWF(31); break;
+    }
+#undef IA_DWF
+    IA_RETURN_IF_LAUNCH_FAILED();
+    return IA_OK;
+}
+
 extern "C" int ia_dwconv_time(const float* x, int B, int T, int d, int ksz, const float* w, const float* bias, int flip,
                               float* y, ia_stream_t stream) {
     if (!x || !w || !y || B <= 0 || T <= 0) return IA_INVALID_VALUE;
     if (!dw_shape_ok(d, ksz)) return IA_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(B * ((T + DW_TB - 1) / DW_TB), (d + 63) / 64), blk(256);
-#define IA_DWF(K) hipLaunchKernelGGL((dwconv_fwd_kernel<K, false>), grid, blk, 0, st, (const void*)x, (const int64_t*)nullptr, B, T, d, ksz, w, bias, flip, y, (float*)nullptr)
+#define IA_DWF(K) hipLaunchKernelGGL((dwconv_fwd_kernel<K, false>), grid, blk, 0, st, (const void*)x, (const int64_t*)nullptr, B, T, d, ksz, w, bias, flip, y, (float*)nullptr, (long long*)nullptr)
     switch (kmax_for(ksz)) {
         case 9: IA_DWF(9); break;
         case 15: IA_DWF(15); break;

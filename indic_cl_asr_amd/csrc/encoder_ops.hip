@@ -103,19 +103,14 @@ __global__ __launch_bounds__(256) void bn_silu_kernel(const float* __restrict__ 
     for (int cch = threadIdx.x; cch < d; cch += 256) {
         float mean, var;
         if (training) {
-            mean = bn_sum[cch] * inv_n;
-            var = fmaxf(bn_sumsq[cch] * inv_n - mean * mean, 0.f);
+            ia_bn_batch_stats(bn_sum[cch], bn_sumsq[cch], inv_n, &mean, &var);
         } else {
             mean = running_mean[cch]; var = running_var[cch];
         }
-        const float sc = rsqrtf(var + eps) * gamma[cch];
-        s_scale[cch] = sc;
-        s_shift[cch] = beta[cch] - mean * sc;
+        ia_bn_scale_shift(mean, var, eps, gamma[cch], beta[cch], &s_scale[cch], &s_shift[cch]);
         // train-mode running statistics (unbiased variance), by the first workgroup: nobody reads them in this mode
         if (training && running_mean && running_var && blockIdx.x == 0) {
-            const float unbiased = var * ((float)n_rows / (float)(n_rows - 1));
-            running_mean[cch] = (1.f - momentum) * running_mean[cch] + momentum * mean;
-            running_var[cch] = (1.f - momentum) * running_var[cch] + momentum * unbiased;
+            ia_bn_running_update(&running_mean[cch], &running_var[cch], mean, var, (float)n_rows, momentum);
             if (cch == 0 && num_batches) num_batches[0] += 1;
         }
     }
@@ -128,8 +123,7 @@ __global__ __launch_bounds__(256) void bn_silu_kernel(const float* __restrict__ 
         union { uint4 u; __bf16 h[8]; } o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float y = xv[j] * s_scale[col + j] + s_shift[col + j];
-            o.h[j] = (__bf16)(y / (1.f + __expf(-y)));
+            o.h[j] = (__bf16)ia_bn_silu_value(xv[j], s_scale[col + j], s_shift[col + j]);
         }
         reinterpret_cast<uint4*>(out)[i] = o.u;
     }

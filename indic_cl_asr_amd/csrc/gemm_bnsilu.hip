@@ -31,7 +31,7 @@ constexpr int BS_REGION = BS_EPI > BS_MAIN ? BS_EPI : BS_MAIN;
 
 struct BsArgs {
     const float* z; int ldz;
-    const float* bn_sum; const float* bn_sumsq; const float* gamma; const float* beta;
+    const float* bn_sum; const float* bn_sumsq; const long long* fixed; const float* gamma; const float* beta;
     float* rm; float* rv; int64_t* nbt; float momentum, eps; int training; int64_t n_rows;
     const __bf16* W; int ldw; const float* bias; const float* R; int ldr;
     float* outF; int ldof; __bf16* outH; int ldoh;
@@ -52,18 +52,16 @@ __global__ __launch_bounds__(BS_THREADS, 4) void gemm_bnsilu_kernel(BsArgs a) {
         for (int ch = tid; ch < a.K; ch += BS_THREADS) {
             float mean, var;
             if (a.training) {
-                mean = a.bn_sum[ch] * inv_n;
-                var = fmaxf(a.bn_sumsq[ch] * inv_n - mean * mean, 0.f);
+                // the batch sums: fp32, or the fixed-point accumulators of ia_glu_dwconv_fixed ([sum | sumsq], 2^-24 units)
+                const float s1 = a.fixed ? (float)((double)a.fixed[ch] * (1.0 / 16777216.0)) : a.bn_sum[ch];
+                const float s2 = a.fixed ? (float)((double)a.fixed[a.K + ch] * (1.0 / 16777216.0)) : a.bn_sumsq[ch];
+                ia_bn_batch_stats(s1, s2, inv_n, &mean, &var);
             } else {
                 mean = a.rm[ch]; var = a.rv[ch];
             }
-            const float sc = rsqrtf(var + a.eps) * a.gamma[ch];
-            s_scale[ch] = sc;
-            s_shift[ch] = a.beta[ch] - mean * sc;
+            ia_bn_scale_shift(mean, var, a.eps, a.gamma[ch], a.beta[ch], &s_scale[ch], &s_shift[ch]);
             if (a.training && a.rm && a.rv && blockIdx.x == 0) {   // nobody reads the running statistics in this mode
-                const float unbiased = var * ((float)a.n_rows / (float)(a.n_rows - 1));
-                a.rm[ch] = (1.f - a.momentum) * a.rm[ch] + a.momentum * mean;
-                a.rv[ch] = (1.f - a.momentum) * a.rv[ch] + a.momentum * unbiased;
+                ia_bn_running_update(&a.rm[ch], &a.rv[ch], mean, var, (float)a.n_rows, a.momentum);
                 if (ch == 0 && a.nbt) a.nbt[0] += 1;
             }
         }
@@ -108,10 +106,8 @@ __global__ __launch_bounds__(BS_THREADS, 4) void gemm_bnsilu_kernel(BsArgs a) {
         if (kk_ < a.K) {                                                                                  \
             const float4 sc_ = *reinterpret_cast<const float4*>(s_scale + kk_);                           \
             const float4 sh_ = *reinterpret_cast<const float4*>(s_shift + kk_);                           \
-            const float y0_ = (v_).x * sc_.x + sh_.x, y1_ = (v_).y * sc_.y + sh_.y;                       \
-            const float y2_ = (v_).z * sc_.z + sh_.z, y3_ = (v_).w * sc_.w + sh_.w;                       \
-            o_.h[0] = (__bf16)(y0_ / (1.f + __expf(-y0_))); o_.h[1] = (__bf16)(y1_ / (1.f + __expf(-y1_))); \
-            o_.h[2] = (__bf16)(y2_ / (1.f + __expf(-y2_))); o_.h[3] = (__bf16)(y3_ / (1.f + __expf(-y3_))); \
+            o_.h[0] = (__bf16)ia_bn_silu_value((v_).x, sc_.x, sh_.x); o_.h[1] = (__bf16)ia_bn_silu_value((v_).y, sc_.y, sh_.y); \
+            o_.h[2] = (__bf16)ia_bn_silu_value((v_).z, sc_.z, sh_.z); o_.h[3] = (__bf16)ia_bn_silu_value((v_).w, sc_.w, sh_.w); \
         } else {                                                                                          \
             o_.u = make_uint2(0, 0);                                                                      \
         }                                                                                                 \
@@ -229,9 +225,10 @@ extern "C" int ia_gemm_bnsilu_bf16(const float* z, int ldz, int64_t n_rows, cons
                                    const float* gamma, const float* beta, float* running_mean, float* running_var,
                                    int64_t* num_batches_tracked, float momentum, float eps, int training, const void* W, int ldw,
                                    int M, int N, int K, const float* bias, float dropout_p, unsigned seed, float alpha,
-                                   const float* R, int ldr, float* outF, int ldof, void* outH, int ldoh, ia_stream_t stream) {
+                                   const float* R, int ldr, float* outF, int ldof, void* outH, int ldoh,
+                                   const long long* bn_sums_fixed, ia_stream_t stream) {
     if (!z || !gamma || !beta || !W || (!outF && !outH) || M <= 0 || N <= 0 || n_rows <= 0) return IA_INVALID_VALUE;
-    if (training ? (!bn_sum || !bn_sumsq) : (!running_mean || !running_var)) return IA_INVALID_VALUE;
+    if (training ? (!bn_sums_fixed && (!bn_sum || !bn_sumsq)) : (!running_mean || !running_var)) return IA_INVALID_VALUE;
     if (!ia_gemm_bnsilu_supported(K)) return IA_UNSUPPORTED;
     if (N % 8 != 0 || ldz % 4 != 0 || ldw % 8 != 0 || (R && ldr % 4 != 0) || (outF && ldof % 4 != 0) || (outH && ldoh % 8 != 0))
         return IA_UNSUPPORTED;
@@ -240,7 +237,7 @@ extern "C" int ia_gemm_bnsilu_bf16(const float* z, int ldz, int64_t n_rows, cons
         return IA_INVALID_VALUE;
     if (dropout_p < 0.f || dropout_p >= 1.f) return IA_INVALID_VALUE;
     BsArgs a;
-    a.z = z; a.ldz = ldz; a.bn_sum = bn_sum; a.bn_sumsq = bn_sumsq; a.gamma = gamma; a.beta = beta;
+    a.z = z; a.ldz = ldz; a.bn_sum = bn_sum; a.bn_sumsq = bn_sumsq; a.fixed = bn_sums_fixed; a.gamma = gamma; a.beta = beta;
     a.rm = running_mean; a.rv = running_var; a.nbt = num_batches_tracked; a.momentum = momentum; a.eps = eps;
     a.training = training; a.n_rows = n_rows;
     a.W = (const __bf16*)W; a.ldw = ldw; a.bias = bias; a.R = R; a.ldr = ldr; a.outF = outF; a.ldof = ldof;

@@ -77,6 +77,37 @@ __device__ __forceinline__ float ia_wave_shl1(float v, float fill) {  // lane i 
         __builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x130, 0xF, 0xF, false));
 }
 
+// Train / eval BatchNorm as y = x * scale + shift.  csrc/encoder_ops.hip (ia_bn_silu) and csrc/gemm_bnsilu.hip must produce the
+// same bits from the same sums, so nothing here is left to the compiler's fma contraction (it contracts a*b - c*d differently
+// from kernel to kernel; the __f*_rn intrinsics do not stop it): explicit fmaf, contraction off for the rest.
+__device__ __forceinline__ void ia_bn_scale_shift(float mean, float var, float eps, float gamma, float beta, float* scale, float* shift) {
+#pragma clang fp contract(off)
+    const float sc = rsqrtf(var + eps) * gamma;
+    *scale = sc;
+    *shift = __builtin_fmaf(-mean, sc, beta);
+}
+__device__ __forceinline__ void ia_bn_batch_stats(float sum, float sumsq, float inv_n, float* mean, float* var) {
+#pragma clang fp contract(off)
+    const float m = sum * inv_n;
+    const float e2 = sumsq * inv_n;
+    *mean = m;
+    *var = fmaxf(__builtin_fmaf(-m, m, e2), 0.f);
+}
+__device__ __forceinline__ void ia_bn_running_update(float* rm, float* rv, float mean, float var, float n_rows, float momentum) {
+#pragma clang fp contract(off)
+    const float unbiased = var * (n_rows / (n_rows - 1.f));
+    const float keep = 1.f - momentum;
+    const float a = keep * *rm, b = keep * *rv;
+    *rm = __builtin_fmaf(momentum, mean, a);
+    *rv = __builtin_fmaf(momentum, unbiased, b);
+}
+__device__ __forceinline__ float ia_bn_silu_value(float x, float scale, float shift) {
+#pragma clang fp contract(off)
+    const float y = __builtin_fmaf(x, scale, shift);
+    const float e = __expf(-y);
+    return y / (1.f + e);
+}
+
 // log(exp(a)+exp(b)) with the reference's -inf short cuts (K/utils/rnnt_helper.py:42-53).
 __device__ __forceinline__ float ia_lse2(float a, float b) {
     const float mx = fmaxf(a, b), mn = fminf(a, b);

@@ -56,3 +56,32 @@ def test_glu_dwconv_masks_padding_and_returns_batchnorm_sums(B, T, d, k):
     assert torch.allclose(z, zr, rtol=1e-3, atol=1e-3)
     assert torch.allclose(sums[0], zr.sum((0, 1)), rtol=1e-3, atol=1e-2)
     assert torch.allclose(sums[1], (zr * zr).sum((0, 1)), rtol=1e-3, atol=1e-2)
+
+
+def test_glu_dwconv_fixed_point_sums_match_the_partial_row_sums():
+    """ia_glu_dwconv_fixed: same z, BatchNorm sums in 2^-24 fixed point (integer atomics) == the fp32 partial-row sums."""
+    from indic_cl_asr_amd import _lib
+    L = _lib.lib()
+    for B, T, d, ksz in ((4, 200, 256, 31), (2, 77, 144, 9)):
+        g = torch.Generator().manual_seed(B * T)
+        x2 = torch.randn(B * T, 2 * d, generator=g).bfloat16().cuda()
+        lens = torch.tensor([T] + [max(1, T - 13 * (i + 1)) for i in range(B - 1)], dtype=torch.long).cuda()
+        w = (torch.randn(d, ksz, generator=g) * 0.2).cuda()
+        bias = (torch.randn(d, generator=g) * 0.1).cuda()
+        za, zb = torch.empty(B * T, d, device="cuda"), torch.empty(B * T, d, device="cuda")
+        sums = torch.empty(2 * d, device="cuda")
+        scr = torch.empty(L.ia_dwconv_scratch_elems(B, T, d, ksz), device="cuda")
+        _lib.check(L.ia_glu_dwconv(_lib.ptr(x2), _lib.ptr(lens), B, T, d, ksz, _lib.ptr(w), _lib.ptr(bias), _lib.ptr(za), _lib.ptr(sums[:d]),
+                                   _lib.ptr(sums[d:]), _lib.ptr(scr), _lib.stream_ptr()), "ia_glu_dwconv")
+        for _ in range(2):      # twice: the accumulators must give the same bits run to run
+            acc = torch.zeros(2 * d, dtype=torch.int64, device="cuda")
+            _lib.check(L.ia_glu_dwconv_fixed(_lib.ptr(x2), _lib.ptr(lens), B, T, d, ksz, _lib.ptr(w), _lib.ptr(bias), _lib.ptr(zb),
+                                             _lib.ptr(acc), _lib.stream_ptr()), "ia_glu_dwconv_fixed")
+            torch.cuda.synchronize()
+            if _ == 0:
+                first = acc.clone()
+            else:
+                assert torch.equal(acc, first)
+        assert torch.equal(za, zb)
+        got = acc.double() / 2 ** 24
+        assert torch.allclose(got, sums.double(), rtol=1e-5, atol=1e-4)

@@ -36,7 +36,7 @@ def _run(M, d, N, training, p, seed=11):
     yb = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
     _lib.check(L.ia_gemm_bnsilu_bf16(_lib.ptr(z), d, M, _lib.ptr(s1), _lib.ptr(s2), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(rm_b),
                                      _lib.ptr(rv_b), _lib.ptr(nbt_b), 0.1, 1e-5, int(training), _lib.ptr(W), d, M, N, d, _lib.ptr(bias),
-                                     float(p), seed, 1.0, _lib.ptr(xb), N, _lib.ptr(xb), N, _lib.ptr(yb), N, _lib.stream_ptr()),
+                                     float(p), seed, 1.0, _lib.ptr(xb), N, _lib.ptr(xb), N, _lib.ptr(yb), N, None, _lib.stream_ptr()),
                "ia_gemm_bnsilu_bf16")
     torch.cuda.synchronize()
     assert torch.equal(xa, xb)
