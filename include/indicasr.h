@@ -291,8 +291,8 @@ int ia_gemm_bnsilu_bf16(const float* z, int ldz, int64_t n_rows, const float* bn
                         int64_t* num_batches_tracked, float momentum, float eps, int training, const void* W, int ldw, int M,
                         int N, int K, const float* bias, float dropout_p, unsigned seed, float alpha, const float* R, int ldr,
                         float* outF, int ldof, void* outH, int ldoh, const long long* bn_sums_fixed, ia_stream_t stream);
-/* ia_glu_dwconv with the BatchNorm sums accumulated into 64-bit fixed-point integers (units of 2^-24; [sum(d) | sumsq(d)],
- * zeroed by the caller): deterministic without partial rows and a finishing launch.  ia_gemm_bnsilu_bf16 reads them through
+/* ia_glu_dwconv with the BatchNorm sums accumulated into 64-bit fixed-point integers (units of 2^-24; 8 copies of
+ * [sum(d) | sumsq(d)] = 16 d values, the workgroups spread over the copies, the reader adds them; zeroed by the caller): deterministic without partial rows and a finishing launch.  ia_gemm_bnsilu_bf16 reads them through
  * `bn_sums_fixed` (then bn_sum / bn_sumsq may be NULL). */
 int ia_glu_dwconv_fixed(const void* x2, const int64_t* lens, int B, int T, int d, int ksz, const float* w, const float* bias,
                         float* z, long long* bn_sums_fixed, ia_stream_t stream);

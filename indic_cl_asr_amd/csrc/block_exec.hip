@@ -9,6 +9,7 @@
 #include <cstdlib>
 
 #include "indicasr.h"
+#include "ia_common.h"
 
 namespace {
 inline size_t up256(size_t x) { return (x + 255) / 256 * 256; }
@@ -30,7 +31,7 @@ PrefixWs prefix_ws(int B, int T, int d, int d_ff, int H, int ksz, int pos_rows) 
     w.c2 = o;   o = up256(o + N * 2 * d * 2);
     w.z = o;    o = up256(o + N * d * 4);
     w.sums = o; o = up256(o + (2 * (size_t)d + 64) * 4);   // [sum | sumsq | row count (SyncBatchNorm exchange)]
-    w.acc = o;  o = up256(o + (size_t)PREFIX_ACC_LAYERS * 2 * d * 8);   // per-layer fixed-point BatchNorm sums (one memset per call)
+    w.acc = o;  o = up256(o + (size_t)PREFIX_ACC_LAYERS * IA_BN_ACC_COPIES * 2 * d * 8);   // per-layer fixed-point BatchNorm sums (one memset per call)
     w.c3 = o;   o = up256(o + N * d * 2);
     w.vt = o;   o = up256(o + ia_attn_vt_elems(B, T, H) * 2);
     w.scr = o;  o = up256(o + (size_t)ia_dwconv_scratch_elems(B, T, d, ksz) * 4);
@@ -96,7 +97,7 @@ extern "C" int ia_conformer_prefix_fwd_seg(const ia_block_params* layers, int n_
     // layer, zeroed by ONE memset here, added to by the depthwise-conv workgroups with integer atomics (deterministic) and read
     // by the fused BatchNorm + SiLU + pointwise-conv launch -- no partial rows, no finishing launch per block
     const bool bn_fixed = bnsilu_fused && !bn_synced && seg_begin == 0 && seg_end >= 2 * n_layers && n_layers <= PREFIX_ACC_LAYERS;
-    if (bn_fixed && hipMemsetAsync(acc, 0, (size_t)n_layers * 2 * d * sizeof(long long), (hipStream_t)stream) != hipSuccess)
+    if (bn_fixed && hipMemsetAsync(acc, 0, (size_t)n_layers * IA_BN_ACC_COPIES * 2 * d * sizeof(long long), (hipStream_t)stream) != hipSuccess)
         return IA_LAUNCH_FAILED;
     // attention: key-tile loop kernel (any T, head dim <= 64); IA_PREFIX_ATTN=old selects the all-keys-in-registers kernel
     const char* attn_env = getenv("IA_PREFIX_ATTN");
@@ -138,7 +139,7 @@ extern "C" int ia_conformer_prefix_fwd_seg(const ia_block_params* layers, int n_
         IA_TRY(ia_layernorm(x, d, N, d, L.ln_conv_g, L.ln_conv_b, L.ln_eps, nullptr, 0, nullptr, nullptr, y, d, stream));
         IA_TRY(ia_gemm_bf16(y, d, L.w_pw1, d, N, 2 * d, d, L.b_pw1, 0, 0.f, 0, 1.f, nullptr, 0, nullptr, 0, c2, 2 * d, stream));
         if (bn_fixed)
-            IA_TRY(ia_glu_dwconv_fixed(c2, lens, B, T, d, ksz, L.dw_w, L.dw_b, z, acc + (size_t)li * 2 * d, stream));
+            IA_TRY(ia_glu_dwconv_fixed(c2, lens, B, T, d, ksz, L.dw_w, L.dw_b, z, acc + (size_t)li * IA_BN_ACC_COPIES * 2 * d, stream));
         else
             IA_TRY(ia_glu_dwconv(c2, lens, B, T, d, ksz, L.dw_w, L.dw_b, z, sums, sums + d, scr, stream));
         }
@@ -147,7 +148,7 @@ extern "C" int ia_conformer_prefix_fwd_seg(const ia_block_params* layers, int n_
             IA_TRY(ia_gemm_bnsilu_bf16(z, d, N, sums, sums + d, L.bn_g, L.bn_b, bn_synced ? nullptr : L.bn_rm,
                                        bn_synced ? nullptr : L.bn_rv, bn_synced ? nullptr : L.bn_nbt, L.bn_momentum, L.bn_eps,
                                        training ? 1 : 0, L.w_pw2, d, (int)N, d, d, L.b_pw2, p, seed + 4, 1.f, x, d, x, d, nullptr, 0,
-                                       bn_fixed ? acc + (size_t)li * 2 * d : nullptr, stream));
+                                       bn_fixed ? acc + (size_t)li * IA_BN_ACC_COPIES * 2 * d : nullptr, stream));
         } else {
             IA_TRY(ia_bn_silu(z, N, d, sums, sums + d, L.bn_g, L.bn_b, bn_synced ? nullptr : L.bn_rm, bn_synced ? nullptr : L.bn_rv,
                               bn_synced ? nullptr : L.bn_nbt, L.bn_momentum, L.bn_eps, training ? 1 : 0, c3, stream));

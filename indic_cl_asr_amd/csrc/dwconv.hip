@@ -89,8 +89,10 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const void* __restrict_
                 // fixed-point (2^-24) 64-bit integer accumulators, zeroed by the caller: integer adds commute, so the sums are
                 // deterministic without partial rows and a finishing launch (a workgroup's share is |t| < 2^20: no overflow
                 // for any batch, rounding 6e-8 per workgroup against sums of 1e3..1e6)
-                atomicAdd(reinterpret_cast<unsigned long long*>(acc + c), (unsigned long long)__float2ll_rn(t1 * 16777216.f));
-                atomicAdd(reinterpret_cast<unsigned long long*>(acc + d + c), (unsigned long long)__float2ll_rn(t2 * 16777216.f));
+                // IA_BN_ACC_COPIES copies, chosen by workgroup: ~190 same-address atomics in a row cost the kernel 3.6 us
+                long long* mine = acc + (size_t)(blockIdx.x & (IA_BN_ACC_COPIES - 1)) * 2 * d;
+                atomicAdd(reinterpret_cast<unsigned long long*>(mine + c), (unsigned long long)__float2ll_rn(t1 * 16777216.f));
+                atomicAdd(reinterpret_cast<unsigned long long*>(mine + d + c), (unsigned long long)__float2ll_rn(t2 * 16777216.f));
             } else {
                 part[(size_t)blockIdx.x * 2 * d + c] = t1;
                 part[(size_t)blockIdx.x * 2 * d + d + c] = t2;

@@ -53,8 +53,15 @@ __global__ __launch_bounds__(BS_THREADS, 4) void gemm_bnsilu_kernel(BsArgs a) {
             float mean, var;
             if (a.training) {
                 // the batch sums: fp32, or the fixed-point accumulators of ia_glu_dwconv_fixed ([sum | sumsq], 2^-24 units)
-                const float s1 = a.fixed ? (float)((double)a.fixed[ch] * (1.0 / 16777216.0)) : a.bn_sum[ch];
-                const float s2 = a.fixed ? (float)((double)a.fixed[a.K + ch] * (1.0 / 16777216.0)) : a.bn_sumsq[ch];
+                float s1, s2;
+                if (a.fixed) {
+                    long long f1 = 0, f2 = 0;
+#pragma unroll
+                    for (int r = 0; r < IA_BN_ACC_COPIES; ++r) { f1 += a.fixed[(size_t)r * 2 * a.K + ch]; f2 += a.fixed[(size_t)r * 2 * a.K + a.K + ch]; }
+                    s1 = (float)((double)f1 * (1.0 / 16777216.0)); s2 = (float)((double)f2 * (1.0 / 16777216.0));
+                } else {
+                    s1 = a.bn_sum[ch]; s2 = a.bn_sumsq[ch];
+                }
                 ia_bn_batch_stats(s1, s2, inv_n, &mean, &var);
             } else {
                 mean = a.rm[ch]; var = a.rv[ch];

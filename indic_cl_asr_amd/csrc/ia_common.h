@@ -77,6 +77,8 @@ __device__ __forceinline__ float ia_wave_shl1(float v, float fill) {  // lane i 
         __builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x130, 0xF, 0xF, false));
 }
 
+constexpr int IA_BN_ACC_COPIES = 8;   // replicas of the fixed-point BatchNorm accumulators (ia_glu_dwconv_fixed): [copies][2][d] int64
+
 // Train / eval BatchNorm as y = x * scale + shift.  csrc/encoder_ops.hip (ia_bn_silu) and csrc/gemm_bnsilu.hip must produce the
 // same bits from the same sums, so nothing here is left to the compiler's fma contraction (it contracts a*b - c*d differently
 // from kernel to kernel; the __f*_rn intrinsics do not stop it): explicit fmaf, contraction off for the rest.

@@ -74,7 +74,7 @@ def test_glu_dwconv_fixed_point_sums_match_the_partial_row_sums():
         _lib.check(L.ia_glu_dwconv(_lib.ptr(x2), _lib.ptr(lens), B, T, d, ksz, _lib.ptr(w), _lib.ptr(bias), _lib.ptr(za), _lib.ptr(sums[:d]),
                                    _lib.ptr(sums[d:]), _lib.ptr(scr), _lib.stream_ptr()), "ia_glu_dwconv")
         for _ in range(2):      # twice: the accumulators must give the same bits run to run
-            acc = torch.zeros(2 * d, dtype=torch.int64, device="cuda")
+            acc = torch.zeros(8, 2 * d, dtype=torch.int64, device="cuda")
             _lib.check(L.ia_glu_dwconv_fixed(_lib.ptr(x2), _lib.ptr(lens), B, T, d, ksz, _lib.ptr(w), _lib.ptr(bias), _lib.ptr(zb),
                                              _lib.ptr(acc), _lib.stream_ptr()), "ia_glu_dwconv_fixed")
             torch.cuda.synchronize()
@@ -83,5 +83,5 @@ def test_glu_dwconv_fixed_point_sums_match_the_partial_row_sums():
             else:
                 assert torch.equal(acc, first)
         assert torch.equal(za, zb)
-        got = acc.double() / 2 ** 24
+        got = acc.sum(0).double() / 2 ** 24
         assert torch.allclose(got, sums.double(), rtol=1e-5, atol=1e-4)
