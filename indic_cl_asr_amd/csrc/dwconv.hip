@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const void* __restrict_
         if (GLU) {
             const __bf16* p = reinterpret_cast<const __bf16*>(xin) + ((size_t)b * T + tt) * (2 * d);
             const float a = (float)p[cc], gate = (float)p[d + cc];
-            v = a / (1.f + __expf(-gate));
+            v = a * ia_sigmoid_fast(gate);
         } else {
             v = reinterpret_cast<const float*>(xin)[((size_t)b * T + tt) * d + cc];
         }

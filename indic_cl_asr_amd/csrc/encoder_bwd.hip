@@ -18,7 +18,7 @@
 namespace {
 
 __device__ __forceinline__ float silu_grad(float x) {
-    const float s = 1.f / (1.f + __expf(-x));
+    const float s = ia_sigmoid_fast(x);
     return s * (1.f + x * (1.f - s));
 }
 
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void silu_dropout_kernel(const __bf16* __restr
         for (int j = 0; j < 8; ++j) {
             const float v = (float)x.h[j];
             float r;
-            if (MODE == 0) r = v / (1.f + __expf(-v));
+            if (MODE == 0) r = ia_silu_fast(v);
             else r = (float)y.h[j] * silu_grad(v);
             o.h[j] = (__bf16)(((m >> j) & 1u) ? r * keep_scale : 0.f);
         }
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void glu_kernel(const __bf16* __restrict__ c2,
         const int t = (int)(row % T), b = (int)(row / T);
         const bool valid = t < (int)lens[b];
         const float a = (float)c2[row * 2 * d + c], g = (float)c2[row * 2 * d + d + c];
-        const float sg = 1.f / (1.f + __expf(-g));
+        const float sg = ia_sigmoid_fast(g);
         if (MODE == 0) {
             G[i] = valid ? a * sg : 0.f;
         } else {

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(G_THREADS, (BM == 128 ? 3 : 4)) void gemm_bf16_nt_k
         }
         if (a.act == 1) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = v[j] / (1.f + __expf(-v[j]));
+            for (int j = 0; j < 8; ++j) v[j] = ia_silu_fast(v[j]);
         } else if (a.act == 2) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(G_THREADS, (BM == 128 ? 3 : 4)) void gemm_bf16_nt_k
             x.u = *reinterpret_cast<const uint4*>(a.aux + (size_t)gm * a.ldaux + gn);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float t = (float)x.h[j], sg = 1.f / (1.f + __expf(-t));
+                const float t = (float)x.h[j], sg = ia_sigmoid_fast(t);
                 v[j] = (float)(__bf16)v[j] * (sg * (1.f + t * (1.f - sg)));
             }
         }

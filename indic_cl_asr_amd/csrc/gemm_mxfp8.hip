@@ -170,7 +170,7 @@ __global__ __launch_bounds__(MX_THREADS, 2) void gemm_mxfp8_nt_kernel(MxArgs a) 
             }
             if (a.act == 1) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = v[j] / (1.f + __expf(-v[j]));
+                for (int j = 0; j < 8; ++j) v[j] = ia_silu_fast(v[j]);
             } else if (a.act == 2) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);

@@ -77,6 +77,13 @@ __device__ __forceinline__ float ia_wave_shl1(float v, float fill) {  // lane i 
         __builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x130, 0xF, 0xF, false));
 }
 
+// sigmoid / SiLU with the hardware reciprocal (1 ulp) instead of the IEEE division sequence (~10 dependent VALU operations):
+// 6 operations per element; every consumer rounds the result to bf16 or feeds a sum (csrc/ffn_fused.hip does the same)
+__device__ __forceinline__ float ia_sigmoid_fast(float x) {
+    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * -1.44269504088896341f));
+}
+__device__ __forceinline__ float ia_silu_fast(float x) { return x * ia_sigmoid_fast(x); }
+
 constexpr int IA_BN_ACC_COPIES = 8;   // replicas of the fixed-point BatchNorm accumulators (ia_glu_dwconv_fixed): [copies][2][d] int64
 
 // Train / eval BatchNorm as y = x * scale + shift.  csrc/encoder_ops.hip (ia_bn_silu) and csrc/gemm_bnsilu.hip must produce the
@@ -106,8 +113,7 @@ __device__ __forceinline__ void ia_bn_running_update(float* rm, float* rv, float
 __device__ __forceinline__ float ia_bn_silu_value(float x, float scale, float shift) {
 #pragma clang fp contract(off)
     const float y = __builtin_fmaf(x, scale, shift);
-    const float e = __expf(-y);
-    return y / (1.f + e);
+    return ia_silu_fast(y);
 }
 
 // log(exp(a)+exp(b)) with the reference's -inf short cuts (K/utils/rnnt_helper.py:42-53).
