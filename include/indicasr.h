@@ -294,6 +294,10 @@ int ia_gemm_bnsilu_bf16(const float* z, int ldz, int64_t n_rows, const float* bn
 /* ia_glu_dwconv with the BatchNorm sums accumulated into 64-bit fixed-point integers (units of 2^-24; 8 copies of
  * [sum(d) | sumsq(d)] = 16 d values, the workgroups spread over the copies, the reader adds them; zeroed by the caller): deterministic without partial rows and a finishing launch.  ia_gemm_bnsilu_bf16 reads them through
  * `bn_sums_fixed` (then bn_sum / bn_sumsq may be NULL). */
+/* ... and the same for an input the GLU has already been applied to (g [B*T, d] bf16: ia_gemm_bf16_ex with act 4 on the
+ * regrouped pointwise_conv1 weight): frames >= lens[b] read as zero, depthwise conv, z, fixed-point BatchNorm sums. */
+int ia_dwconv_gated_fixed(const void* g, const int64_t* lens, int B, int T, int d, int ksz, const float* w, const float* bias,
+                          float* z, long long* bn_sums_fixed, ia_stream_t stream);
 int ia_glu_dwconv_fixed(const void* x2, const int64_t* lens, int B, int T, int d, int ksz, const float* w, const float* bias,
                         float* z, long long* bn_sums_fixed, ia_stream_t stream);
 
@@ -495,6 +499,10 @@ typedef struct ia_block_params {
     int d, d_ff, n_heads, ksz;
     const void* pl_cached;   /* optional: linear_pos(pos_emb) [pos_rows, d] bf16 computed earlier (frozen weights: it only
                                 depends on T) -- the executor then skips that GEMM; NULL: computed per call */
+    const void* w_pw1_glu;   /* optional (d % 64 == 0): pointwise_conv1 weight / bias with the rows regrouped so that every 128 */
+    const float* b_pw1_glu;  /* consecutive outputs are 64 value channels followed by THEIR 64 gate channels (rows 128t+j = value
+                                channel 64t+j, rows 128t+64+j = gate channel d+64t+j): the prefix executor then applies the GLU in
+                                the GEMM epilogue (act 4) and the depthwise conv reads the gated [N,d] bf16 tensor; NULL: off */
 } ia_block_params;
 size_t ia_conformer_prefix_ws_bytes(int B, int T, int d, int d_ff, int H, int ksz, int pos_rows);
 int ia_conformer_prefix_fwd(const ia_block_params* layers, int n_layers, float* x, const void* pos_emb, int pos_rows,

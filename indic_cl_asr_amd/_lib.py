@@ -28,7 +28,7 @@ class BlockParams(_c.Structure):
         "pos_u", "pos_v", "dw_w", "dw_b", "bn_g", "bn_b", "bn_rm", "bn_rv", "bn_nbt")]
         + [(n, _c.c_float) for n in ("ln_eps", "bn_eps", "bn_momentum", "p_drop", "p_ff", "p_att", "fc_factor")]
         + [(n, _c.c_int) for n in ("d", "d_ff", "n_heads", "ksz")]
-        + [("pl_cached", _c.c_void_p)])
+        + [("pl_cached", _c.c_void_p), ("w_pw1_glu", _c.c_void_p), ("b_pw1_glu", _c.c_void_p)])
 
 
 class BlockSaved(_c.Structure):
@@ -110,6 +110,7 @@ SIGNATURES = {
     "ia_gemm_bnsilu_bf16": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _i, _i, _i, _i, _vp, _f, _c.c_uint, _f,
                                  _vp, _i, _vp, _i, _vp, _i, _vp, _vp]),
     "ia_glu_dwconv_fixed": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "ia_dwconv_gated_fixed": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "ia_attn_vt_elems": (_sz, [_i, _i, _i]),
     "ia_relpos_attention": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _c.c_uint, _vp, _vp, _vp]),
     "ia_relpos_attention_flash_supported": (_i, [_i, _i]),

@@ -99,6 +99,8 @@ extern "C" int ia_conformer_prefix_fwd_seg(const ia_block_params* layers, int n_
     const bool bn_fixed = bnsilu_fused && !bn_synced && seg_begin == 0 && seg_end >= 2 * n_layers && n_layers <= PREFIX_ACC_LAYERS;
     if (bn_fixed && hipMemsetAsync(acc, 0, (size_t)n_layers * IA_BN_ACC_COPIES * 2 * d * sizeof(long long), (hipStream_t)stream) != hipSuccess)
         return IA_LAUNCH_FAILED;
+    const char* glu_env = getenv("IA_PREFIX_GLU");   // "dwconv": GLU inside the depthwise-conv kernel (A/B switch)
+    const bool glu_in_gemm = d % 64 == 0 && !(glu_env && glu_env[0] == 'd');
     // attention: key-tile loop kernel (any T, head dim <= 64); IA_PREFIX_ATTN=old selects the all-keys-in-registers kernel
     const char* attn_env = getenv("IA_PREFIX_ATTN");
     const bool use_flash = ia_relpos_attention_flash_supported(T, dk) != 0 && !(attn_env && attn_env[0] == 'o');
@@ -137,11 +139,20 @@ extern "C" int ia_conformer_prefix_fwd_seg(const ia_block_params* layers, int n_
         IA_TRY(ia_gemm_bf16(ctx, d, L.w_out, d, N, d, d, L.b_out, 0, p, seed + 3, 1.f, x, d, x, d, nullptr, 0, stream));
         // convolution module
         IA_TRY(ia_layernorm(x, d, N, d, L.ln_conv_g, L.ln_conv_b, L.ln_eps, nullptr, 0, nullptr, nullptr, y, d, stream));
-        IA_TRY(ia_gemm_bf16(y, d, L.w_pw1, d, N, 2 * d, d, L.b_pw1, 0, 0.f, 0, 1.f, nullptr, 0, nullptr, 0, c2, 2 * d, stream));
-        if (bn_fixed)
-            IA_TRY(ia_glu_dwconv_fixed(c2, lens, B, T, d, ksz, L.dw_w, L.dw_b, z, acc + (size_t)li * IA_BN_ACC_COPIES * 2 * d, stream));
-        else
-            IA_TRY(ia_glu_dwconv(c2, lens, B, T, d, ksz, L.dw_w, L.dw_b, z, sums, sums + d, scr, stream));
+        if (bn_fixed && glu_in_gemm && L.w_pw1_glu && L.b_pw1_glu) {
+            // GLU in the epilogue of pointwise_conv1 (weight rows regrouped by the caller: value | gate halves per 128-column
+            // tile): the [N,2d] tensor is never written, the depthwise conv reads the gated [N,d] bf16 rows (half the loads,
+            // no sigmoid per window element)
+            IA_TRY(ia_gemm_bf16_ex(y, d, L.w_pw1_glu, d, N, 2 * d, d, L.b_pw1_glu, 4, 0.f, 0, 1.f, nullptr, 0, nullptr, 0, c2, d, nullptr, 0,
+                                   nullptr, 0, stream));
+            IA_TRY(ia_dwconv_gated_fixed(c2, lens, B, T, d, ksz, L.dw_w, L.dw_b, z, acc + (size_t)li * IA_BN_ACC_COPIES * 2 * d, stream));
+        } else {
+            IA_TRY(ia_gemm_bf16(y, d, L.w_pw1, d, N, 2 * d, d, L.b_pw1, 0, 0.f, 0, 1.f, nullptr, 0, nullptr, 0, c2, 2 * d, stream));
+            if (bn_fixed)
+                IA_TRY(ia_glu_dwconv_fixed(c2, lens, B, T, d, ksz, L.dw_w, L.dw_b, z, acc + (size_t)li * IA_BN_ACC_COPIES * 2 * d, stream));
+            else
+                IA_TRY(ia_glu_dwconv(c2, lens, B, T, d, ksz, L.dw_w, L.dw_b, z, sums, sums + d, scr, stream));
+        }
         }
         if (!second_half) break;
         if (bnsilu_fused) {   // BatchNorm + SiLU while the A tile of the pointwise convolution is staged: one launch, no c3 tensor

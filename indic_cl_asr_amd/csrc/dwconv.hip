@@ -33,7 +33,9 @@ __device__ __forceinline__ void load_taps(float (&wt)[KMAX], const float* __rest
     }
 }
 
-template <int KMAX, bool GLU>
+// GLU: 0 = plain fp32 input [B*T, d]; 1 = bf16 [B*T, 2d], GLU applied here; 2 = bf16 [B*T, d] already gated (modes 1 and 2:
+// frames >= lens[b] read as zero, BatchNorm sums of the output)
+template <int KMAX, int GLU>
 __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const void* __restrict__ xin, const int64_t* __restrict__ lens, int B,
                                                          int T, int d, int ksz, const float* __restrict__ w,
                                                          const float* __restrict__ bias, int flip, float* __restrict__ y,
@@ -56,10 +58,12 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const void* __restrict_
         const bool ok = t >= 0 && t < tmax;
         const int tt = t < 0 ? 0 : (t >= T ? T - 1 : t);
         float v;
-        if (GLU) {
+        if (GLU == 1) {
             const __bf16* p = reinterpret_cast<const __bf16*>(xin) + ((size_t)b * T + tt) * (2 * d);
             const float a = (float)p[cc], gate = (float)p[d + cc];
             v = a * ia_sigmoid_fast(gate);
+        } else if (GLU == 2) {
+            v = (float)reinterpret_cast<const __bf16*>(xin)[((size_t)b * T + tt) * d + cc];
         } else {
             v = reinterpret_cast<const float*>(xin)[((size_t)b * T + tt) * d + cc];
         }
@@ -205,7 +209,7 @@ extern "C" int ia_glu_dwconv(const void* x2, const int64_t* lens, int B, int T, 
     if (!dw_shape_ok(d, ksz)) return IA_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(B * ((T + DW_TB - 1) / DW_TB), (d + 63) / 64), blk(256);
-#define IA_DWF(K) hipLaunchKernelGGL((dwconv_fwd_kernel<K, true>), grid, blk, 0, st, x2, lens, B, T, d, ksz, w, bias, 0, z, scratch, (long long*)nullptr)
+#define IA_DWF(K) hipLaunchKernelGGL((dwconv_fwd_kernel<K, 1>), grid, blk, 0, st, x2, lens, B, T, d, ksz, w, bias, 0, z, scratch, (long long*)nullptr)
     switch (kmax_for(ksz)) {
         case 9: IA_DWF(9); break;
         case 15: IA_DWF(15); break;
@@ -224,7 +228,24 @@ extern "C" int ia_glu_dwconv_fixed(const void* x2, const int64_t* lens, int B, i
     if (!dw_shape_ok(d, ksz)) return IA_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(B * ((T + DW_TB - 1) / DW_TB), (d + 63) / 64), blk(256);
-#define IA_DWF(K) hipLaunchKernelGGL((dwconv_fwd_kernel<K, true>), grid, blk, 0, st, x2, lens, B, T, d, ksz, w, bias, 0, z, (float*)nullptr, bn_sums_fixed)
+#define IA_DWF(K) hipLaunchKernelGGL((dwconv_fwd_kernel<K, 1>), grid, blk, 0, st, x2, lens, B, T, d, ksz, w, bias, 0, z, (float*)nullptr, bn_sums_fixed)
+    switch (kmax_for(ksz)) {
+        case 9: IA_DWF(9); break;
+        case 15: IA_DWF(15); break;
+        default: IA_DWF(31); break;
+    }
+#undef IA_DWF
+    IA_RETURN_IF_LAUNCH_FAILED();
+    return IA_OK;
+}
+
+extern "C" int ia_dwconv_gated_fixed(const void* g, const int64_t* lens, int B, int T, int d, int ksz, const float* w,
+                                     const float* bias, float* z, long long* bn_sums_fixed, ia_stream_t stream) {
+    if (!g || !lens || !w || !bias || !z || !bn_sums_fixed || B <= 0 || T <= 0) return IA_INVALID_VALUE;
+    if (!dw_shape_ok(d, ksz)) return IA_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(B * ((T + DW_TB - 1) / DW_TB), (d + 63) / 64), blk(256);
+#define IA_DWF(K) hipLaunchKernelGGL((dwconv_fwd_kernel<K, 2>), grid, blk, 0, st, g, lens, B, T, d, ksz, w, bias, 0, z, (float*)nullptr, bn_sums_fixed)
     switch (kmax_for(ksz)) {
         case 9: IA_DWF(9); break;
         case 15: IA_DWF(15); break;
@@ -241,7 +262,7 @@ extern "C" int ia_dwconv_time(const float* x, int B, int T, int d, int ksz, cons
     if (!dw_shape_ok(d, ksz)) return IA_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(B * ((T + DW_TB - 1) / DW_TB), (d + 63) / 64), blk(256);
-#define IA_DWF(K) hipLaunchKernelGGL((dwconv_fwd_kernel<K, false>), grid, blk, 0, st, (const void*)x, (const int64_t*)nullptr, B, T, d, ksz, w, bias, flip, y, (float*)nullptr, (long long*)nullptr)
+#define IA_DWF(K) hipLaunchKernelGGL((dwconv_fwd_kernel<K, 0>), grid, blk, 0, st, (const void*)x, (const int64_t*)nullptr, B, T, d, ksz, w, bias, flip, y, (float*)nullptr, (long long*)nullptr)
     switch (kmax_for(ksz)) {
         case 9: IA_DWF(9); break;
         case 15: IA_DWF(15); break;

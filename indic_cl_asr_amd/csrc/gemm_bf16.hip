@@ -182,6 +182,30 @@ __global__ __launch_bounds__(G_THREADS, (BM == 128 ? 3 : 4)) void gemm_bf16_nt_k
                     sc[(wm * WM - pass * EP_ROWS + i * 16 + q * 4 + r) * LDC + wn * WN + j * 16 + c] = acc[i][j][r];
     }
     __syncthreads();
+    if (a.act == 4) {
+        // GLU over the tile's column halves (weight rows regrouped by the caller: columns [0,64) of a 128-column tile are value
+        // channels, [64,128) their gates): out[gm][n0/2 + c] = (v + b) * sigmoid(g + b'), bf16, N/2 columns wide.  Thread = 4
+        // channels of one row: float4 reads of both halves, one 8-byte store, every thread busy.
+        if constexpr (BN == 128) {
+            for (int it = tid; it < EP_ROWS * 16; it += G_THREADS) {
+                const int row = it >> 4, cg = it & 15;
+                const int gm = m0 + pass * EP_ROWS + row, gc = n0 + cg * 4;
+                if (gm >= a.M) continue;
+                float4 vv = *reinterpret_cast<const float4*>(sc + row * LDC + cg * 4);
+                float4 gg = *reinterpret_cast<const float4*>(sc + row * LDC + 64 + cg * 4);
+                if (a.bias) {
+                    const float4 bv = *reinterpret_cast<const float4*>(a.bias + gc), bg = *reinterpret_cast<const float4*>(a.bias + gc + 64);
+                    vv.x += bv.x; vv.y += bv.y; vv.z += bv.z; vv.w += bv.w;
+                    gg.x += bg.x; gg.y += bg.y; gg.z += bg.z; gg.w += bg.w;
+                }
+                union { uint2 u; __bf16 h[4]; } o;
+                o.h[0] = (__bf16)(vv.x * ia_sigmoid_fast(gg.x)); o.h[1] = (__bf16)(vv.y * ia_sigmoid_fast(gg.y));
+                o.h[2] = (__bf16)(vv.z * ia_sigmoid_fast(gg.z)); o.h[3] = (__bf16)(vv.w * ia_sigmoid_fast(gg.w));
+                *reinterpret_cast<uint2*>(a.outH + (size_t)gm * a.ldoh + (n0 >> 1) + cg * 4) = o.u;
+            }
+        }
+        continue;   // next epilogue pass
+    }
     for (int it = tid; it < EP_ROWS * VEC_PER_ROW; it += G_THREADS) {
         const int row = it / VEC_PER_ROW, cv = it - row * VEC_PER_ROW;
         const int gm = m0 + pass * EP_ROWS + row, gn = n0 + cv * 8;
@@ -279,7 +303,8 @@ extern "C" int ia_gemm_bf16_ex(const void* A, int lda, const void* W, int ldw, i
     if (!ia_is_aligned(A, 16) || !ia_is_aligned(W, 16) || (bias && !ia_is_aligned(bias, 16)) || (R && !ia_is_aligned(R, 16)) ||
         (outF && !ia_is_aligned(outF, 16)) || (outH && !ia_is_aligned(outH, 16)))
         return IA_INVALID_VALUE;
-    if (act < 0 || act > 3 || dropout_p < 0.f || dropout_p >= 1.f) return IA_INVALID_VALUE;
+    if (act < 0 || act > 4 || dropout_p < 0.f || dropout_p >= 1.f) return IA_INVALID_VALUE;
+    if (act == 4 && (N % 128 != 0 || !outH || outF || R || outPre || dropout_p != 0.f || alpha != 1.f || ldoh < N / 2)) return IA_INVALID_VALUE;
     GemmArgs a;
     a.A = (const __bf16*)A; a.W = (const __bf16*)W; a.bias = bias; a.R = R; a.outF = outF; a.outH = (__bf16*)outH;
     a.outPre = (__bf16*)outPre; a.aux = (const __bf16*)aux; a.ldpre = ldpre; a.ldaux = ldaux;

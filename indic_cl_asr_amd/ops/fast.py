@@ -76,6 +76,30 @@ def bf16_shadow(*params):
     return w
 
 
+def glu_regrouped(weight, bias):
+    """pointwise_conv1 weight [2d, d(,1)] / bias [2d] with the output channels regrouped for the GLU epilogue of the HIP GEMM
+    (ia_gemm_bf16_ex act 4): every 128 consecutive rows are 64 value channels followed by their 64 gate channels.  bf16 weight,
+    f32 bias; cached per parameter version like bf16_shadow.  None when d % 64 != 0."""
+    d2 = weight.shape[0]
+    d = d2 // 2
+    if d % 64 != 0:
+        return None
+    key = ("glu", id(weight), id(bias))
+    ver = (weight._version, bias._version, weight.data_ptr(), bias.data_ptr()) + \
+        ((WEIGHT_EPOCH,) if (weight.requires_grad or bias.requires_grad) else ())
+    hit = _SHADOW.get(key)
+    if hit is not None and hit[0] == ver and _same(hit[2], (weight, bias)):
+        return hit[1]
+    with torch.no_grad():
+        t = torch.arange(d // 64, device=weight.device).view(-1, 1, 1) * 64
+        j = torch.arange(64, device=weight.device).view(1, 1, -1)
+        idx = torch.cat([t + j, d + t + j], dim=1).reshape(-1)            # [2d]: per tile 64 values then 64 gates
+        w = weight.detach().reshape(d2, -1).float().index_select(0, idx).to(torch.bfloat16).contiguous()
+        b = bias.detach().float().index_select(0, idx).contiguous()
+    _SHADOW[key] = (ver, (w, b), _refs(_SHADOW, key, (weight, bias)))
+    return w, b
+
+
 def f32_cat(*params):
     key = ("f32",) + tuple(id(p) for p in params)
     ver = tuple(p._version for p in params) + tuple(p.data_ptr() for p in params) + \
@@ -597,7 +621,7 @@ def _block_params(layer):
     watch = (ff1.linear1.weight, ff1.linear2.weight, att.linear_q.weight, att.linear_k.weight, att.linear_v.weight,
              att.linear_pos.weight, att.linear_out.weight, cv.pointwise_conv1.weight, cv.pointwise_conv2.weight,
              ff2.linear1.weight, ff2.linear2.weight, att.linear_q.bias, att.linear_k.bias, att.linear_v.bias,
-             cv.depthwise_conv.weight)
+             cv.depthwise_conv.weight, cv.pointwise_conv1.bias)
     ver = tuple(p._version for p in watch) + tuple(p.data_ptr() for p in watch) + \
         ((WEIGHT_EPOCH,) if any(p.requires_grad for p in watch) else ()) + \
         (layer.dropout.p, ff1.dropout.p, ff2.dropout.p, att.dropout_rate)
@@ -619,6 +643,9 @@ def _block_params(layer):
         ln_out_b=layer.norm_out.bias, pos_u=att.pos_bias_u, pos_v=att.pos_bias_v, dw_w=cv.depthwise_conv.weight,
         dw_b=cv.depthwise_conv.bias, bn_g=bn.weight, bn_b=bn.bias, bn_rm=bn.running_mean, bn_rv=bn.running_var,
         bn_nbt=bn.num_batches_tracked)
+    glu = glu_regrouped(cv.pointwise_conv1.weight, cv.pointwise_conv1.bias)
+    if glu is not None:
+        keep["w_pw1_glu"], keep["b_pw1_glu"] = glu
     bp = _lib.BlockParams()
     for k, t in keep.items():
         setattr(bp, k, t.data_ptr())

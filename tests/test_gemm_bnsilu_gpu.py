@@ -61,3 +61,47 @@ def _run(M, d, N, training, p, seed=11):
 def test_bnsilu_gemm_matches_two_launches(M, d, N, training):
     _run(M, d, N, training, 0.0)
     _run(M, d, N, training, 0.1)
+
+
+def test_glu_epilogue_of_the_regrouped_pointwise_conv1():
+    """ia_gemm_bf16_ex act 4 on fast.glu_regrouped weights == GLU(x @ W^T + b) of the original layout."""
+    from indic_cl_asr_amd import _lib
+    from indic_cl_asr_amd.ops import fast
+    L = _lib.lib()
+    for M, d in ((1000, 256), (130, 512), (64, 64)):
+        g = torch.Generator().manual_seed(M + d)
+        x = torch.randn(M, d, generator=g).bfloat16().cuda()
+        w = torch.nn.Parameter((torch.randn(2 * d, d, 1, generator=g) * 0.1).cuda())
+        b = torch.nn.Parameter((torch.randn(2 * d, generator=g) * 0.1).cuda())
+        wg, bg = fast.glu_regrouped(w, b)
+        out = torch.empty(M, d, dtype=torch.bfloat16, device="cuda")
+        _lib.check(L.ia_gemm_bf16_ex(_lib.ptr(x), d, _lib.ptr(wg), d, M, 2 * d, d, _lib.ptr(bg), 4, 0.0, 0, 1.0, None, 0, None, 0,
+                                     _lib.ptr(out), d, None, 0, None, 0, _lib.stream_ptr()), "ia_gemm_bf16_ex")
+        ref = torch.nn.functional.glu(x.float() @ w.detach().reshape(2 * d, d).bfloat16().float().t() + b.detach(), dim=1)
+        assert torch.allclose(out.float(), ref, rtol=1e-2, atol=1e-2)
+    assert fast.glu_regrouped(torch.nn.Parameter(torch.zeros(288, 144, 1)), torch.nn.Parameter(torch.zeros(288))) is None
+
+
+def test_depthwise_conv_on_gated_rows_matches_the_glu_variant():
+    """ia_dwconv_gated_fixed(GLU(c2) rounded to bf16) against ia_glu_dwconv_fixed(c2): same masking, conv and sums up to the
+    extra bf16 rounding of the gated value."""
+    from indic_cl_asr_amd import _lib
+    L = _lib.lib()
+    B, T, d, ksz = 3, 150, 128, 31
+    g = torch.Generator().manual_seed(5)
+    c2 = torch.randn(B * T, 2 * d, generator=g).bfloat16().cuda()
+    lens = torch.tensor([150, 97, 20], dtype=torch.long).cuda()
+    w = (torch.randn(d, ksz, generator=g) * 0.2).cuda()
+    bias = (torch.randn(d, generator=g) * 0.1).cuda()
+    za, zb = torch.empty(B * T, d, device="cuda"), torch.empty(B * T, d, device="cuda")
+    acc_a = torch.zeros(8, 2 * d, dtype=torch.int64, device="cuda")
+    acc_b = torch.zeros(8, 2 * d, dtype=torch.int64, device="cuda")
+    _lib.check(L.ia_glu_dwconv_fixed(_lib.ptr(c2), _lib.ptr(lens), B, T, d, ksz, _lib.ptr(w), _lib.ptr(bias), _lib.ptr(za), _lib.ptr(acc_a),
+                                     _lib.stream_ptr()), "ia_glu_dwconv_fixed")
+    gated = torch.nn.functional.glu(c2.float(), dim=1).bfloat16().contiguous()
+    _lib.check(L.ia_dwconv_gated_fixed(_lib.ptr(gated), _lib.ptr(lens), B, T, d, ksz, _lib.ptr(w), _lib.ptr(bias), _lib.ptr(zb),
+                                       _lib.ptr(acc_b), _lib.stream_ptr()), "ia_dwconv_gated_fixed")
+    torch.cuda.synchronize()
+    assert torch.allclose(za, zb, rtol=2e-2, atol=2e-2)
+    sa, sb = acc_a.sum(0).double() / 2 ** 24, acc_b.sum(0).double() / 2 ** 24
+    assert torch.allclose(sa, sb, rtol=2e-2, atol=0.5)
