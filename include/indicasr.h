@@ -214,7 +214,10 @@ int ia_gemm_bf16(const void* A, int lda, const void* W, int ldw, int M, int N, i
                  void* outH, int ldoh, ia_stream_t stream);
 /* The same with two more epilogue features (trainable blocks): out_pre [M,N] bf16 = the bias-added value before act /
  * dropout (the activation is applied to that rounded value: one launch instead of GEMM + ia_silu_dropout); act = 3 with aux
- * [M,N] bf16: out = bf16(acc) * SiLU'(aux), then the dropout mask (GEMM + ia_silu_dropout_bwd in one launch). */
+ * [M,N] bf16: out = bf16(acc) * SiLU'(aux), then the dropout mask (GEMM + ia_silu_dropout_bwd in one launch); act = 4 (N % 128
+ * == 0, bf16 output only, no dropout / residual): GLU over the column halves of every 128-column tile, outH [M, N/2] =
+ * (acc[:, 128t+c] + b) * sigmoid(acc[:, 128t+64+c] + b'), c < 64 -- pointwise_conv1 + GLU (conformer_modules.py:340-349) with
+ * the weight rows regrouped value | gate per tile (ia_block_params.w_pw1_glu). */
 int ia_gemm_bf16_ex(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const float* bias, int act,
                     float dropout_p, unsigned seed, float alpha, const float* R, int ldr, float* outF, int ldof, void* outH,
                     int ldoh, void* out_pre, int ldpre, const void* aux, int ldaux, ia_stream_t stream);
