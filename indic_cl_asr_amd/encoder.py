@@ -22,6 +22,8 @@ def subsampled_length(n):
     return (n - 1) // 2 + 1
 
 
+SUBSAMPLED_EVENT = {}   # device index -> event recorded behind the subsampling of the most recent encoder forward
+
 class FastLinear(nn.Linear):
     """nn.Linear (same parameter names) whose forward/backward run on the HIP GEMM path inside the bf16 region."""
 
@@ -285,6 +287,9 @@ class ConformerEncoder(nn.Module):
                         length = subsampled_len
                 length = length.to(torch.int64)
                 T = x.size(1)
+                if x.is_cuda:   # lets the caller start side-stream work behind the subsampling instead of beside it (model.training_step)
+                    ev = SUBSAMPLED_EVENT[x.device.index] = torch.cuda.Event()   # (module-level: models stay deep-copyable)
+                    ev.record(torch.cuda.current_stream(x.device))
                 x, pos_emb = self.pos_enc(x)
                 pad_mask = torch.arange(T, device=x.device)[None, :] >= length[:, None]
             lth = 0

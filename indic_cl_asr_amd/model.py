@@ -9,6 +9,8 @@ What is deliberately NOT reproduced from the reference step: 6
 from dataclasses import dataclass, field
 from typing import List, Optional
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -260,7 +262,13 @@ class EncDecHybridRNNTCTCModel(TranscriptionMixin, nn.Module):
         self._host_signal_len = h_sig   # lets forward() draw the SpecAugment spans on the host
         encoded, encoded_len = self.forward(input_signal=signal, input_signal_length=signal_len)
         if side is not None:
-            side.wait_event(inputs_ready)
+            # ... and it starts BEHIND the front end and the subsampling, not beside them: those are chip-filling kernels
+            # (0.5 GB write, a 284 GFLOP implicit GEMM) that lose a sixth of their speed to the 40 CUs of the persistent LSTM;
+            # under the blocks' latency-bound launches the CUs are cheaper (3 x 150 steps, one box: 10.31 -> 10.26 ms;
+            # IA_DELAY_DECODER=0 restores the start at step begin)
+            from .encoder import SUBSAMPLED_EVENT
+            ev_sub = SUBSAMPLED_EVENT.get(signal.device.index)
+            side.wait_event(ev_sub if (ev_sub is not None and os.environ.get("IA_DELAY_DECODER", "1") != "0") else inputs_ready)
             from . import cl
             if cl.LAST_UPDATE_EVENT is not None:   # a deferred optimizer update was applied on the main stream inside forward
                 side.wait_event(cl.LAST_UPDATE_EVENT)
