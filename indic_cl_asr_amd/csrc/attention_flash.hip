@@ -136,6 +136,7 @@ __global__ __launch_bounds__(FA_THREADS, 3) void relpos_flash_fwd_kernel(FaArgs 
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) O[mt] = (f4){0.f, 0.f, 0.f, 0.f};
     float m_run = IA_NEG_INF, l_run = 0.f;      // running maximum of this lane's query, this lane's share of the sum
+    const float scale2 = a.scale * 1.44269504088896341f;
 
     for (int t = 0; t < nkt; ++t) {
         const unsigned char* sK = smem;
@@ -174,23 +175,39 @@ __global__ __launch_bounds__(FA_THREADS, 3) void relpos_flash_fwd_kernel(FaArgs 
             }
         }
         // ---- scores: lane (query c, q4), key j = j0 + 16 jt + 4 q4 + r; band element at strip column 16 jt + 4 q4 + r + 16
+        // scores in base-2 units (scale * log2 e folded into one multiply, exp2 directly: no multiply per exponential); the
+        // length mask only exists in the tile that straddles the length (uniform branch)
         float tmax = IA_NEG_INF;
+        if (j0 + FA_KT <= len) {
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt) {
-            union { uint2 u; __bf16 e[4]; } bd;
-            bd.u = *reinterpret_cast<const uint2*>(sR + (c * FA_SR_LD + jt * 16 + q4 * 4 + 16) * 2);
+            for (int jt = 0; jt < 4; ++jt) {
+                union { uint2 u; __bf16 e[4]; } bd;
+                bd.u = *reinterpret_cast<const uint2*>(sR + (c * FA_SR_LD + jt * 16 + q4 * 4 + 16) * 2);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int j = j0 + jt * 16 + q4 * 4 + r;
-                const float s = (j < len) ? (S[jt][r] + (float)bd.e[r]) * a.scale : IA_NEG_INF;
-                S[jt][r] = s;
-                tmax = fmaxf(tmax, s);
+                for (int r = 0; r < 4; ++r) {
+                    const float s = (S[jt][r] + (float)bd.e[r]) * scale2;
+                    S[jt][r] = s;
+                    tmax = fmaxf(tmax, s);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) {
+                union { uint2 u; __bf16 e[4]; } bd;
+                bd.u = *reinterpret_cast<const uint2*>(sR + (c * FA_SR_LD + jt * 16 + q4 * 4 + 16) * 2);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = j0 + jt * 16 + q4 * 4 + r;
+                    const float s = (j < len) ? (S[jt][r] + (float)bd.e[r]) * scale2 : IA_NEG_INF;
+                    S[jt][r] = s;
+                    tmax = fmaxf(tmax, s);
+                }
             }
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float m_new = fmaxf(m_run, tmax);           // finite: key j0 < len exists in every processed tile
-        const float alpha = __expf(m_run - m_new);        // exp(-inf) = 0 on the first tile
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // exp2(-inf) = 0 on the first tile
         m_run = m_new;
         float psum = 0.f;
         bf8 Pf[2];
@@ -200,9 +217,10 @@ __global__ __launch_bounds__(FA_THREADS, 3) void relpos_flash_fwd_kernel(FaArgs 
             if (a.thr > 0) rnd4 = fa_keep_rand4(a.seed, bh, T, iq, (j0 + jt * 16 + q4 * 4) >> 2);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float p = __expf(S[jt][r] - m_new);       // exp(-inf) = 0 for excluded keys
+                float p = __builtin_amdgcn_exp2f(S[jt][r] - m_new);   // exp2(-inf) = 0 for excluded keys
                 psum += p;
-                if (a.thr > 0) p = (((rnd4 >> (8 * r)) & 0xFFu) >= a.thr) ? p * a.keep_scale : 0.f;
+                // (the keep scale 1/(1-p) of the dropout is applied once, to the normalised output)
+                if (a.thr > 0) p = (((rnd4 >> (8 * r)) & 0xFFu) >= a.thr) ? p : 0.f;
                 Pf[jt >> 1][(jt & 1) * 4 + r] = (__bf16)p;
             }
         }
@@ -241,8 +259,9 @@ __global__ __launch_bounds__(FA_THREADS, 3) void relpos_flash_fwd_kernel(FaArgs 
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);
     if (iq < T) {
-        if (a.lse && q4 == 0) a.lse[(size_t)bh * T + iq] = (iq < len && l_run > 0.f) ? m_run + __logf(l_run) : 0.f;
-        const float inv = (iq < len && l_run > 0.f) ? 1.f / l_run : 0.f;
+        // natural-log LSE for the backward: (m + log2 l) ln 2
+        if (a.lse && q4 == 0) a.lse[(size_t)bh * T + iq] = (iq < len && l_run > 0.f) ? (m_run + __builtin_amdgcn_logf(l_run)) * 0.69314718055994531f : 0.f;
+        const float inv = (iq < len && l_run > 0.f) ? a.keep_scale / l_run : 0.f;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             if (mt * 16 + q4 * 4 < dk) {
