@@ -280,6 +280,13 @@ int ia_dwconv_time(const float* x, int B, int T, int d, int ksz, const float* w,
                    ia_stream_t stream);
 int ia_dwconv_time_wgrad(const float* x, const float* dy, int B, int T, int d, int ksz, float* dw, float* db,
                          float* scratch, ia_stream_t stream);
+/* Backward of GLU -> depthwise conv in two launches (trainable blocks): ia_dwconv_glu_bwd = ia_dwconv_time(dz, flip 1) followed
+ * by ia_glu_bwd, without the dG tensor (dc2 [B*T, 2d] bf16); ia_dwconv_glu_wgrad = ia_dwconv_time_wgrad on mask(GLU(c2)),
+ * regenerated in the window loads instead of read from ia_glu_mask's output.  Same results as the four-launch sequence. */
+int ia_dwconv_glu_bwd(const float* dz, const void* c2, const int64_t* lens, int B, int T, int d, int ksz, const float* w, void* dc2,
+                      ia_stream_t stream);
+int ia_dwconv_glu_wgrad(const void* c2, const int64_t* lens, const float* dy, int B, int T, int d, int ksz, float* dw, float* db,
+                        float* scratch, ia_stream_t stream);
 int ia_bn_silu(const float* z, int64_t n_rows, int d, const float* bn_sum, const float* bn_sumsq, const float* gamma,
                const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                float momentum, float eps, int training, void* out, ia_stream_t stream);

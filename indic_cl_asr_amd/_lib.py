@@ -105,6 +105,8 @@ SIGNATURES = {
     "ia_colsum_bf16": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "ia_dwconv_time": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "ia_dwconv_time_wgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "ia_dwconv_glu_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "ia_dwconv_glu_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ia_bn_silu": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp]),
     "ia_gemm_bnsilu_supported": (_i, [_i]),
     "ia_gemm_bnsilu_bf16": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _i, _i, _i, _i, _vp, _f, _c.c_uint, _f,

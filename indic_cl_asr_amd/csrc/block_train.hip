@@ -290,8 +290,7 @@ extern "C" int ia_conformer_block_bwd_a_phase(const ia_block_params* Lp, const i
     const BwdWs w = bwd_ws(B, T, d, d_ff, ksz);
     if (workspace_bytes < w.total) return IA_WORKSPACE_TOO_SMALL;
     char* ws = (char*)workspace;
-    float *dxa = (float*)(ws + w.dxa), *dxb = (float*)(ws + w.dxb), *dz = (float*)(ws + w.dz), *dG = (float*)(ws + w.dG),
-          *Gm = (float*)(ws + w.Gm), *scr = (float*)(ws + w.scr);
+    float *dxa = (float*)(ws + w.dxa), *dxb = (float*)(ws + w.dxb), *dz = (float*)(ws + w.dz), *scr = (float*)(ws + w.scr);
     void *dB = ws + w.dB, *dB1 = ws + w.dB1, *dB2 = ws + w.dB2, *dhp = ws + w.dhp, *dy = ws + w.dy, *dc3 = ws + w.dc3, *dc2 = ws + w.dc2,
          *dctx = ws + w.dctx, *wt = ws + w.wt;
     const float p = L.p_drop, pff = L.p_ff;
@@ -334,10 +333,10 @@ extern "C" int ia_conformer_block_bwd_a_phase(const ia_block_params* Lp, const i
     }
     if (phase == 2)
         IA_TRY(ia_bn_silu_bwd_apply(S.z, dc3, N, d, S.sums, S.sums + d, L.bn_g, L.bn_b, L.bn_eps, bn_S12, bn_S12 + d, dz, stream));
-    IA_TRY(ia_dwconv_time(dz, B, T, d, ksz, L.dw_w, nullptr, 1, dG, stream));
-    IA_TRY(ia_glu_mask(S.c2, lens, B, T, d, Gm, stream));
-    IA_TRY(ia_dwconv_time_wgrad(Gm, dz, B, T, d, ksz, G.dw_w, G.dw_b, scr, stream));
-    IA_TRY(ia_glu_bwd(S.c2, dG, lens, B, T, d, dc2, stream));
+    // GLU -> depthwise conv backward: data gradient straight through the GLU backward, weight gradient on the regenerated
+    // mask(GLU(c2)) -- two launches (+ the finishing sum) instead of four, no dG / G tensors
+    IA_TRY(ia_dwconv_glu_bwd(dz, S.c2, lens, B, T, d, ksz, L.dw_w, dc2, stream));
+    IA_TRY(ia_dwconv_glu_wgrad(S.c2, lens, dz, B, T, d, ksz, G.dw_w, G.dw_b, scr, stream));
     IA_TRY(linear_bwd_deferred(dc2, S.y3, L.w_pw1, N, 2 * d, d, dy, G.w_pw1, G.b_pw1, wt_pw1, grp, &ngrp, stream));
     IA_TRY(ia_layernorm_bwd_drop(S.x2, d, nullptr, dy, d, N, d, L.ln_conv_g, L.ln_eps, dxb, dxa, d, G.ln_conv_g, G.ln_conv_b, 1.f, p,
                                  seed + 3, dB2, d, scr, stream));  // d x2 -> dxa

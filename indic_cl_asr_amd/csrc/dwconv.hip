@@ -35,12 +35,14 @@ __device__ __forceinline__ void load_taps(float (&wt)[KMAX], const float* __rest
 }
 
 // GLU: 0 = plain fp32 input [B*T, d]; 1 = bf16 [B*T, 2d], GLU applied here; 2 = bf16 [B*T, d] already gated (modes 1 and 2:
-// frames >= lens[b] read as zero, BatchNorm sums of the output)
+// frames >= lens[b] read as zero, BatchNorm sums of the output); 3 = plain fp32 input, the result dG goes straight through the
+// backward of the GLU in front of the convolution (c2 [B*T, 2d] bf16, frames >= lens[b] get zero): dc2 [B*T, 2d] bf16
 template <int KMAX, int GLU>
 __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const void* __restrict__ xin, const int64_t* __restrict__ lens, int B,
                                                          int T, int d, int ksz, const float* __restrict__ w,
                                                          const float* __restrict__ bias, int flip, float* __restrict__ y,
-                                                         float* __restrict__ part, long long* __restrict__ acc) {
+                                                         float* __restrict__ part, long long* __restrict__ acc,
+                                                         const __bf16* __restrict__ c2 = nullptr, __bf16* __restrict__ dc2 = nullptr) {
     constexpr int HM = (KMAX - 1) / 2, WIN = DW_TT + KMAX - 1;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int ntb = (T + DW_TB - 1) / DW_TB;
@@ -49,7 +51,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const void* __restrict_
     const bool cok = c < d;
     const int cc = cok ? c : d - 1;
     int tmax = T;
-    if (GLU) { const int len = (int)lens[b]; tmax = len < T ? len : T; }  // frames >= len are zeroed AFTER the GLU (:351)
+    if (GLU == 1 || GLU == 2) { const int len = (int)lens[b]; tmax = len < T ? len : T; }  // frames >= len are zeroed AFTER the GLU (:351)
     float wt[KMAX];
     load_taps<KMAX>(wt, w, cc, ksz, flip);
     float win[WIN];
@@ -79,11 +81,20 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const void* __restrict_
         for (int jj = 0; jj < KMAX; ++jj) acc += wt[jj] * win[i + jj];
         const int t = t0 + i;
         if (t < T && cok) {
-            y[((size_t)b * T + t) * d + c] = acc;
-            s += acc; s2 += acc * acc;
+            if (GLU == 3) {   // ia_glu_bwd of acc (= dG[t][c]) without the dG tensor
+                const size_t row = (size_t)b * T + t;
+                const float av = (float)c2[row * 2 * d + c], gv = (float)c2[row * 2 * d + d + c];
+                const float sg = ia_sigmoid_fast(gv);
+                const float dg = (t < (int)lens[b]) ? acc : 0.f;
+                dc2[row * 2 * d + c] = (__bf16)(dg * sg);
+                dc2[row * 2 * d + d + c] = (__bf16)(dg * av * sg * (1.f - sg));
+            } else {
+                y[((size_t)b * T + t) * d + c] = acc;
+                s += acc; s2 += acc * acc;
+            }
         }
     }
-    if (GLU) {
+    if (GLU == 1 || GLU == 2) {
         __shared__ float red[4][2][64];
         red[wv][0][lane] = s; red[wv][1][lane] = s2;
         __syncthreads();
@@ -108,9 +119,12 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const void* __restrict_
 
 // dw[c][j] = sum_{b,t} dy[b,t,c] x[b,t+j-half,c]; db[c] = sum dy.  Workgroup = (b, time split, 64 channels), its 4 waves
 // stride over the split's 8-frame chunks; block partial row = [(KMAX+1)][d].
-template <int KMAX>
+// XGLU: x = mask(GLU(c2)) regenerated from c2 [B*T, 2d] bf16 and lens (what ia_glu_mask would have written)
+template <int KMAX, bool XGLU>
 __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, int B,
-                                                           int T, int d, int nsplit, float* __restrict__ part) {
+                                                           int T, int d, int nsplit, float* __restrict__ part,
+                                                           const __bf16* __restrict__ c2 = nullptr,
+                                                           const int64_t* __restrict__ lens = nullptr) {
     constexpr int HM = (KMAX - 1) / 2, WIN = DW_TT + KMAX - 1;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int b = blockIdx.x / nsplit, sp = blockIdx.x - b * nsplit;
@@ -123,6 +137,8 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const float* __restri
 #pragma unroll
     for (int jj = 0; jj < KMAX; ++jj) acc[jj] = 0.f;
     float sb = 0.f;
+    int tlen = T;
+    if constexpr (XGLU) { const int len = (int)lens[b]; tlen = len < T ? len : T; }
     for (int t0 = ts + wv * DW_TT; t0 < te; t0 += 4 * DW_TT) {
         float g[DW_TT], win[WIN];
 #pragma unroll
@@ -135,8 +151,14 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const float* __restri
         for (int r = 0; r < WIN; ++r) {
             const int t = t0 - HM + r;
             const int tt = t < 0 ? 0 : (t >= T ? T - 1 : t);
-            const float v = x[((size_t)b * T + tt) * d + cc];
-            win[r] = (t >= 0 && t < T) ? v : 0.f;
+            if constexpr (XGLU) {
+                const size_t row = (size_t)b * T + tt;
+                const float av = (float)c2[row * 2 * d + cc], gv = (float)c2[row * 2 * d + d + cc];
+                win[r] = (t >= 0 && t < tlen) ? av * ia_sigmoid_fast(gv) : 0.f;
+            } else {
+                const float v = x[((size_t)b * T + tt) * d + cc];
+                win[r] = (t >= 0 && t < T) ? v : 0.f;
+            }
         }
 #pragma unroll
         for (int i = 0; i < DW_TT; ++i) {
@@ -283,7 +305,48 @@ extern "C" int ia_dwconv_time_wgrad(const float* x, const float* dy, int B, int 
     hipStream_t st = (hipStream_t)stream;
     const int ns = wgrad_splits(B, T, d), kmax = kmax_for(ksz);
     const dim3 grid(B * ns, (d + 63) / 64), blk(256);
-#define IA_DWG(K) hipLaunchKernelGGL((dwconv_wgrad_kernel<K>), grid, blk, 0, st, x, dy, B, T, d, ns, scratch)
+#define IA_DWG(K) hipLaunchKernelGGL((dwconv_wgrad_kernel<K, false>), grid, blk, 0, st, x, dy, B, T, d, ns, scratch, (const __bf16*)nullptr, (const int64_t*)nullptr)
+    switch (kmax) {
+        case 9: IA_DWG(9); break;
+        case 15: IA_DWG(15); break;
+        default: IA_DWG(31); break;
+    }
+#undef IA_DWG
+    IA_RETURN_IF_LAUNCH_FAILED();
+    hipLaunchKernelGGL(dwconv_wgrad_finish_kernel, dim3(((kmax + 1) * d + 255) / 256), dim3(256), 0, st, scratch, (int)grid.x, d,
+                       kmax, ksz, dw, db);
+    IA_RETURN_IF_LAUNCH_FAILED();
+    return IA_OK;
+}
+
+// Backward of GLU -> depthwise conv in two launches instead of four (ia_dwconv_time flip 1, ia_glu_mask, ia_dwconv_time_wgrad,
+// ia_glu_bwd): the data gradient goes through the GLU backward in the conv kernel's epilogue (no dG tensor), the weight
+// gradient regenerates mask(GLU(c2)) in its window loads (no G tensor).  Same arithmetic, same summation order.
+extern "C" int ia_dwconv_glu_bwd(const float* dz, const void* c2, const int64_t* lens, int B, int T, int d, int ksz, const float* w,
+                                 void* dc2, ia_stream_t stream) {
+    if (!dz || !c2 || !lens || !w || !dc2 || B <= 0 || T <= 0) return IA_INVALID_VALUE;
+    if (!dw_shape_ok(d, ksz)) return IA_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(B * ((T + DW_TB - 1) / DW_TB), (d + 63) / 64), blk(256);
+#define IA_DWF(K) hipLaunchKernelGGL((dwconv_fwd_kernel<K, 3>), grid, blk, 0, st, (const void*)dz, lens, B, T, d, ksz, w, (const float*)nullptr, 1, (float*)nullptr, (float*)nullptr, (long long*)nullptr, (const __bf16*)c2, (__bf16*)dc2)
+    switch (kmax_for(ksz)) {
+        case 9: IA_DWF(9); break;
+        case 15: IA_DWF(15); break;
+        default: IA_DWF(31); break;
+    }
+#undef IA_DWF
+    IA_RETURN_IF_LAUNCH_FAILED();
+    return IA_OK;
+}
+
+extern "C" int ia_dwconv_glu_wgrad(const void* c2, const int64_t* lens, const float* dy, int B, int T, int d, int ksz, float* dw,
+                                   float* db, float* scratch, ia_stream_t stream) {
+    if (!c2 || !lens || !dy || !dw || !scratch || B <= 0 || T <= 0) return IA_INVALID_VALUE;
+    if (!dw_shape_ok(d, ksz)) return IA_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int ns = wgrad_splits(B, T, d), kmax = kmax_for(ksz);
+    const dim3 grid(B * ns, (d + 63) / 64), blk(256);
+#define IA_DWG(K) hipLaunchKernelGGL((dwconv_wgrad_kernel<K, true>), grid, blk, 0, st, (const float*)nullptr, dy, B, T, d, ns, scratch, (const __bf16*)c2, lens)
     switch (kmax) {
         case 9: IA_DWG(9); break;
         case 15: IA_DWG(15); break;

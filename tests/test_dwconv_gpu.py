@@ -85,3 +85,33 @@ def test_glu_dwconv_fixed_point_sums_match_the_partial_row_sums():
         assert torch.equal(za, zb)
         got = acc.sum(0).double() / 2 ** 24
         assert torch.allclose(got, sums.double(), rtol=1e-5, atol=1e-4)
+
+
+def test_glu_dwconv_backward_in_two_launches_matches_the_four_launch_sequence():
+    """ia_dwconv_glu_bwd / ia_dwconv_glu_wgrad == ia_dwconv_time(flip) + ia_glu_bwd / ia_glu_mask + ia_dwconv_time_wgrad."""
+    from indic_cl_asr_amd import _lib
+    L = _lib.lib()
+    for B, T, d, ksz in ((3, 150, 128, 31), (2, 70, 144, 9)):
+        g = torch.Generator().manual_seed(B + T)
+        c2 = torch.randn(B * T, 2 * d, generator=g).bfloat16().cuda()
+        dz = torch.randn(B * T, d, generator=g).cuda()
+        lens = torch.tensor([T, max(1, T - 40), 7][:B], dtype=torch.long).cuda()
+        w = (torch.randn(d, ksz, generator=g) * 0.2).cuda()
+        scr = torch.empty(L.ia_dwconv_scratch_elems(B, T, d, ksz), device="cuda")
+        dG, Gm = torch.empty(B * T, d, device="cuda"), torch.empty(B * T, d, device="cuda")
+        dc2a, dc2b = (torch.empty(B * T, 2 * d, dtype=torch.bfloat16, device="cuda") for _ in range(2))
+        dwa, dba, dwb, dbb = (torch.empty(*s, device="cuda") for s in ((d, ksz), (d,), (d, ksz), (d,)))
+        _lib.check(L.ia_dwconv_time(_lib.ptr(dz), B, T, d, ksz, _lib.ptr(w), None, 1, _lib.ptr(dG), _lib.stream_ptr()), "dwconv_time")
+        _lib.check(L.ia_glu_mask(_lib.ptr(c2), _lib.ptr(lens), B, T, d, _lib.ptr(Gm), _lib.stream_ptr()), "glu_mask")
+        _lib.check(L.ia_dwconv_time_wgrad(_lib.ptr(Gm), _lib.ptr(dz), B, T, d, ksz, _lib.ptr(dwa), _lib.ptr(dba), _lib.ptr(scr),
+                                          _lib.stream_ptr()), "wgrad")
+        _lib.check(L.ia_glu_bwd(_lib.ptr(c2), _lib.ptr(dG), _lib.ptr(lens), B, T, d, _lib.ptr(dc2a), _lib.stream_ptr()), "glu_bwd")
+        _lib.check(L.ia_dwconv_glu_bwd(_lib.ptr(dz), _lib.ptr(c2), _lib.ptr(lens), B, T, d, ksz, _lib.ptr(w), _lib.ptr(dc2b),
+                                       _lib.stream_ptr()), "ia_dwconv_glu_bwd")
+        _lib.check(L.ia_dwconv_glu_wgrad(_lib.ptr(c2), _lib.ptr(lens), _lib.ptr(dz), B, T, d, ksz, _lib.ptr(dwb), _lib.ptr(dbb),
+                                         _lib.ptr(scr), _lib.stream_ptr()), "ia_dwconv_glu_wgrad")
+        torch.cuda.synchronize()
+        # (same arithmetic, but the compiler's fma contraction differs between the kernels: at most one bf16 ulp)
+        assert torch.allclose(dc2a.float(), dc2b.float(), rtol=8e-3, atol=1e-6)
+        # (the regenerated window element of the last tap is contracted differently by the compiler: 1 ulp in that tap's sums)
+        assert torch.allclose(dwa, dwb, rtol=1e-6, atol=1e-5) and torch.equal(dba, dbb)
