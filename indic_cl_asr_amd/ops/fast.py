@@ -643,7 +643,10 @@ def _block_params(layer):
         ln_out_b=layer.norm_out.bias, pos_u=att.pos_bias_u, pos_v=att.pos_bias_v, dw_w=cv.depthwise_conv.weight,
         dw_b=cv.depthwise_conv.bias, bn_g=bn.weight, bn_b=bn.bias, bn_rm=bn.running_mean, bn_rv=bn.running_var,
         bn_nbt=bn.num_batches_tracked)
-    glu = glu_regrouped(cv.pointwise_conv1.weight, cv.pointwise_conv1.bias)
+    # (frozen weights only: the regrouped image costs half a dozen small launches to rebuild, and the trainable blocks' own
+    #  executor keeps the pre-GLU tensor for its backward anyway)
+    frozen_pw1 = not (cv.pointwise_conv1.weight.requires_grad or cv.pointwise_conv1.bias.requires_grad)
+    glu = glu_regrouped(cv.pointwise_conv1.weight, cv.pointwise_conv1.bias) if frozen_pw1 else None
     if glu is not None:
         keep["w_pw1_glu"], keep["b_pw1_glu"] = glu
     bp = _lib.BlockParams()
