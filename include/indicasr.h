@@ -610,6 +610,13 @@ int ia_layernorm_bwd_drop(const float* x, int ldx, const float* dy_f32, const vo
                           const float* gamma, float eps, const float* dx_in, float* dx_out, int lddx, float* dgamma,
                           float* dbeta, float alpha, float dropout_p, unsigned seed, void* dx_bf16, int lddxh, float* scratch,
                           ia_stream_t stream);
+/* Deferred column sums: ia_layernorm_bwd(_drop) with dgamma = dbeta = NULL leaves its ia_layernorm_bwd_partial_rows(N) partial
+ * rows [rows][2d] (d gamma | d beta) in `scratch`; ia_partials_finish_multi adds up to eight such sets in ONE launch:
+ * out0[c] = sum_g part[g*C + c] for c < C0, out1[c - C0] for the rest (a trainable block's five LayerNorm gradients: one
+ * finishing launch instead of five). */
+typedef struct ia_finish_job { const float* part; int G, C, C0; float* out0; float* out1; } ia_finish_job;
+int ia_layernorm_bwd_partial_rows(int N);
+int ia_partials_finish_multi(const ia_finish_job* jobs, int count, ia_stream_t stream);
 int64_t ia_layernorm_bwd_scratch_elems(int N, int d);
 int ia_silu_dropout(const void* h_pre, int64_t M, int N, float dropout_p, unsigned seed, void* out, ia_stream_t stream);
 int ia_silu_dropout_bwd(const void* h_pre, const void* dh, int64_t M, int N, float dropout_p, unsigned seed, void* out,

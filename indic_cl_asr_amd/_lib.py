@@ -154,6 +154,8 @@ SIGNATURES = {
     "ia_conformer_block_bwd_b": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _c.c_uint, _vp, _sz, _vp, _vp, _i, _vp]),
     "ia_layernorm_bwd": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _f, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "ia_layernorm_bwd_drop": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _f, _vp, _vp, _i, _vp, _vp, _f, _f, _c.c_uint, _vp, _i, _vp, _vp]),
+    "ia_layernorm_bwd_partial_rows": (_i, [_i]),
+    "ia_partials_finish_multi": (_i, [_vp, _i, _vp]),
     "ia_layernorm_bwd_scratch_elems": (_i64, [_i, _i]),
     "ia_silu_dropout": (_i, [_vp, _i64, _i, _f, _c.c_uint, _vp, _vp]),
     "ia_silu_dropout_bwd": (_i, [_vp, _vp, _i64, _i, _f, _c.c_uint, _vp, _vp]),

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void multi_add_kernel(const AddRow* __restrict
 }
 
 struct BwdWs {   // workspace of the two backward calls (offsets in bytes)
-    size_t dxa, dxb, dB, dB1, dB2, dh, dhp, dy, dc3, dz, dG, Gm, dc2, dctx, wt, scr, total;
+    size_t dxa, dxb, dB, dB1, dB2, dh, dhp, dy, dc3, dz, dG, dc2, dctx, wt, scr, total;
 };
 
 size_t max3(size_t a, size_t b, size_t c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
@@ -140,8 +140,8 @@ BwdWs bwd_ws(int B, int T, int d, int d_ff, int ksz) {
     w.dy = o;   o = up256(o + N * d * 2);
     w.dc3 = o;  o = up256(o + N * d * 2);
     w.dz = o;   o = up256(o + N * d * 4);
-    w.dG = o;   o = up256(o + N * d * 4);
-    w.Gm = o;   o = up256(o + N * d * 4);
+    w.dG = o;   o = up256(o + (size_t)5 * (size_t)ia_layernorm_bwd_scratch_elems((int)N, d) * 4);   // the five LayerNorm backward
+                                                        // partial-row sets of a block (summed in one launch at the end)
     w.dc2 = o;  o = up256(o + N * 2 * d * 2);
     w.dctx = o; o = up256(o + N * d * 2);
     w.wt = o;   o = up256(o + ((size_t)4 * d_ff * d + (size_t)7 * d * d) * 2);              // the block's eight transposed weight images
@@ -291,6 +291,9 @@ extern "C" int ia_conformer_block_bwd_a_phase(const ia_block_params* Lp, const i
     if (workspace_bytes < w.total) return IA_WORKSPACE_TOO_SMALL;
     char* ws = (char*)workspace;
     float *dxa = (float*)(ws + w.dxa), *dxb = (float*)(ws + w.dxb), *dz = (float*)(ws + w.dz), *scr = (float*)(ws + w.scr);
+    // LayerNorm gradient partial rows: five sets per block, summed by ONE launch at the end of the second backward call
+    float* lnp = (float*)(ws + w.dG);
+    const size_t lnp_set = (size_t)ia_layernorm_bwd_scratch_elems(N, d);
     void *dB = ws + w.dB, *dB1 = ws + w.dB1, *dB2 = ws + w.dB2, *dhp = ws + w.dhp, *dy = ws + w.dy, *dc3 = ws + w.dc3, *dc2 = ws + w.dc2,
          *dctx = ws + w.dctx, *wt = ws + w.wt;
     const float p = L.p_drop, pff = L.p_ff;
@@ -310,16 +313,16 @@ extern "C" int ia_conformer_block_bwd_a_phase(const ia_block_params* Lp, const i
     // norm_out: d x4 -> dxa
     // (each LayerNorm backward below also emits the dropout-scaled bf16 copy of its result: the gradient entering the residual
     //  branch in front of it, operand of that branch's data- and weight-gradient GEMMs -- no separate elementwise launch)
-    IA_TRY(ia_layernorm_bwd_drop(S.x4, d, dout, nullptr, d, N, d, L.ln_out_g, L.ln_eps, nullptr, dxa, d, G.ln_out_g, G.ln_out_b,
-                                 L.fc_factor, p, seed + 6, dB, d, scr, stream));
+    IA_TRY(ia_layernorm_bwd_drop(S.x4, d, dout, nullptr, d, N, d, L.ln_out_g, L.ln_eps, nullptr, dxa, d, nullptr, nullptr,
+                                 L.fc_factor, p, seed + 6, dB, d, lnp + 0 * lnp_set, stream));
     // feed_forward2
     // d h4p = dropout'(SiLU'(h4p)) o (dB W_ff2b) in the data-gradient GEMM's epilogue (act 3 against the saved pre-activation)
     IA_TRY(ia_gemm_bf16_ex(dB, d, wt_ff2b, d, N, d_ff, d, nullptr, 3, pff, seed + 5, 1.f, nullptr, 0, nullptr, 0, dhp, d_ff, nullptr, 0,
                            S.h4p, d_ff, stream));
     IA_TRY(linear_bwd_deferred(dB, S.h4, L.w_ff2b, N, d, d_ff, nullptr, G.w_ff2b, G.b_ff2b, wt_ff2b, grp, &ngrp, stream));
     IA_TRY(linear_bwd_deferred(dhp, S.y4, L.w_ff2a, N, d_ff, d, dy, G.w_ff2a, G.b_ff2a, wt_ff2a, grp, &ngrp, stream));
-    IA_TRY(ia_layernorm_bwd_drop(S.x3, d, nullptr, dy, d, N, d, L.ln_ff2_g, L.ln_eps, dxa, dxb, d, G.ln_ff2_g, G.ln_ff2_b, 1.f, p,
-                                 seed + 4, dB1, d, scr, stream));   // d x3 -> dxb
+    IA_TRY(ia_layernorm_bwd_drop(S.x3, d, nullptr, dy, d, N, d, L.ln_ff2_g, L.ln_eps, dxa, dxb, d, nullptr, nullptr, 1.f, p,
+                                 seed + 4, dB1, d, lnp + 1 * lnp_set, stream));   // d x3 -> dxb
     // convolution module
     IA_TRY(linear_bwd_deferred(dB1, S.c3, L.w_pw2, N, d, d, dc3, G.w_pw2, G.b_pw2, wt_pw2, grp, &ngrp, stream));
     if (phase == 0)
@@ -338,8 +341,8 @@ extern "C" int ia_conformer_block_bwd_a_phase(const ia_block_params* Lp, const i
     IA_TRY(ia_dwconv_glu_bwd(dz, S.c2, lens, B, T, d, ksz, L.dw_w, dc2, stream));
     IA_TRY(ia_dwconv_glu_wgrad(S.c2, lens, dz, B, T, d, ksz, G.dw_w, G.dw_b, scr, stream));
     IA_TRY(linear_bwd_deferred(dc2, S.y3, L.w_pw1, N, 2 * d, d, dy, G.w_pw1, G.b_pw1, wt_pw1, grp, &ngrp, stream));
-    IA_TRY(ia_layernorm_bwd_drop(S.x2, d, nullptr, dy, d, N, d, L.ln_conv_g, L.ln_eps, dxb, dxa, d, G.ln_conv_g, G.ln_conv_b, 1.f, p,
-                                 seed + 3, dB2, d, scr, stream));  // d x2 -> dxa
+    IA_TRY(ia_layernorm_bwd_drop(S.x2, d, nullptr, dy, d, N, d, L.ln_conv_g, L.ln_eps, dxb, dxa, d, nullptr, nullptr, 1.f, p,
+                                 seed + 3, dB2, d, lnp + 2 * lnp_set, stream));  // d x2 -> dxa
     // linear_out
     IA_TRY(linear_bwd_deferred(dB2, S.ctxv, L.w_out, N, d, d, dctx, G.w_out, G.b_out, wt_out, grp, &ngrp, stream));
     // the five weight (+ bias) gradients of this half in one GEMM launch + one finishing launch
@@ -366,6 +369,8 @@ extern "C" int ia_conformer_block_bwd_b(const ia_block_params* Lp, const ia_bloc
     if (workspace_bytes < w.total) return IA_WORKSPACE_TOO_SMALL;
     char* ws = (char*)workspace;
     float *dxa = (float*)(ws + w.dxa), *dxb = (float*)(ws + w.dxb), *scr = (float*)(ws + w.scr);
+    float* lnp = (float*)(ws + w.dG);   // (sets 0..2 were written by the first backward call)
+    const size_t lnp_set = (size_t)ia_layernorm_bwd_scratch_elems(N, d);
     void *dB = ws + w.dB, *dhp = ws + w.dhp, *dy = ws + w.dy, *wt = ws + w.wt;
     const float p = L.p_drop, pff = L.p_ff;
     ia_tn_problem grp[8];
@@ -381,15 +386,24 @@ extern "C" int ia_conformer_block_bwd_b(const ia_block_params* Lp, const ia_bloc
     // q|k|v projection (dW rows q, k, v contiguous; bias likewise) and the bias-free position projection
     IA_TRY(linear_bwd_deferred(dqkv, S.y2, L.w_qkv, N, 3 * d, d, dy, G.w_qkv, G.b_qkv, wt_qkv, grp, &ngrp, stream));
     grp[ngrp++] = ia_tn_problem{dpl, pos_emb, G.w_pos, nullptr, d, d, pos_rows, d, d};
-    IA_TRY(ia_layernorm_bwd_drop(S.x1, d, nullptr, dy, d, N, d, L.ln_att_g, L.ln_eps, dxa, dxb, d, G.ln_att_g, G.ln_att_b, L.fc_factor,
-                                 p, seed + 2, dB, d, scr, stream));   // d x1 -> dxb
+    IA_TRY(ia_layernorm_bwd_drop(S.x1, d, nullptr, dy, d, N, d, L.ln_att_g, L.ln_eps, dxa, dxb, d, nullptr, nullptr, L.fc_factor,
+                                 p, seed + 2, dB, d, lnp + 3 * lnp_set, stream));   // d x1 -> dxb
     // feed_forward1
     IA_TRY(ia_gemm_bf16_ex(dB, d, wt_ff1b, d, N, d_ff, d, nullptr, 3, pff, seed + 1, 1.f, nullptr, 0, nullptr, 0, dhp, d_ff, nullptr, 0,
                            S.h1p, d_ff, stream));
     IA_TRY(linear_bwd_deferred(dB, S.h1, L.w_ff1b, N, d, d_ff, nullptr, G.w_ff1b, G.b_ff1b, wt_ff1b, grp, &ngrp, stream));
     IA_TRY(linear_bwd_deferred(dhp, S.y1, L.w_ff1a, N, d_ff, d, dy, G.w_ff1a, G.b_ff1a, wt_ff1a, grp, &ngrp, stream));
-    IA_TRY(ia_layernorm_bwd(x0, d, nullptr, dy, d, N, d, L.ln_ff1_g, L.ln_eps, dxb, dx0, d, G.ln_ff1_g, G.ln_ff1_b, scr, stream));
+    IA_TRY(ia_layernorm_bwd(x0, d, nullptr, dy, d, N, d, L.ln_ff1_g, L.ln_eps, dxb, dx0, d, nullptr, nullptr, lnp + 4 * lnp_set, stream));
     IA_TRY(flush_group(grp, ngrp, scr, stream));   // the four weight gradients of this half, before the multi-tensor add
+    {   // d gamma | d beta of the block's five LayerNorms: one finishing launch
+        const int rows = ia_layernorm_bwd_partial_rows(N);
+        const ia_finish_job jobs[5] = {{lnp + 0 * lnp_set, rows, 2 * d, d, G.ln_out_g, G.ln_out_b},
+                                       {lnp + 1 * lnp_set, rows, 2 * d, d, G.ln_ff2_g, G.ln_ff2_b},
+                                       {lnp + 2 * lnp_set, rows, 2 * d, d, G.ln_conv_g, G.ln_conv_b},
+                                       {lnp + 3 * lnp_set, rows, 2 * d, d, G.ln_att_g, G.ln_att_b},
+                                       {lnp + 4 * lnp_set, rows, 2 * d, d, G.ln_ff1_g, G.ln_ff1_b}};
+        IA_TRY(ia_partials_finish_multi(jobs, 5, stream));
+    }
     if (add_table && n_add > 0) {
         hipLaunchKernelGGL(multi_add_kernel, dim3(64, n_add < 64 ? n_add : 64), dim3(256), 0, (hipStream_t)stream,
                            (const AddRow*)add_table, n_add);

@@ -312,7 +312,7 @@ extern "C" int ia_layernorm_bwd_drop(const float* x, int ldx, const float* dy_f3
                                      const float* gamma, float eps, const float* dx_in, float* dx_out, int lddx, float* dgamma,
                                      float* dbeta, float alpha, float dropout_p, unsigned seed, void* dx_bf16, int lddxh,
                                      float* scratch, ia_stream_t stream) {
-    if (!x || (!dy_f32 && !dy_bf16) || !gamma || !dx_out || !dgamma || !dbeta || !scratch || N <= 0 || d <= 0)
+    if (!x || (!dy_f32 && !dy_bf16) || !gamma || !dx_out || ((dgamma == nullptr) != (dbeta == nullptr)) || !scratch || N <= 0 || d <= 0)
         return IA_INVALID_VALUE;
     if (d % 4 != 0 || d > 1024 || ldx % 4 != 0 || ldy % 4 != 0 || lddx % 4 != 0) return IA_UNSUPPORTED;
     if (dx_bf16 && (d % 8 != 0 || lddxh % 4 != 0 || dropout_p < 0.f || dropout_p >= 1.f)) return IA_INVALID_VALUE;
@@ -339,7 +339,61 @@ extern "C" int ia_layernorm_bwd_drop(const float* x, int ldx, const float* dy_f3
     }
 #undef IA_LNB
     IA_RETURN_IF_LAUNCH_FAILED();
+    if (!dgamma) return IA_OK;   // deferred: the caller sums the partial rows later (ia_partials_finish_multi)
     ia_partials_finish(scratch, G, 2 * d, d, dgamma, dbeta, st);
+    IA_RETURN_IF_LAUNCH_FAILED();
+    return IA_OK;
+}
+
+extern "C" int ia_layernorm_bwd_partial_rows(int N) { return N > 0 ? lnb_blocks(N) : 0; }
+
+namespace {
+struct FinishJobs { ia_finish_job j[8]; int first_block[9]; int n; };
+// the column sums of up to eight partial-row sets in one launch (block = 64 columns x 16 row groups of one job)
+__global__ __launch_bounds__(1024) void partials_finish_multi_kernel(FinishJobs f) {
+    __shared__ float red[16][64];
+    int k = 0;
+    while (k + 1 < f.n && (int)blockIdx.x >= f.first_block[k + 1]) ++k;
+    const ia_finish_job J = f.j[k];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = ((int)blockIdx.x - f.first_block[k]) * 64 + cl;
+    float a0 = 0.f, a1 = 0.f;
+    if (c < J.C) {
+        int r = rg;
+        for (; r + 112 < J.G; r += 128) {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = J.part[(size_t)(r + 16 * q) * J.C + c];
+            a0 += (v[0] + v[2]) + (v[4] + v[6]);
+            a1 += (v[1] + v[3]) + (v[5] + v[7]);
+        }
+        for (; r < J.G; r += 16) a0 += J.part[(size_t)r * J.C + c];
+    }
+    red[rg][cl] = a0 + a1;
+    __syncthreads();
+    if (rg == 0 && c < J.C) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s += red[q][cl];
+        if (c < J.C0) J.out0[c] = s; else J.out1[c - J.C0] = s;
+    }
+}
+}  // namespace
+
+extern "C" int ia_partials_finish_multi(const ia_finish_job* jobs, int count, ia_stream_t stream) {
+    if (!jobs || count <= 0 || count > 8) return IA_INVALID_VALUE;
+    FinishJobs f;
+    f.n = count;
+    int blocks = 0;
+    for (int i = 0; i < count; ++i) {
+        const ia_finish_job& J = jobs[i];
+        if (!J.part || !J.out0 || J.G <= 0 || J.C <= 0 || J.C0 < 0 || J.C0 > J.C || (J.C0 < J.C && !J.out1)) return IA_INVALID_VALUE;
+        f.j[i] = J;
+        f.first_block[i] = blocks;
+        blocks += (J.C + 63) / 64;
+    }
+    f.first_block[count] = blocks;
+    hipLaunchKernelGGL(partials_finish_multi_kernel, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, f);
     IA_RETURN_IF_LAUNCH_FAILED();
     return IA_OK;
 }
