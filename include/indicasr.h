@@ -182,12 +182,13 @@ int ia_joint_dh_fused(const void* G, const void* Wt, const void* f, const void* 
  * ia_joint_backward_g's dbias_out).  The hidden tensor is regenerated tile by
  * tile in LDS (same counter-based dropout mask as the forward), so neither hidden^T nor a transposed copy of G exists.
  * Split-K over the lattice cells: partial tiles in `scratch` (ia_joint_dw_fused_scratch_elems floats) + a finishing sum.
- * The steps are laid out per utterance and the utterance's prediction rows g[b, :, tile] stay resident in LDS.
+ * The steps are laid out per utterance and the utterance's prediction rows g[b, :, tile] stay resident in LDS; with act_lens
+ * (optional, may be NULL) the steps behind an utterance's last live frame -- where G is zero -- are skipped.
  * Supported when ia_joint_dw_fused_supported(U1, H, LD): U1 <= 128, H % 8 == 0, LD % 8 == 0, LD <= 288; B*T*U1 < 2^31. */
 int ia_joint_dw_fused_supported(int U1, int H, int LD);
 int64_t ia_joint_dw_fused_scratch_elems(int B, int T, int U1, int H, int LD);
-int ia_joint_dw_fused(const void* G, const void* f, const void* g, int B, int T, int U1, int H, int LD, float dropout_p,
-                      unsigned seed, float* dW, float* scratch, ia_stream_t stream);
+int ia_joint_dw_fused(const void* G, const void* f, const void* g, const int64_t* act_lens, int B, int T, int U1, int H, int LD,
+                      float dropout_p, unsigned seed, float* dW, float* scratch, ia_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Conformer block forward building blocks (bf16 projections, fp32 residual stream).

@@ -68,6 +68,16 @@ __device__ __forceinline__ void dw_divmod(unsigned x, unsigned d, unsigned m, un
     *q = qq - lo + hi; *r = (unsigned)(rr + (lo - hi) * (int)d);
 }
 
+// live 64-cell steps of utterance b: up to its last live frame
+__device__ __forceinline__ int dw_live_spu(const int64_t* __restrict__ act_lens, int b, int T, int U1, int spu) {
+    if (!act_lens) return spu;
+    long long tb = act_lens[b];
+    tb = tb < 0 ? 0 : (tb > T ? T : tb);
+    int live = (int)((tb * U1 + DW_MS - 1) / DW_MS);
+    live = live < 1 ? 1 : live;
+    return live < spu ? live : spu;
+}
+
 struct DwArgs {
     const _Float16* G; const _Float16* f; const _Float16* g;
     float* part;
@@ -77,6 +87,7 @@ struct DwArgs {
     int spu;             // steps per utterance ceil(cpu / 64): a step never straddles two utterances
     int steps_per_split;
     unsigned seed, thr, mU1, mV, mSpu;   // magic reciprocals of U1, LD/8 and spu
+    const int64_t* act_lens;             // optional: frames >= act_lens[b] carry no gradient (G is zero there): their steps are skipped
 };
 
 // GRES: the utterance's prediction rows stay resident in LDS (U+1 <= 128: the bench shapes); otherwise (30 s utterances:
@@ -97,10 +108,38 @@ __global__ __launch_bounds__(DW_THREADS, 1) void joint_dw_fused_kernel(DwArgs a)
     const int htile = slot % a.ntiles;
     const int h0 = htile * DW_BH;
     const int T = a.T, U1 = a.U1, H = a.H, LD = a.LD, vpr = LD / 8;
-    const int nsteps = a.B * a.spu;
-    const int step_beg = split * a.steps_per_split;
-    int step_end = step_beg + a.steps_per_split;
-    step_end = step_end < nsteps ? step_end : nsteps;
+    // Steps = 64 consecutive lattice cells of one utterance.  With the frame counts the steps of an utterance end behind its
+    // last live frame (G is zero beyond: a fifth of the lattice at lengths 0.6-1.0 x T), and the splits share the LIVE steps.
+    // live_spu(b) is uniform (scalar loads); the starting point of this split comes from a prefix pass through LDS.
+#define live_spu(b_) __builtin_amdgcn_readfirstlane(dw_live_spu(a.act_lens, (b_), T, U1, a.spu))   /* uniform b only */
+    int nsteps = a.B * a.spu, step_beg, step_end, b_first = 0, s_first = 0;
+    if (a.act_lens && a.B <= 4096) {
+        int* s_spu = reinterpret_cast<int*>(smem);        // (the stages are free until the loop starts; re-zeroed below)
+        for (int i = tid; i < a.B; i += DW_THREADS) s_spu[i] = dw_live_spu(a.act_lens, i, T, U1, a.spu);
+        __syncthreads();
+        int total = 0;
+        for (int i = 0; i < a.B; ++i) total += s_spu[i];
+        nsteps = total;
+        const int sps = (nsteps + a.nsplit - 1) / a.nsplit;
+        step_beg = split * sps;
+        step_end = step_beg + sps < nsteps ? step_beg + sps : nsteps;
+        int accu = 0;
+        for (int i = 0; i < a.B; ++i) {
+            const int n = s_spu[i];
+            if (step_beg >= accu && step_beg < accu + n) { b_first = i; s_first = step_beg - accu; }
+            accu += n;
+        }
+        __syncthreads();
+        nsteps = __builtin_amdgcn_readfirstlane(nsteps); step_beg = __builtin_amdgcn_readfirstlane(step_beg);
+        step_end = __builtin_amdgcn_readfirstlane(step_end);
+        b_first = __builtin_amdgcn_readfirstlane(b_first); s_first = __builtin_amdgcn_readfirstlane(s_first);
+    } else {
+        step_beg = split * a.steps_per_split;
+        step_end = step_beg + a.steps_per_split < nsteps ? step_beg + a.steps_per_split : nsteps;
+        unsigned q0_, r0_;
+        dw_divmod((unsigned)(step_beg < nsteps ? step_beg : 0), (unsigned)a.spu, a.mSpu, &q0_, &r0_);
+        b_first = (int)q0_; s_first = (int)r0_;
+    }
 
     f4 acc[9][2];
 #pragma unroll
@@ -110,7 +149,14 @@ __global__ __launch_bounds__(DW_THREADS, 1) void joint_dw_fused_kernel(DwArgs a)
     }
     // the chunk slots LD/8 .. 47 of every G row stay zero for the whole kernel (both stages)
     for (int i = tid; i < 2 * DW_STAGE / 16; i += DW_THREADS) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
-    if (step_beg >= step_end) return;   // (uniform) nothing to do: the finishing sum never reads this split
+    if (step_beg >= step_end) {   // (uniform) no live step left for this split: its partial tile is zeros
+        float* prow0 = a.part + (size_t)split * a.row_stride;
+        for (int i = tid; i < LD * DW_BH; i += DW_THREADS) {
+            const int v = i / DW_BH, hh = h0 + (i - v * DW_BH);
+            if (hh < H) prow0[(size_t)v * H + hh] = 0.f;
+        }
+        return;
+    }
 
     // ---- loaders.  G: chunks idx = tid + 512k of the step's flat 64-row region (contiguous in memory); hidden: item idx
     // = tid + 512k -> (row = idx >> 4, chunk = idx & 15).  Loads are unconditional on clamped addresses (the compiler keeps
@@ -200,9 +246,9 @@ __global__ __launch_bounds__(DW_THREADS, 1) void joint_dw_fused_kernel(DwArgs a)
     } while (0)
     // advance (b, s) by one step, stopping at the split's last step (re-staged once more at the end: harmless, and the
     // loop body stays free of divergent branches)
-#define DW_NEXT(b_, s_, idx_)                                                                                  \
+#define DW_NEXT(b_, s_, idx_, n_)                                                                              \
     do {                                                                                                       \
-        if ((idx_) + 1 < step_end) { ++(idx_); if (++(s_) == a.spu) { (s_) = 0; ++(b_); } }                    \
+        if ((idx_) + 1 < step_end) { ++(idx_); if (++(s_) == (n_)) { (s_) = 0; ++(b_); (n_) = live_spu(b_); } } \
     } while (0)
 
     // fragment addresses of k-step 0 in the current stage; k-step 1 = 32 rows further (same swizzle phase: an immediate
@@ -214,15 +260,14 @@ __global__ __launch_bounds__(DW_THREADS, 1) void joint_dw_fused_kernel(DwArgs a)
     for (int i = 0; i < 9; ++i) dw_frag_addr(lds0, DW_YROW, q4 * 8, wv * 144 + i * 16, lane, &aA0[i], &aA1[i]);
 
     // (b, s) of the step being multiplied is implicit; sb/ss/si = the step being staged, lb/ls/li = the step being loaded
-    unsigned q0, r0;
-    dw_divmod((unsigned)step_beg, (unsigned)a.spu, a.mSpu, &q0, &r0);
-    int sb = __builtin_amdgcn_readfirstlane((int)q0), ss = __builtin_amdgcn_readfirstlane((int)r0), si = step_beg;
+    int sb = __builtin_amdgcn_readfirstlane(b_first), ss = __builtin_amdgcn_readfirstlane(s_first), si = step_beg;
+    int sn = live_spu(sb);            // live steps of the utterance being staged / loaded
     int gb = sb;                      // utterance whose prediction rows are resident
     __syncthreads();                  // zero fill done
     DW_GTILE(gb);
     DW_LOAD(0, sb, ss);
     DW_STORE(0, sb, ss, 0);
-    int lb = sb, ls = ss, li = si;
+    int lb = sb, ls = ss, li = si, ln = sn;
     int cur = 0;
 #define DW_KSTEP(KS)                                                                                           \
         {                                                                                                      \
@@ -253,13 +298,13 @@ __global__ __launch_bounds__(DW_THREADS, 1) void joint_dw_fused_kernel(DwArgs a)
 #define DW_MMA DW_KSTEP(0) DW_KSTEP(1)
     // stage the next step (register set R) into the other LDS stage -- nobody reads it before the barrier -- and refill R
 #define DW_STAGE_NEXT(R)                                                                                       \
-        DW_NEXT(sb, ss, si);                                                                                   \
+        DW_NEXT(sb, ss, si, sn);                                                                               \
         if (sb != gb) {   /* (uniform) next utterance: its prediction rows replace the resident ones (all readers of the */ \
             gb = sb;      /* old rows finished before the previous step's barrier) */                          \
             DW_GTILE(gb);                                                                                      \
         }                                                                                                      \
         DW_STORE(R, sb, ss, cur ^ 1);                                                                          \
-        DW_NEXT(lb, ls, li);                                                                                   \
+        DW_NEXT(lb, ls, li, ln);                                                                               \
         DW_LOAD(R, lb, ls);
 #define DW_BODY(FIRST, SECOND)                                                                                 \
     {                                                                                                          \
@@ -276,14 +321,14 @@ __global__ __launch_bounds__(DW_THREADS, 1) void joint_dw_fused_kernel(DwArgs a)
     // one register set is enough.  Waves 4-7 multiply first: the loads of the step they stage next were issued only one
     // multiply phase earlier, so they keep two sets in flight (steps n+2 and n+3 while step n is multiplied).
     if (__builtin_amdgcn_readfirstlane(wave >> 2) == 0) {
-        DW_NEXT(lb, ls, li);
+        DW_NEXT(lb, ls, li, ln);
         DW_LOAD(0, lb, ls);
         __syncthreads();
         for (int step = step_beg; step < step_end; ++step) DW_BODY(DW_STAGE_NEXT(0), DW_MMA)
     } else {
-        DW_NEXT(lb, ls, li);
+        DW_NEXT(lb, ls, li, ln);
         DW_LOAD(1, lb, ls);
-        DW_NEXT(lb, ls, li);
+        DW_NEXT(lb, ls, li, ln);
         DW_LOAD(0, lb, ls);
         __syncthreads();
         for (int step = step_beg; step < step_end; step += 2) {
@@ -300,6 +345,7 @@ __global__ __launch_bounds__(DW_THREADS, 1) void joint_dw_fused_kernel(DwArgs a)
 #undef DW_STORE
 #undef DW_GTILE
 #undef DW_NEXT
+#undef live_spu
     // partial tile of this split: rows v < LD, columns h0 .. h0+127
     float* prow = a.part + (size_t)split * a.row_stride;
 #pragma unroll
@@ -340,8 +386,8 @@ extern "C" int64_t ia_joint_dw_fused_scratch_elems(int B, int T, int U1, int H, 
     return (int64_t)dw_splits(dw_nsteps(B, T, U1), H) * ((int64_t)LD * H);
 }
 
-extern "C" int ia_joint_dw_fused(const void* G, const void* f, const void* g, int B, int T, int U1, int H, int LD,
-                                 float dropout_p, unsigned seed, float* dW, float* scratch, ia_stream_t stream) {
+extern "C" int ia_joint_dw_fused(const void* G, const void* f, const void* g, const int64_t* act_lens, int B, int T, int U1, int H,
+                                 int LD, float dropout_p, unsigned seed, float* dW, float* scratch, ia_stream_t stream) {
     if (!G || !f || !g || !dW || !scratch || B <= 0 || T <= 0 || U1 <= 0) return IA_INVALID_VALUE;
     if (!ia_joint_dw_fused_supported(U1, H, LD)) return IA_UNSUPPORTED;
     if (!ia_is_aligned(G, 16) || !ia_is_aligned(f, 16) || !ia_is_aligned(g, 16) || !ia_is_aligned(dW, 16) || !ia_is_aligned(scratch, 16) ||
@@ -351,7 +397,7 @@ extern "C" int ia_joint_dw_fused(const void* G, const void* f, const void* g, in
     if (cells >= (1ll << 31) || nsteps >= (1ll << 30)) return IA_UNSUPPORTED;
     DwArgs a;
     a.G = (const _Float16*)G; a.f = (const _Float16*)f; a.g = (const _Float16*)g; a.part = scratch;
-    a.B = B; a.T = T; a.U1 = U1; a.H = H; a.LD = LD;
+    a.B = B; a.T = T; a.U1 = U1; a.H = H; a.LD = LD; a.act_lens = act_lens;
     a.cpu = T * U1; a.spu = (a.cpu + DW_MS - 1) / DW_MS;
     const int S = dw_splits(nsteps, H);
     a.steps_per_split = (int)((nsteps + S - 1) / S);

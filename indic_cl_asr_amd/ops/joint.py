@@ -7,6 +7,8 @@ operands, f32 accumulation, logits rounded to f16, loss in f32.
 """
 import math
 
+import os
+
 import torch
 
 from .. import _lib
@@ -18,6 +20,7 @@ MFMA_PROFILE_HOOK = None   # bench.py: callable(flops) -> (start, stop) torch ev
 USE_FUSED_DH = True
 # csrc/joint_dw.hip regenerates the hidden tile in LDS and contracts it with G row-major (transposing LDS reads): no
 # hidden^T tensor, no transposed copy of G.  False selects hidden^T + the batched split-K library GEMM.
+DW_SKIP_DEAD_FRAMES = os.environ.get("IA_DW_SKIP", "1") != "0"   # the weight-gradient kernel skips the steps behind each utterance's last frame
 USE_FUSED_DW = True
 # Recorded right after the HBM-bound gradient kernel of the latest backward: work that other streams run under the joint's
 # backward (the CTC branch, losses/ctc.py) waits for it, so that kernel has the memory system to itself and the MFMA-bound
@@ -307,7 +310,8 @@ class _FusedJointRNNT(torch.autograd.Function):
         if fused_dw:
             dWk = torch.empty(LD, H, dtype=torch.float32, device=dev)
             scr = torch.empty(L.ia_joint_dw_fused_scratch_elems(B, T, U1, H, LD), dtype=torch.float32, device=dev)
-            st = L.ia_joint_dw_fused(_lib.ptr(G), _lib.ptr(f16), _lib.ptr(g16), B, T, U1, H, LD, p, seed, _lib.ptr(dWk),
+            st = L.ia_joint_dw_fused(_lib.ptr(G), _lib.ptr(f16), _lib.ptr(g16), _lib.ptr(act_lens) if DW_SKIP_DEAD_FRAMES else None, B, T, U1,
+                                     H, LD, p, seed, _lib.ptr(dWk),
                                      _lib.ptr(scr), _lib.stream_ptr())
             _lib.check(st, "ia_joint_dw_fused")
             dW = dWk[:V] * (1.0 / (kappa * (1.0 - p)))

@@ -9,11 +9,20 @@ G = (torch.randn(B * T * U1, LD, device="cuda") * 0.01).half()
 f = torch.randn(B, T, H, device="cuda").half(); g = torch.randn(B, U1, H, device="cuda").half()
 dW = torch.empty(LD, H, device="cuda")
 scr = torch.empty(L.ia_joint_dw_fused_scratch_elems(B, T, U1, H, LD), device="cuda")
-def run():
-    _lib.check(L.ia_joint_dw_fused(_lib.ptr(G), _lib.ptr(f), _lib.ptr(g), B, T, U1, H, LD, p, 7, _lib.ptr(dW), _lib.ptr(scr), _lib.stream_ptr()), "dw")
-run(); torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(10): run()
-e1.record(); torch.cuda.synchronize()
-print(os.environ.get("IA_LIB_PATH", "default"), f"{e0.elapsed_time(e1) / 10:.3f} ms")
+lens = torch.round(T * (0.6 + 0.4 * torch.rand(B, generator=torch.Generator().manual_seed(0)))).long().cuda()
+t_idx = torch.arange(T, device="cuda").view(1, T, 1)
+Gm = (G.view(B, T, U1 * LD) * (t_idx < lens.view(B, 1, 1))).view(B * T * U1, LD).contiguous()   # zero beyond the frame counts
+ref = None
+for name, ln in (("no frame counts", None), ("frame counts 0.6-1.0 T", lens)):
+    def run():
+        _lib.check(L.ia_joint_dw_fused(_lib.ptr(Gm), _lib.ptr(f), _lib.ptr(g), _lib.ptr(ln), B, T, U1, H, LD, p, 7, _lib.ptr(dW), _lib.ptr(scr), _lib.stream_ptr()), "dw")
+    run(); torch.cuda.synchronize()
+    if ref is None:
+        ref = dW.clone()
+    else:
+        print("max |diff| vs no-skip:", float((dW - ref).abs().max()), "of", float(ref.abs().max()))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10): run()
+    e1.record(); torch.cuda.synchronize()
+    print(name, f"{e0.elapsed_time(e1) / 10:.3f} ms")
