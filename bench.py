@@ -68,6 +68,7 @@ class HipEvents:
         self.hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
         self.pairs, self.shapes, self.free = [], [], []
         self.enabled = False
+        self.touched_fraction = None
         self.kernel_name = "rnnt_grad"
 
     def _new(self):
@@ -75,7 +76,7 @@ class HipEvents:
         assert self.hip.hipEventCreate(ctypes.byref(e)) == 0
         return e
 
-    def hook(self, B, T, U1, V, elem_bytes=4, passes=2, kernel=None):
+    def hook(self, B, T, U1, V, elem_bytes=4, passes=2, kernel=None, skips_dead_frames=False):
         """passes = lattice-sized streams the kernel must move: read logits + write grads (2); the
         library-GEMM fallback of the f16 path also writes G^T for the split-K weight-gradient GEMM (3)."""
         if kernel is not None:
@@ -84,7 +85,10 @@ class HipEvents:
             return None
         a, b = self._new(), self._new()
         self.pairs.append((a, b))
-        self.shapes.append((B, T, U1, V, elem_bytes * passes / 2.0))
+        # the kernel leaves the tiles behind frame T_b + 3 of every utterance alone (nothing reads them): the algorithmic
+        # bytes are those of the cells it has to touch (self.touched_fraction, from the host-side lengths of the batch)
+        frac = self.touched_fraction if (skips_dead_frames and self.touched_fraction is not None) else 1.0
+        self.shapes.append((B, T, U1, V, elem_bytes * passes / 2.0 * frac))
         return a, b
 
     def summary(self):
@@ -225,6 +229,15 @@ def main():
 
     events = HipEvents()
     rnnt_mod.PROFILE_HOOK = events.hook
+    try:   # cells the gradient kernel has to touch: frames < T_b + 4 of every utterance (+ the 64-cell tile that straddles the end)
+        from indic_cl_asr_amd.encoder import subsampled_length
+        from indic_cl_asr_amd.features import mel_frame_count
+        h_enc = [int(subsampled_length(mel_frame_count(int(n), cfg.n_fft, cfg.n_window_stride))) for n in host_lens[0]]
+        Tq, U1q = max(h_enc), max(int(u) for u in host_lens[1]) + 1
+        live = sum(min(Tq * U1q, (min(Tq, t + 4) * U1q + 63) // 64 * 64) for t in h_enc)
+        events.touched_fraction = live / float(len(h_enc) * Tq * U1q)
+    except Exception:
+        events.touched_fraction = None
     from indic_cl_asr_amd.ops import joint as joint_mod
     mfma_events = []          # (start, stop, flops) of the fused hidden-gradient kernel (the dominant MFMA kernel)
     timing = {"on": False}

@@ -146,6 +146,13 @@ int ia_joint_backward_g(void* logits_inout, const int64_t* labels, const int64_t
                         float kappa, void* gt_out, int S, int Kc, float* dbias_out, float* dbias_scratch, void* workspace,
                         size_t workspace_bytes, ia_stream_t stream, void* grad_kernel_start_event,
                         void* grad_kernel_stop_event);
+/* The same; skip_dead_frames != 0 (fused dbias variant only, i.e. dbias_out != NULL): the kernel neither reads nor zero-fills
+ * the 64-cell tiles that lie entirely behind frame act_lens[b] + 3 of an utterance -- valid when G is consumed by
+ * ia_joint_dh_fused and ia_joint_dw_fused (with act_lens), which read nothing there. */
+int ia_joint_backward_g_skip(void* logits_inout, const int64_t* labels, const int64_t* act_lens, const int64_t* label_lens, int B,
+                             int T, int U1, int V, int LD, int blank, float fastemit, const float* cost_grad, float kappa,
+                             void* gt_out, int S, int Kc, float* dbias_out, float* dbias_scratch, void* workspace,
+                             size_t workspace_bytes, int skip_dead_frames, ia_stream_t stream, void* ev_start, void* ev_stop);
 /* dbias_out (optional, NULL to skip; only with gt_out == NULL): receives sum_cells G[cell, v] for v < LD (f32, un-scaled:
  * the bias gradient of the per-language head times kappa), accumulated by the gradient kernel itself in registers;
  * dbias_scratch = ia_joint_backward_g_dbias_scratch_elems(LD) floats of per-workgroup partial rows. */

@@ -83,6 +83,8 @@ SIGNATURES = {
     "ia_rnnt_lattice": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _sz, _vp]),
     "ia_joint_backward_g": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _f, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp,
                                  _vp]),
+    "ia_joint_backward_g_skip": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _f, _vp, _i, _i, _vp, _vp, _vp, _sz, _i, _vp,
+                                      _vp, _vp]),
     "ia_joint_backward_g_dbias_scratch_elems": (_i64, [_i]),
     "ia_joint_hidden_t": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _c.c_uint, _vp]),
     "ia_joint_hidden": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _c.c_uint, _vp]),

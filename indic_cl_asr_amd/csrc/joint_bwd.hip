@@ -270,7 +270,11 @@ constexpr int GD_THREADS = 512;
 constexpr int GD_NV = 5;         // 16-byte chunks per thread per tile: ceil(64 * (LD/8 <= 36) / 512); 40 accumulators per thread
 __global__ __launch_bounds__(GD_THREADS, 4) void joint_grad_h_db_kernel(_Float16* __restrict__ x, const float4* __restrict__ cs,
                                                                         int64_t cells, int LD, int V, int blank, float kappa,
-                                                                        float* __restrict__ db_part) {
+                                                                        float* __restrict__ db_part,
+                                                                        const unsigned char* __restrict__ far) {
+    // far (optional): one byte per 64-cell tile, written by rnnt_cell_scalars: every cell of the tile lies behind frame
+    // T_b + 3 of its utterance.  The fused hidden- / weight-gradient kernels read nothing there (4-frame passes, 64-cell steps
+    // up to the last live frame), so such a tile is neither read nor zero-filled.
     __shared__ float4 scs[2][GT_CELLS];
     __shared__ __attribute__((aligned(16))) float red[GD_THREADS * 8];
     const int vpr = LD / 8;
@@ -293,7 +297,8 @@ __global__ __launch_bounds__(GD_THREADS, 4) void joint_grad_h_db_kernel(_Float16
     float4 pc = make_float4(IA_NEG_INF, 0.f, 0.f, 0.f);
     int64_t tile_id = blockIdx.x;
     int par = 0;
-    if (tile_id < ntiles) {
+    int cur_far = (far && tile_id < ntiles) ? __builtin_amdgcn_readfirstlane((int)far[tile_id]) : 0;
+    if (tile_id < ntiles && !cur_far) {
         const int64_t c0 = tile_id * GT_CELLS, left = cells - c0;
         const int nv = (int)(left < GT_CELLS ? left : GT_CELLS) * vpr;   // >= vpr
         if (tid < GT_CELLS) pc = cs[c0 + (tid < left ? tid : 0)];
@@ -303,8 +308,6 @@ __global__ __launch_bounds__(GD_THREADS, 4) void joint_grad_h_db_kernel(_Float16
     }
     for (; tile_id < ntiles; tile_id += gridDim.x, par ^= 1) {
         const int64_t cell0 = tile_id * GT_CELLS;
-        if (tid < GT_CELLS) scs[par][tid] = pc;
-        __syncthreads();   // one barrier per tile: the record buffer alternates
         // the next tile of this workgroup (the last one is re-read once: the loop stays branch-free); chunk k's successor
         // is requested as soon as chunk k has been consumed, so no second register set is needed
         int64_t next = tile_id + gridDim.x;
@@ -312,6 +315,22 @@ __global__ __launch_bounds__(GD_THREADS, 4) void joint_grad_h_db_kernel(_Float16
         const int64_t n0 = next * GT_CELLS, nleft = cells - n0;
         const int nnv = (int)(nleft < GT_CELLS ? nleft : GT_CELLS) * vpr;
         const uint4* nsrc = reinterpret_cast<const uint4*>(x + n0 * LD);
+        if (far) {   // (uniform branches; without `far` the loop is the branch-free one)
+            const int next_far = __builtin_amdgcn_readfirstlane((int)far[next]);
+            if (cur_far) {   // nothing of this tile is read or written: only request the next tile's operands
+                if (!next_far) {
+                    if (tid < GT_CELLS) pc = cs[n0 + (tid < nleft ? tid : 0)];
+#pragma unroll
+                    for (int k = 0; k < GD_NV; ++k) px[k] = nsrc[tid + GD_THREADS * k < nnv ? tid + GD_THREADS * k : nnv - 1];
+                }
+                cur_far = next_far;
+                continue;
+            }
+            cur_far = next_far;
+            if (next_far) nsrc = reinterpret_cast<const uint4*>(x + cell0 * LD);   // (loads stay unconditional: re-read this tile, in cache)
+        }
+        if (tid < GT_CELLS) scs[par][tid] = pc;
+        __syncthreads();   // one barrier per tile: the record buffer alternates
         if (tid < GT_CELLS) pc = cs[n0 + (tid < nleft ? tid : 0)];
         uint4* dst = reinterpret_cast<uint4*>(x + cell0 * LD);
 #pragma unroll
@@ -430,6 +449,15 @@ extern "C" int ia_joint_backward_g(void* logits_inout, const int64_t* labels, co
                                    float fastemit, const float* cost_grad, float kappa, void* gt_out, int S, int Kc,
                                    float* dbias_out, float* dbias_scratch, void* workspace, size_t workspace_bytes,
                                    ia_stream_t stream, void* ev_start, void* ev_stop) {
+    return ia_joint_backward_g_skip(logits_inout, labels, act_lens, label_lens, B, T, U1, V, LD, blank, fastemit, cost_grad, kappa,
+                                    gt_out, S, Kc, dbias_out, dbias_scratch, workspace, workspace_bytes, 0, stream, ev_start, ev_stop);
+}
+
+extern "C" int ia_joint_backward_g_skip(void* logits_inout, const int64_t* labels, const int64_t* act_lens,
+                                        const int64_t* label_lens, int B, int T, int U1, int V, int LD, int blank,
+                                        float fastemit, const float* cost_grad, float kappa, void* gt_out, int S, int Kc,
+                                        float* dbias_out, float* dbias_scratch, void* workspace, size_t workspace_bytes,
+                                        int skip_dead_frames, ia_stream_t stream, void* ev_start, void* ev_stop) {
     if (!logits_inout || !act_lens || !label_lens || !workspace || B <= 0 || T <= 0 || U1 <= 0) return IA_INVALID_VALUE;
     if (LD < V || LD % 8 != 0 || !ia_is_aligned(logits_inout, 16) || !ia_is_aligned(workspace, 256) || !(kappa > 0.f))
         return IA_INVALID_VALUE;
@@ -457,7 +485,8 @@ extern "C" int ia_joint_backward_g(void* logits_inout, const int64_t* labels, co
     } else if (dbias_out) {
         const int grid = gd_grid(cells);
         hipLaunchKernelGGL(joint_grad_h_db_kernel, dim3(grid), dim3(GD_THREADS), 0, st, (_Float16*)logits_inout,
-                           (const float4*)(ws + w.off_cs), cells, LD, V, blank, kappa, dbias_scratch);
+                           (const float4*)(ws + w.off_cs), cells, LD, V, blank, kappa, dbias_scratch,
+                           skip_dead_frames ? (const unsigned char*)(ws + w.off_far) : (const unsigned char*)nullptr);
         IA_RETURN_IF_LAUNCH_FAILED();
         if (ev_stop && hipEventRecord((hipEvent_t)ev_stop, st) != hipSuccess) return IA_LAUNCH_FAILED;
         ia_partials_finish(dbias_scratch, grid, LD, LD, dbias_out, nullptr, st);

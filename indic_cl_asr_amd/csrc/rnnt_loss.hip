@@ -240,10 +240,21 @@ __global__ __launch_bounds__(256) void rnnt_cell_scalars(
     const float* __restrict__ ALPHA, const float* __restrict__ BETA, const float* __restrict__ ll,
     const int64_t* __restrict__ labels, const int64_t* __restrict__ act_lens, const int64_t* __restrict__ label_lens,
     int B, int T, int U1, int rows, int U1s, float fastemit, const float* __restrict__ cost_grad,
-    float4* __restrict__ cs) {
+    float4* __restrict__ cs, unsigned char* __restrict__ far) {
     const int64_t cells = (int64_t)B * T * U1;
     const float l1p = log1pf(fastemit);
-    for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < cells; c += (int64_t)gridDim.x * 256) {
+    for (int64_t c0 = (int64_t)blockIdx.x * 256; c0 < cells; c0 += (int64_t)gridDim.x * 256) {
+        const int64_t c = c0 + threadIdx.x;
+        const bool in = c < cells;
+        const int64_t cc = in ? c : cells - 1;
+        const int64_t btq = cc / U1;
+        const int tq = (int)(btq % T), bq = (int)(btq / T);
+        // a wave = one 64-cell tile of the gradient kernel: flag it when every cell lies behind frame T_b + 3 (nothing reads G
+        // there when the fused hidden- and weight-gradient kernels consume it: csrc/joint_bwd.hip skips such tiles on request)
+        const bool cell_far = !in || tq >= (int)act_lens[bq] + 4;
+        const unsigned long long all_far = __ballot(cell_far);
+        if (far && (threadIdx.x & 63) == 0 && in) far[c >> 6] = (all_far == ~0ull) ? 1 : 0;
+        if (!in) continue;
         const int u = (int)(c % U1);
         const int64_t bt = c / U1;
         const int t = (int)(bt % T), b = (int)(bt / T);
@@ -391,7 +402,7 @@ int ia_rnnt_cell_scalars_launch(char* ws, const RnntWs* w, const int64_t* labels
     hipLaunchKernelGGL(rnnt_cell_scalars, dim3(gridc), dim3(256), 0, st, (const float*)(ws + w->off_denom),
                        (const float*)(ws + w->off_pb), (const float*)(ws + w->off_pl), (const float*)(ws + w->off_alpha),
                        (const float*)(ws + w->off_beta), (const float*)(ws + w->off_ll), labels, act_lens, label_lens, B,
-                       T, U1, w->rows, w->U1s, fastemit, cost_grad, (float4*)(ws + w->off_cs));
+                       T, U1, w->rows, w->U1s, fastemit, cost_grad, (float4*)(ws + w->off_cs), (unsigned char*)(ws + w->off_far));
     IA_RETURN_IF_LAUNCH_FAILED();
     return IA_OK;
 }

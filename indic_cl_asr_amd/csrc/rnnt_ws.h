@@ -8,7 +8,7 @@ struct RnntWs {
     int K;        // label positions per lane in K2 (power of two)
     int U1s;      // side-array row stride (= 64*K floats)
     int rows;     // side-array rows per utterance (diagonals + 2 + guard rows on both sides)
-    size_t off_denom, off_pb, off_pl, off_pla, off_alpha, off_beta, off_ll, off_cs, total;
+    size_t off_denom, off_pb, off_pl, off_pla, off_alpha, off_beta, off_ll, off_cs, off_far, total;
 };
 
 static inline bool rnnt_ws_layout(int B, int T, int U1, RnntWs* w) {
@@ -29,6 +29,7 @@ static inline bool rnnt_ws_layout(int B, int T, int U1, RnntWs* w) {
     w->off_beta = o;  o = ia_align_up(o + side, 256);
     w->off_ll = o;    o = ia_align_up(o + (size_t)2 * B * sizeof(float), 256);
     w->off_cs = o;    o = ia_align_up(o + cells * sizeof(float4), 256);
+    w->off_far = o;   o = ia_align_up(o + (cells + 63) / 64, 256);   // one byte per 64-cell tile: all its cells lie behind frame T_b + 3
     w->total = o;
     return true;
 }

@@ -208,7 +208,7 @@ class _FusedJointRNNT(torch.autograd.Function):
         return costs, (torch.zeros((), dtype=torch.float32, device=dev) if stash is not None else None)
 
     @staticmethod
-    def _rnnt_gradient(ctx, L, rl, gcosts, logits, ws, labels, act_lens, label_lens, fused_dw, kappa):
+    def _rnnt_gradient(ctx, L, rl, gcosts, logits, ws, labels, act_lens, label_lens, fused_dw, kappa, skip_dead=False):
         """logits -> kappa * d loss / d logits in place (csrc/joint_bwd.hip); returns (G, kappa*dbias | None, GT, S, Kc)."""
         B, T, U1, H, V, LD, blank, p, seed, fastemit, _, fdt, gdt, wdt, bdt, nbytes = ctx.meta
         dev = logits.device
@@ -222,16 +222,19 @@ class _FusedJointRNNT(torch.autograd.Function):
             GT = torch.empty(S, LD, Kc, dtype=torch.float16, device=dev)
         hook = None
         if rl.PROFILE_HOOK is not None:   # bench.py: HIP events around the gradient kernel on its launch stream
-            hook = rl.PROFILE_HOOK(B, T, U1, V, 2, 2 if fused_dw else 3, "joint_grad_h_db_kernel" if fused_dw else "joint_grad_h_t_kernel")
+            hook = rl.PROFILE_HOOK(B, T, U1, V, 2, 2 if fused_dw else 3, "joint_grad_h_db_kernel" if fused_dw else "joint_grad_h_t_kernel",
+                                   bool(skip_dead))
         ev0, ev1 = hook if hook is not None else (None, None)
         dbk = dbscr = None
         if fused_dw:   # the gradient kernel also returns kappa * dbias (register column sums, partial rows in dbscr)
             dbk = torch.empty(LD, dtype=torch.float32, device=dev)
             dbscr = torch.empty(L.ia_joint_backward_g_dbias_scratch_elems(LD), dtype=torch.float32, device=dev)
-        st = L.ia_joint_backward_g(_lib.ptr(logits), _lib.ptr(labels), _lib.ptr(act_lens), _lib.ptr(label_lens), B, T, U1, V,
-                                   LD, blank, fastemit, _lib.ptr(cg), kappa, _lib.ptr(GT), S, Kc, _lib.ptr(dbk), _lib.ptr(dbscr),
-                                   _lib.ptr(ws), nbytes, _lib.stream_ptr(), ev0, ev1)
-        _lib.check(st, "ia_joint_backward_g")
+        # tiles behind an utterance's last frame: not touched when nothing reads them (fused hidden- and weight-gradient kernels
+        # that know the frame counts, no continual-learning term to be added over the sub-batch boxes)
+        st = L.ia_joint_backward_g_skip(_lib.ptr(logits), _lib.ptr(labels), _lib.ptr(act_lens), _lib.ptr(label_lens), B, T, U1, V,
+                                        LD, blank, fastemit, _lib.ptr(cg), kappa, _lib.ptr(GT), S, Kc, _lib.ptr(dbk), _lib.ptr(dbscr),
+                                        _lib.ptr(ws), nbytes, int(bool(skip_dead)), _lib.stream_ptr(), ev0, ev1)
+        _lib.check(st, "ia_joint_backward_g_skip")
         global LAST_GRAD_KERNEL_EVENT
         LAST_GRAD_KERNEL_EVENT = torch.cuda.Event()
         LAST_GRAD_KERNEL_EVENT.record()
@@ -273,8 +276,10 @@ class _FusedJointRNNT(torch.autograd.Function):
             dbk = torch.sum(E, 0, dtype=torch.float32)
             GT, S, Kc = None, 0, 0
         else:
+            skip_dead = (E is None and fused_dw and DW_SKIP_DEAD_FRAMES and USE_FUSED_DH
+                         and bool(L.ia_joint_dh_fused_supported(U1, H, LD)))
             G, dbk, GT, S, Kc = _FusedJointRNNT._rnnt_gradient(ctx, L, rl, gcosts, logits, ws, labels, act_lens, label_lens,
-                                                               fused_dw, kappa)
+                                                               fused_dw, kappa, skip_dead)
             if E is not None:
                 st = L.ia_lattice_add_f16(_lib.ptr(G), _lib.ptr(E), G.numel(), _lib.stream_ptr())
                 _lib.check(st, "ia_lattice_add_f16")
