@@ -69,6 +69,7 @@ class HipEvents:
         self.pairs, self.shapes, self.free = [], [], []
         self.enabled = False
         self.touched_fraction = None
+        self.full_scale = 1.0
         self.kernel_name = "rnnt_grad"
 
     def _new(self):
@@ -89,6 +90,7 @@ class HipEvents:
         # bytes are those of the cells it has to touch (self.touched_fraction, from the host-side lengths of the batch)
         frac = self.touched_fraction if (skips_dead_frames and self.touched_fraction is not None) else 1.0
         self.shapes.append((B, T, U1, V, elem_bytes * passes / 2.0 * frac))
+        self.full_scale = 1.0 / frac   # full lattice / touched cells (reported next to the roofline, never as `achieved`)
         return a, b
 
     def summary(self):
@@ -358,7 +360,11 @@ def main():
             out["roofline"] = {"kernel": events.kernel_name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                                "launches": n, "avg_launch_ms": round(avg_ms, 4),
-                               "algorithmic_bytes_per_launch": int(avg_bytes)}
+                               "algorithmic_bytes_per_launch": int(avg_bytes),
+                               # the same launch priced on ALL B*T'*(U+1) cells (what the kernel streamed before it left the
+                               # tiles behind the utterances' ends alone): for comparison with earlier rounds only
+                               "full_lattice_bytes_per_launch": int(avg_bytes * events.full_scale),
+                               "frac_if_full_lattice": round(ach * events.full_scale / HBM_PEAK_GBS, 4)}
         if mfma_events:
             ms_l = [a.elapsed_time(b) for a, b, _ in mfma_events]
             fl = sum(f for _, _, f in mfma_events) / len(mfma_events)
