@@ -89,3 +89,30 @@ def test_layernorm_bwd_emits_the_dropout_scaled_bf16_gradient():
         torch.cuda.synchronize()
         assert torch.equal(dxa, dxb) and torch.equal(dga, dgb) and torch.equal(dba, dbb)
         assert torch.equal(ha, hb)
+
+
+def test_partials_finish_multi_sums_several_partial_sets_in_one_launch():
+    """ia_partials_finish_multi: the column sums of several partial-row sets (a block's five LayerNorm gradients)."""
+    import ctypes
+    from indic_cl_asr_amd import _lib
+    L = _lib.lib()
+
+    class Job(ctypes.Structure):
+        _fields_ = [("part", ctypes.c_void_p), ("G", ctypes.c_int), ("C", ctypes.c_int), ("C0", ctypes.c_int),
+                    ("out0", ctypes.c_void_p), ("out1", ctypes.c_void_p)]
+
+    g = torch.Generator().manual_seed(0)
+    shapes = [(300, 512, 256), (7, 288, 144), (1024, 512, 256), (33, 64, 64)]
+    parts = [torch.randn(G, C, generator=g).cuda() for G, C, _ in shapes]
+    out0 = [torch.empty(C0, device="cuda") for _, _, C0 in shapes]
+    out1 = [torch.empty(max(C - C0, 1), device="cuda") for _, C, C0 in shapes]
+    jobs = (Job * len(shapes))()
+    for i, (G, C, C0) in enumerate(shapes):
+        jobs[i] = Job(parts[i].data_ptr(), G, C, C0, out0[i].data_ptr(), out1[i].data_ptr())
+    _lib.check(L.ia_partials_finish_multi(ctypes.addressof(jobs), len(shapes), _lib.stream_ptr()), "ia_partials_finish_multi")
+    torch.cuda.synchronize()
+    for i, (G, C, C0) in enumerate(shapes):
+        ref = parts[i].double().sum(0)
+        assert torch.allclose(out0[i].double(), ref[:C0], rtol=1e-5, atol=1e-4)
+        if C > C0:
+            assert torch.allclose(out1[i][:C - C0].double(), ref[C0:], rtol=1e-5, atol=1e-4)

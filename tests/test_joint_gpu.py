@@ -188,3 +188,28 @@ def test_dropout_mask_matches_numpy_replica_and_is_unbiased():
     assert max(corr(c[..., i], c[..., j]) for i in range(8) for j in range(i)) < 3e-3
     a, b = keeps[0].astype(np.float64), keeps[1].astype(np.float64)        # consecutive seeds: unrelated masks
     assert abs(float(((a - a.mean()) * (b - b.mean())).mean() / a.var())) < 2e-2
+
+
+def test_joint_weight_gradient_skips_dead_frames_without_changing_the_result():
+    """ia_joint_dw_fused with the frame counts (steps behind each utterance's last live frame skipped, the splits share the live
+    steps) == without, when G is zero behind those frames -- including a very short and a full-length utterance."""
+    from indic_cl_asr_amd import _lib
+    L = _lib.lib()
+    B, T, U1, H, LD, p = 5, 70, 23, 320, 264, 0.2
+    g = torch.Generator().manual_seed(3)
+    lens = torch.tensor([70, 1, 33, 64, 12], dtype=torch.long)
+    G = (torch.randn(B, T, U1 * LD, generator=g) * 0.01)
+    G = (G * (torch.arange(T).view(1, T, 1) < lens.view(B, 1, 1))).half().view(B * T * U1, LD).contiguous().cuda()
+    f = torch.randn(B, T, H, generator=g).half().cuda()
+    gg = torch.randn(B, U1, H, generator=g).half().cuda()
+    scr = torch.empty(L.ia_joint_dw_fused_scratch_elems(B, T, U1, H, LD), device="cuda")
+    outs = []
+    for ln in (None, lens.cuda()):
+        dW = torch.empty(LD, H, device="cuda")
+        _lib.check(L.ia_joint_dw_fused(_lib.ptr(G), _lib.ptr(f), _lib.ptr(gg), _lib.ptr(ln), B, T, U1, H, LD, p, 7, _lib.ptr(dW),
+                                       _lib.ptr(scr), _lib.stream_ptr()), "ia_joint_dw_fused")
+        outs.append(dW)
+    torch.cuda.synchronize()
+    scale = outs[0].abs().max().item()
+    assert scale > 0
+    assert (outs[0] - outs[1]).abs().max().item() < 1e-5 * scale + 1e-7
