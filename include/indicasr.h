@@ -309,6 +309,14 @@ int ia_gemm_bnsilu_bf16(const float* z, int ldz, int64_t n_rows, const float* bn
                         int64_t* num_batches_tracked, float momentum, float eps, int training, const void* W, int ldw, int M,
                         int N, int K, const float* bias, float dropout_p, unsigned seed, float alpha, const float* R, int ldr,
                         float* outF, int ldof, void* outH, int ldoh, const long long* bn_sums_fixed, ia_stream_t stream);
+/* ... keeping SiLU(BN(z)) as well (outA [M,K] bf16, written by the first column tile): the trainable blocks' forward, whose
+ * backward needs it for the weight gradient of the pointwise convolution. */
+int ia_gemm_bnsilu_bf16_keep(const float* z, int ldz, int64_t n_rows, const float* bn_sum, const float* bn_sumsq,
+                             const float* gamma, const float* beta, float* running_mean, float* running_var,
+                             int64_t* num_batches_tracked, float momentum, float eps, int training, const void* W, int ldw, int M,
+                             int N, int K, const float* bias, float dropout_p, unsigned seed, float alpha, const float* R, int ldr,
+                             float* outF, int ldof, void* outH, int ldoh, const long long* bn_sums_fixed, void* outA, int ldoa,
+                             ia_stream_t stream);
 /* ia_glu_dwconv with the BatchNorm sums accumulated into 64-bit fixed-point integers (units of 2^-24; 8 copies of
  * [sum(d) | sumsq(d)] = 16 d values, the workgroups spread over the copies, the reader adds them; zeroed by the caller): deterministic without partial rows and a finishing launch.  ia_gemm_bnsilu_bf16 reads them through
  * `bn_sums_fixed` (then bn_sum / bn_sumsq may be NULL). */

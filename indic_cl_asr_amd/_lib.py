@@ -113,6 +113,8 @@ SIGNATURES = {
     "ia_gemm_bnsilu_supported": (_i, [_i]),
     "ia_gemm_bnsilu_bf16": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _i, _i, _i, _i, _vp, _f, _c.c_uint, _f,
                                  _vp, _i, _vp, _i, _vp, _i, _vp, _vp]),
+    "ia_gemm_bnsilu_bf16_keep": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _i, _i, _i, _i, _vp, _f, _c.c_uint,
+                                      _f, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp]),
     "ia_glu_dwconv_fixed": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "ia_dwconv_gated_fixed": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "ia_attn_vt_elems": (_sz, [_i, _i, _i]),

@@ -252,9 +252,15 @@ extern "C" int ia_conformer_block_fwd_phase(const ia_block_params* Lp, const flo
     }
     if (phase == 1) return IA_OK;
     const bool synced = phase == 2;
-    IA_TRY(ia_bn_silu(S.z, N, d, S.sums, S.sums + d, L.bn_g, L.bn_b, synced ? nullptr : L.bn_rm, synced ? nullptr : L.bn_rv,
-                      synced ? nullptr : L.bn_nbt, L.bn_momentum, L.bn_eps, 1, S.c3, stream));
-    IA_TRY(ia_gemm_bf16(S.c3, d, L.w_pw2, d, N, d, d, L.b_pw2, 0, p, seed + 4, 1.f, S.x2, d, S.x3, d, nullptr, 0, stream));
+    if (ia_gemm_bnsilu_supported(d)) {   // BatchNorm + SiLU while the pointwise convolution stages its A tile; c3 kept for the backward
+        IA_TRY(ia_gemm_bnsilu_bf16_keep(S.z, d, N, S.sums, S.sums + d, L.bn_g, L.bn_b, synced ? nullptr : L.bn_rm,
+                                        synced ? nullptr : L.bn_rv, synced ? nullptr : L.bn_nbt, L.bn_momentum, L.bn_eps, 1, L.w_pw2,
+                                        d, N, d, d, L.b_pw2, p, seed + 4, 1.f, S.x2, d, S.x3, d, nullptr, 0, nullptr, S.c3, d, stream));
+    } else {
+        IA_TRY(ia_bn_silu(S.z, N, d, S.sums, S.sums + d, L.bn_g, L.bn_b, synced ? nullptr : L.bn_rm, synced ? nullptr : L.bn_rv,
+                          synced ? nullptr : L.bn_nbt, L.bn_momentum, L.bn_eps, 1, S.c3, stream));
+        IA_TRY(ia_gemm_bf16(S.c3, d, L.w_pw2, d, N, d, d, L.b_pw2, 0, p, seed + 4, 1.f, S.x2, d, S.x3, d, nullptr, 0, stream));
+    }
     // 1/2 feed-forward
     IA_TRY(ia_layernorm(S.x3, d, N, d, L.ln_ff2_g, L.ln_ff2_b, L.ln_eps, nullptr, 0, nullptr, nullptr, S.y4, d, stream));
     IA_TRY(ia_gemm_bf16_ex(S.y4, d, L.w_ff2a, d, N, d_ff, d, L.b_ff2a, 1, pff, seed + 5, 1.f, nullptr, 0, nullptr, 0, S.h4, d_ff,

@@ -35,10 +35,12 @@ struct BsArgs {
     float* rm; float* rv; int64_t* nbt; float momentum, eps; int training; int64_t n_rows;
     const __bf16* W; int ldw; const float* bias; const float* R; int ldr;
     float* outF; int ldof; __bf16* outH; int ldoh;
+    __bf16* outA; int ldoa;   // optional: SiLU(BN(z)) itself, bf16 [M,K] (kept for a backward), written by the first column tile
     int M, N, K;
     float alpha; unsigned seed, thr; float keep_scale;
 };
 
+template <bool KEEP>   // KEEP: also write SiLU(BN(z)) to a.outA (first column tile)
 __global__ __launch_bounds__(BS_THREADS, 4) void gemm_bnsilu_kernel(BsArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* s_scale = reinterpret_cast<float*>(smem + BS_REGION);
@@ -119,6 +121,8 @@ __global__ __launch_bounds__(BS_THREADS, 4) void gemm_bnsilu_kernel(BsArgs a) {
             o_.u = make_uint2(0, 0);                                                                      \
         }                                                                                                 \
         *reinterpret_cast<uint2*>(smem + row_ * BS_ROWB + kq_ * 8) = o_.u;                                \
+        if (KEEP && n0 == 0 && m0 + row_ < a.M && kk_ < a.K)                                              \
+            *reinterpret_cast<uint2*>(a.outA + (size_t)(m0 + row_) * a.ldoa + kk_) = o_.u;                \
     } while (0)
 #define BS_STB(i_, v_)                                                                                    \
     do {                                                                                                  \
@@ -234,6 +238,18 @@ extern "C" int ia_gemm_bnsilu_bf16(const float* z, int ldz, int64_t n_rows, cons
                                    int M, int N, int K, const float* bias, float dropout_p, unsigned seed, float alpha,
                                    const float* R, int ldr, float* outF, int ldof, void* outH, int ldoh,
                                    const long long* bn_sums_fixed, ia_stream_t stream) {
+    return ia_gemm_bnsilu_bf16_keep(z, ldz, n_rows, bn_sum, bn_sumsq, gamma, beta, running_mean, running_var, num_batches_tracked,
+                                    momentum, eps, training, W, ldw, M, N, K, bias, dropout_p, seed, alpha, R, ldr, outF, ldof, outH,
+                                    ldoh, bn_sums_fixed, nullptr, 0, stream);
+}
+
+extern "C" int ia_gemm_bnsilu_bf16_keep(const float* z, int ldz, int64_t n_rows, const float* bn_sum, const float* bn_sumsq,
+                                        const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                        int64_t* num_batches_tracked, float momentum, float eps, int training, const void* W,
+                                        int ldw, int M, int N, int K, const float* bias, float dropout_p, unsigned seed,
+                                        float alpha, const float* R, int ldr, float* outF, int ldof, void* outH, int ldoh,
+                                        const long long* bn_sums_fixed, void* outA, int ldoa, ia_stream_t stream) {
+    if (outA && (ldoa % 4 != 0 || ldoa < K || !ia_is_aligned(outA, 8))) return IA_INVALID_VALUE;
     if (!z || !gamma || !beta || !W || (!outF && !outH) || M <= 0 || N <= 0 || n_rows <= 0) return IA_INVALID_VALUE;
     if (training ? (!bn_sums_fixed && (!bn_sum || !bn_sumsq)) : (!running_mean || !running_var)) return IA_INVALID_VALUE;
     if (!ia_gemm_bnsilu_supported(K)) return IA_UNSUPPORTED;
@@ -248,13 +264,14 @@ extern "C" int ia_gemm_bnsilu_bf16(const float* z, int ldz, int64_t n_rows, cons
     a.rm = running_mean; a.rv = running_var; a.nbt = num_batches_tracked; a.momentum = momentum; a.eps = eps;
     a.training = training; a.n_rows = n_rows;
     a.W = (const __bf16*)W; a.ldw = ldw; a.bias = bias; a.R = R; a.ldr = ldr; a.outF = outF; a.ldof = ldof;
-    a.outH = (__bf16*)outH; a.ldoh = ldoh; a.M = M; a.N = N; a.K = K; a.alpha = alpha; a.seed = seed;
+    a.outH = (__bf16*)outH; a.ldoh = ldoh; a.outA = (__bf16*)outA; a.ldoa = ldoa; a.M = M; a.N = N; a.K = K; a.alpha = alpha; a.seed = seed;
     a.thr = (unsigned)(dropout_p * 256.f + 0.5f);
     a.keep_scale = a.thr > 0 ? 256.f / (256.f - (float)a.thr) : 1.f;
     const int ntm = (M + BS_BM - 1) / BS_BM, ntn = (N + BS_BN - 1) / BS_BN;
     const int grid = 8 * ((ntm + 7) / 8) * ntn;
     const size_t lds = (size_t)BS_REGION + (size_t)2 * K * sizeof(float);
-    hipLaunchKernelGGL(gemm_bnsilu_kernel, dim3(grid), dim3(BS_THREADS), lds, (hipStream_t)stream, a);
+    if (outA) hipLaunchKernelGGL(gemm_bnsilu_kernel<true>, dim3(grid), dim3(BS_THREADS), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(gemm_bnsilu_kernel<false>, dim3(grid), dim3(BS_THREADS), lds, (hipStream_t)stream, a);
     IA_RETURN_IF_LAUNCH_FAILED();
     return IA_OK;
 }

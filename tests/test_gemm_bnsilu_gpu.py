@@ -38,8 +38,17 @@ def _run(M, d, N, training, p, seed=11):
                                      _lib.ptr(rv_b), _lib.ptr(nbt_b), 0.1, 1e-5, int(training), _lib.ptr(W), d, M, N, d, _lib.ptr(bias),
                                      float(p), seed, 1.0, _lib.ptr(xb), N, _lib.ptr(xb), N, _lib.ptr(yb), N, None, _lib.stream_ptr()),
                "ia_gemm_bnsilu_bf16")
+    # ... and the variant that keeps SiLU(BN(z)) for a backward
+    rm_c, rv_c, nbt_c = stats()
+    xc = x0.clone()
+    c3k = torch.empty(M, d, dtype=torch.bfloat16, device=dev)
+    _lib.check(L.ia_gemm_bnsilu_bf16_keep(_lib.ptr(z), d, M, _lib.ptr(s1), _lib.ptr(s2), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(rm_c),
+                                          _lib.ptr(rv_c), _lib.ptr(nbt_c), 0.1, 1e-5, int(training), _lib.ptr(W), d, M, N, d,
+                                          _lib.ptr(bias), float(p), seed, 1.0, _lib.ptr(xc), N, _lib.ptr(xc), N, None, 0, None,
+                                          _lib.ptr(c3k), d, _lib.stream_ptr()), "ia_gemm_bnsilu_bf16_keep")
     torch.cuda.synchronize()
     assert torch.equal(xa, xb)
+    assert torch.equal(xa, xc) and torch.equal(c3, c3k)
     assert torch.equal(yb, xb.bfloat16())
     assert torch.equal(rm_a, rm_b) and torch.equal(rv_a, rv_b) and torch.equal(nbt_a, nbt_b)
     # and against plain torch arithmetic (bf16 operands, fp32 accumulation)
