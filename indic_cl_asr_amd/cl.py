@@ -309,8 +309,18 @@ class FusedAdamW:
     exists -- the reference wraps the model in DDP but never arms its reducer."""
 
     def __init__(self, model_or_flat, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, group=None,
-                 bf16_shadow=None, defer_update=True):
+                 bf16_shadow=None, defer_update=True, grad_exchange_dtype=None):
+        """`grad_exchange_dtype="bf16"` ("fp32 or bf16"): the data-parallel exchange all-reduces a bf16 image of the
+        flat gradient (half the bytes over xGMI: 80 instead of 160 MB per step at 40 M trainable parameters); every rank
+        then applies AdamW to the same bf16-rounded sum, so the weights stay identical across ranks.  None: fp32 exchange."""
         self.flat = model_or_flat if isinstance(model_or_flat, FlatParams) else flat_of(model_or_flat)
+        if grad_exchange_dtype not in (None, "fp32", "bf16"):
+            raise ValueError("grad_exchange_dtype: None | 'fp32' | 'bf16'")
+        self.grad_exchange_dtype = None if grad_exchange_dtype == "fp32" else grad_exchange_dtype
+        self._g16 = None
+        self.profile_exchange = False     # bench.py: HIP events around the wait for the exchange (exposed time per step)
+        self.exchange_events = []
+        self.exchange_bytes = 0           # bytes handed to the last all-reduce
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.exp_avg = torch.zeros_like(self.flat.theta)
         self.exp_avg_sq = torch.zeros_like(self.flat.theta)
@@ -340,11 +350,28 @@ class FusedAdamW:
         else:
             self.flat.zero_grad()
 
+    def _exchange_buffer(self):
+        """The tensor the all-reduce runs on: the flat fp32 gradient itself, or its bf16 image (copied back by _exchange_done)."""
+        if self.grad_exchange_dtype == "bf16":
+            if self._g16 is None:
+                self._g16 = torch.empty_like(self.flat.grad, dtype=torch.bfloat16)
+            self._g16.copy_(self.flat.grad)
+            buf = self._g16
+        else:
+            buf = self.flat.grad
+        self.exchange_bytes = buf.numel() * buf.element_size()
+        return buf
+
+    def _exchange_done(self):
+        if self.grad_exchange_dtype == "bf16":
+            self.flat.grad.copy_(self._g16)
+
     def allreduce_grads(self):
         if dist.is_available() and dist.is_initialized():
             ws = dist.get_world_size(self.group)
             if ws > 1:
-                dist.all_reduce(self.flat.grad, group=self.group)
+                dist.all_reduce(self._exchange_buffer(), group=self.group)
+                self._exchange_done()
                 return 1.0 / ws
         return 1.0
 
@@ -361,7 +388,7 @@ class FusedAdamW:
         ws = self._world()
         gs = 1.0 if grad_scale is None else grad_scale
         if ws > 1 and self.defer_update:
-            work = dist.all_reduce(self.flat.grad, group=self.group, async_op=True)
+            work = dist.all_reduce(self._exchange_buffer(), group=self.group, async_op=True)
             self._pending = (work, gs / ws, self.flat.all_grads_live)
             _PENDING_OPTIMIZERS.add(self)
             return
@@ -373,7 +400,15 @@ class FusedAdamW:
         work, scale, live = self._pending
         self._pending = None
         _PENDING_OPTIMIZERS.discard(self)
-        work.wait()
+        if self.profile_exchange and self.flat.theta.is_cuda:   # how long the compute stream stalls for the exchange
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            work.wait()
+            e1.record()
+            self.exchange_events.append((e0, e1))
+        else:
+            work.wait()
+        self._exchange_done()
         self._apply(scale, live)
         if self._zero_after_flush:
             self._zero_after_flush = False

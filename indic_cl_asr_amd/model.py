@@ -109,15 +109,6 @@ class StepMonitor(dict):
         return super().__repr__()
 
 
-class _WerStub(nn.Module):
-    """Holds `log_prediction` (the scripts set it, R/cl_baseline.py:127-128).  Batch-WER inside the step is a
-    SURVEY §8(f) NEXT row (greedy decode + editdistance); until then the monitor carries NaN for it."""
-
-    def __init__(self):
-        super().__init__()
-        self.log_prediction = False
-
-
 class EncDecHybridRNNTCTCModel(TranscriptionMixin, nn.Module):
     def __init__(self, cfg: Optional[ModelConfig] = None, **kw):
         super().__init__()
@@ -132,8 +123,14 @@ class EncDecHybridRNNTCTCModel(TranscriptionMixin, nn.Module):
         self.ctc_decoder = ConvASRDecoder(cfg)
         self.ctc_loss = CTCLoss(num_classes=cfg.vocab_per_lang, zero_infinity=True, reduction='mean_batch')
         self.ctc_loss_weight = cfg.ctc_loss_weight
-        self.wer = _WerStub()
-        self.ctc_wer = _WerStub()
+        # metric objects with the reference's update / compute / reset surface (A/metrics/wer.py; hybrid_rnnt_ctc_bpe_models.py
+        # :126-149 builds them with log_prediction from the config, the CL scripts switch it off: R/cl_baseline.py:127-128)
+        from .metrics import WER
+        self.wer = WER(self, "rnnt", log_prediction=True)
+        self.ctc_wer = WER(self, "ctc", log_prediction=True)
+        # the reference decodes EVERY training batch for its monitor (compute_wer = True, hybrid_rnnt_ctc_models.py:875); here
+        # that is a switch: None -> follow the training_step argument (default off), True / False -> fixed
+        self.compute_wer_in_step = None
         self.cur_decoder = "rnnt"
         self.language_masks = self.ctc_decoder.language_masks
         self._step = 0
@@ -218,13 +215,20 @@ class EncDecHybridRNNTCTCModel(TranscriptionMixin, nn.Module):
 
     @torch.no_grad()
     def batch_wer(self, encoded, encoded_len, log_probs, transcript, transcript_len, language_ids):
-        from .decoding import greedy_ctc_decode, word_error_rate
+        """The step's two rates as the reference forms them: `training_batch_wer` = mean over the fused joint's sub-batches of
+        each sub-batch's (cross-rank) WER (A/modules/rnnt.py:1511-1553), a 0-dim tensor; `training_batch_wer_ctc` = the CTC
+        head's WER over the whole batch through ctc_wer.update / compute / reset (hybrid_rnnt_ctc_models.py:903-912), a float.
+        ONE device-resident greedy decode serves all sub-batches (utterances decode independently of their neighbours)."""
+        self.wer.bind(self); self.ctc_wer.bind(self)
         lens = transcript_len.tolist()
         refs = [row[:n] for row, n in zip(transcript.tolist(), lens)]
-        det = getattr(self, "detokenize", None)
-        wer = word_error_rate(self.decode(encoded.detach(), encoded_len, language_ids), refs, det)[0]
-        wer_ctc = word_error_rate(greedy_ctc_decode(log_probs.detach(), encoded_len), refs, det)[0]
-        return wer, wer_ctc
+        hyps = self.decode(encoded.detach(), encoded_len, language_ids)
+        wer, _, _ = self.wer.grouped(hyps, refs, language_ids, max(1, int(self.joint.fused_batch_size)))
+        self.ctc_wer.update(predictions=log_probs, predictions_lengths=encoded_len, targets=transcript,
+                            targets_lengths=transcript_len, lang_ids=language_ids)
+        ctc_wer, _, _ = self.ctc_wer.compute()
+        self.ctc_wer.reset()
+        return wer, ctc_wer.item()
 
     # ------------------------------------------------------------------ training_step (:859-930)
     def training_step(self, batch, lang_ids, return_probs=False, host_lengths=None, compute_wer=False):
@@ -322,7 +326,7 @@ class EncDecHybridRNNTCTCModel(TranscriptionMixin, nn.Module):
                 vals.append(flag); keys.append('_lstm_timeout')
         monitor = StepMonitor({'training_batch_wer': torch.tensor(float('nan')), 'training_batch_wer_ctc': float('nan')},
                               tuple(keys), torch.stack(vals))
-        if compute_wer:
+        if (self.compute_wer_in_step if self.compute_wer_in_step is not None else compute_wer):
             wer, wer_ctc = self.batch_wer(encoded, encoded_len, log_probs, transcript, transcript_len, language_ids)
             monitor['training_batch_wer'], monitor['training_batch_wer_ctc'] = wer, wer_ctc
         self._step += 1

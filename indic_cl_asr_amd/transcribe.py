@@ -141,6 +141,9 @@ class TranscriptionMixin:
 
     # -------------------------------------------------------------------------------------------------- transcribe
     def _ids_to_text(self, ids, language_id):
+        det = getattr(self, "detokenize", None)   # explicit ids -> str hook (data.MultilingualTokenizer.detokenizer(lang))
+        if det is not None:
+            return det(list(ids))
         if self.tokenizer is not None and language_id in getattr(self.tokenizer, "sp", {}):
             return self.tokenizer.ids_to_text(ids, language_id)
         return " ".join(str(int(i)) for i in ids)     # no SentencePiece model at hand: the token ids themselves

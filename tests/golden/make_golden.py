@@ -205,8 +205,49 @@ def module_cases():
     print("module_cases.npz:", len(out), "arrays")
 
 
+def _empty_packages(*names):
+    """Empty package objects (only `__path__`, so that sub-module FILES still resolve) for the packages whose
+    `__init__.py` pulls in hydra / lightning / numba: lets subsampling.py -- whose only blocker is the package-path
+    import of causal_convs -- load unmodified ('optional technique')."""
+    for name in names:
+        if name in sys.modules:
+            continue
+        mod = types.ModuleType(name)
+        mod.__path__ = [os.path.join(NEMO, *name.split("."))]
+        sys.modules[name] = mod
+
+
+def subsampling_cases():
+    """ConvSubsampling ('striding', x4) + calc_length (A/parts/submodules/subsampling.py:217-253,385-437,566-576) RUN
+    here on seeded inputs: pins SURVEY row a6 and the frame-count rule on the reference's own arithmetic."""
+    _asr_pkg_stubs()
+    import nemo.utils  # noqa: F401  (imports fine here: SURVEY 8(c))
+    _empty_packages("nemo.collections", "nemo.collections.asr", "nemo.collections.asr.parts",
+                    "nemo.collections.asr.parts.submodules")
+    sub = _load(os.path.join(NEMO, "nemo/collections/asr/parts/submodules/subsampling.py"), "ref_subsampling")
+    out = {}
+    torch.manual_seed(4321)
+    for tag, (feat_in, C, d, B, Tm) in {"a": (80, 16, 24, 3, 61), "b": (80, 8, 16, 2, 37)}.items():
+        m = sub.ConvSubsampling(subsampling="striding", subsampling_factor=4, feat_in=feat_in, feat_out=d, conv_channels=C,
+                                subsampling_conv_chunking_factor=1, activation=torch.nn.ReLU(True), is_causal=False)
+        m.eval()
+        x = torch.randn(B, Tm, feat_in)
+        lens = torch.tensor([Tm, max(1, Tm - 9), max(1, Tm // 2)][:B])
+        y, ylen = m(x, lens)
+        out[f"sub/{tag}/x"], out[f"sub/{tag}/lens"] = x, lens
+        out[f"sub/{tag}/y"], out[f"sub/{tag}/ylen"] = y.detach(), ylen
+        for n, p in m.named_parameters():
+            out[f"sub/{tag}/param/{n}"] = p.detach()
+    n = torch.arange(1, 3100)
+    out["calc_length/n"] = n
+    out["calc_length/out"] = sub.calc_length(n, all_paddings=2, kernel_size=3, stride=2, ceil_mode=False, repeat_num=2)
+    np.savez_compressed(os.path.join(HERE, "subsampling_cases.npz"), **{k: np.asarray(v) for k, v in out.items()})
+    print("subsampling_cases.npz:", len(out), "arrays")
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference not mounted; fixtures are generated in the build container only"
     extract_known_answers()
     rnnt_numpy_cases()
     module_cases()
+    subsampling_cases()

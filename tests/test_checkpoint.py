@@ -1,5 +1,6 @@
 """Checkpoint interchange: trainable-only .pth (R/utils.py:265-271), .nemo archive round trip
 (model_config.yaml + model_weights.ckpt), and the persisted continual-learning state."""
+import pytest
 import torch
 
 from indic_cl_asr_amd import checkpoint as ck
@@ -59,3 +60,49 @@ def test_cl_state_persists_and_checks_layout(tmp_path):
         assert False, "layout mismatch must be refused"
     except ValueError:
         pass
+
+
+@pytest.mark.gpu
+def test_nemo_archive_into_hip_model_step_matches_oracle(tmp_path):
+    """SURVEY 8(f).4 end to end on the device: an oracle's weights -> `.nemo` archive (model_config.yaml +
+    model_weights.ckpt, as save_restore_connector.py lays it out) -> checkpoint.model_from_nemo -> bf16 HIP model -> one
+    training step; losses and gradients against the oracle stepping on the weights the archive was written from."""
+    import math
+
+    from oracle import step_ref as S
+    from test_parity_configs_gpu import _grad_table, _synth
+    torch.manual_seed(21)
+    dims = dict(d_model=64, n_layers=3, n_heads=4, pred_hidden=64, joint_hidden=64, languages=['hi', 'ta'], vocab_per_lang=32,
+                fused_batch_size=2)
+    o = S.OracleHybridModel(**dims)
+    with torch.no_grad():
+        for l in o.encoder.layers:
+            l.self_attn.pos_bias_u.normal_(0, 0.1); l.self_attn.pos_bias_v.normal_(0, 0.1)
+    src = EncDecHybridRNNTCTCModel(model_config('tiny', compute_dtype='fp32', dither=0.0, **{k: v for k, v in dims.items()}))
+    src.load_state_dict(o.state_dict())
+    p = tmp_path / "oracle.nemo"
+    ck.write_nemo(src, p)
+    m, rep = ck.model_from_nemo(p, strict=True, languages=dims['languages'], vocab_per_lang=dims['vocab_per_lang'],
+                                compute_dtype='bf16', dither=0.0)
+    assert not rep.missing_keys and not rep.unexpected_keys
+    assert (m.cfg.d_model, m.cfg.n_layers, m.cfg.pred_hidden, m.cfg.fused_batch_size) == (64, 3, 64, 2)
+    m = m.disable_dropout().cuda().train()
+    m.spec_augment_enabled = False
+    S.freeze_layer(o, 1); freeze_layer(m, 1); m.encoder.encoder_frozen_till = 1
+    o.train()
+    batch = _synth(3, 4.0, seed=9, vocab=32)
+    lo, mo = o.training_step(batch, ['ta'] * 3)
+    lo.backward()
+    lp, mp = m.training_step(tuple(t.cuda() for t in batch), ['ta'] * 3)
+    lp.backward()
+    torch.cuda.synchronize()
+    for k in ('train_rnnt_loss', 'train_ctc_loss', 'train_loss'):
+        assert math.isclose(mp[k], mo[k], rel_tol=1e-3), (k, mp[k], mo[k])
+    rows = _grad_table(m, o, min_checked=40)
+    assert rows[0][0] <= 0.05, rows[:3]
+    # ... and the trainable-only .pth of R/utils.py:265-271 written from the device model loads back into the oracle
+    q = tmp_path / "task.pth"
+    ck.save_trainable(m, q)
+    st = torch.load(q)
+    assert set(st) == {n for n, prm in o.named_parameters() if prm.requires_grad}
+    assert not o.load_state_dict(st, strict=False).unexpected_keys

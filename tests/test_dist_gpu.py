@@ -1,4 +1,5 @@
-"""Data-parallel step on the GPU with two ranks (gloo over 127.0.0.1, both ranks on cuda:0): the deferred optimizer update
+"""Data-parallel step on the GPU with two ranks -- one rank per device over RCCL (backend "nccl") when the box shows two
+or more GPUs, otherwise the rehearsal of the same path with both ranks on cuda:0 over gloo: the deferred optimizer update
 (gradient all-reduce launched asynchronously in FusedAdamW.step, AdamW applied right before the first trainable module of
 the next forward) must leave exactly the weights of the immediate update, identical on both ranks."""
 import os
@@ -14,6 +15,19 @@ pytestmark = pytest.mark.gpu
 
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _init(rank, world, port):
+    """RCCL with one rank per device when the box has enough devices (device_count() does not initialise the GPU), else
+    gloo with every rank on cuda:0 (one-GPU boxes: the collectives then go through host memory, the HIP path is the same)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    if torch.cuda.device_count() >= world:
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+        return "nccl"
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    return "gloo"
 
 
 def _batch(rank, step, B=3, L=12000, U=8):
@@ -49,9 +63,7 @@ def _run(rank, defer):
 
 
 def _worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _init(rank, world, port)
     th_now, l_now, n_now = _run(rank, defer=False)
     th_def, l_def, n_def = _run(rank, defer=True)
     same_modes = bool(torch.equal(th_now, th_def)) and l_now == l_def and n_now == n_def == 3
@@ -130,9 +142,7 @@ def _encoder_pass(m, sig, sl, R):
 
 
 def _sync_worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _init(rank, world, port)
     m, sig, sl, R = _sync_setup()
     m = torch.nn.SyncBatchNorm.convert_sync_batchnorm(m)
     assert isinstance(m.encoder.layers[0].conv.batch_norm, torch.nn.SyncBatchNorm)
@@ -182,3 +192,85 @@ def test_sync_batchnorm_two_ranks_equal_single_process_union_batch():
         for v2, v1 in zip(r[5], rvs1):
             assert torch.allclose(v2, v1.cpu(), rtol=2e-2, atol=1e-4)
         assert r[6] == nbt1
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The wrapping the CL scripts apply (R/cl_baseline.py:133-134): SyncBatchNorm.convert_sync_batchnorm, then
+# DistributedDataParallel(model, device_ids=[local_rank]), then `model.module.training_step` (:190) with ONE optimizer over
+# model.parameters().  The model's parameters are views of cl.FlatParams' flat buffers: they must survive both wraps, the
+# HIP paths must stay selected, and the ranks must end with identical weights (with the fp32 and the bf16 exchange).
+def _ddp_worker(rank, world, port, q):
+    try:
+        backend = _init(rank, world, port)
+        from indic_cl_asr_amd import cl
+        from indic_cl_asr_amd.config import model_config
+        from indic_cl_asr_amd.model import EncDecHybridRNNTCTCModel, freeze_layer
+        out = {}
+        for exch in (None, "bf16"):
+            torch.manual_seed(50 + rank)            # DIFFERENT initial weights per rank: DDP's constructor broadcasts rank 0's
+            cfg = model_config('tiny', d_model=128, n_layers=3, n_heads=2, pred_hidden=64, joint_hidden=64, languages=['hi', 'ta'],
+                               vocab_per_lang=16, fused_batch_size=2, compute_dtype='bf16', dither=0.0)
+            m = EncDecHybridRNNTCTCModel(cfg).disable_dropout().cuda()
+            m.spec_augment_enabled = False
+            freeze_layer(m, 0); m.encoder.encoder_frozen_till = 0
+            m.ctc_wer.log_prediction = False; m.wer.log_prediction = False          # R/cl_baseline.py:127-128
+            model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(m)
+            dev = torch.cuda.current_device()
+            model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev], output_device=dev)
+            model.train()
+            opt = cl.FusedAdamW(model, lr=1e-2, grad_exchange_dtype=exch)
+            assert isinstance(model.module.encoder.layers[0].conv.batch_norm, torch.nn.SyncBatchNorm)
+            th0 = cl.get_params_clone(model).flat.clone()
+            losses = []
+            for step in range(3):
+                batch = _batch(rank, step)
+                opt.zero_grad()
+                loss, monitor = model.module.training_step(batch, ['hi'] * len(batch[0]), compute_wer=(step == 2))
+                loss.backward()
+                opt.step()
+                losses.append(monitor['train_loss'])
+            wer = float(monitor['training_batch_wer'])
+            th = cl.get_params_clone(model).flat.clone()
+            both = [torch.empty_like(th) for _ in range(world)]
+            dist.all_gather(both, th)
+            both0 = [torch.empty_like(th0) for _ in range(world)]
+            dist.all_gather(both0, th0)
+            wers = [torch.zeros(1, device="cuda") for _ in range(world)]
+            dist.all_gather(wers, torch.tensor([wer], device="cuda"))
+            views = dict(model.module.named_parameters())
+            out[str(exch)] = dict(
+                same_start=bool(torch.equal(both0[0], both0[1])), same_end=bool(torch.equal(both[0], both[1])),
+                moved=float((th - th0).abs().max()), finite=all(l == l for l in losses),
+                views=all(views[n].data_ptr() == opt.flat.params_dict()[n].data_ptr() for n in opt.flat.names),
+                wer_same=bool(torch.equal(wers[0], wers[1])), wer=wer, steps=opt.step_count, bytes=opt.exchange_bytes,
+                numel=opt.flat.numel)
+        q.put((rank, backend, out, None))
+    except Exception:
+        import traceback
+        q.put((rank, "?", None, traceback.format_exc()))
+        raise
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_syncbn_plus_ddp_wrapped_model_trains_identically_on_two_ranks():
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=300) for _ in ps]
+    for p in ps:
+        p.join(60)
+    for rank, backend, out, err in res:
+        assert err is None, err
+        for exch, r in out.items():
+            assert r["same_start"], (exch, "DDP did not broadcast rank 0's weights into the flat buffer")
+            assert r["same_end"], (exch, "ranks diverged")
+            assert r["moved"] > 0 and r["finite"] and r["views"] and r["steps"] == 3, (exch, r)
+            assert r["wer_same"] and r["wer"] == r["wer"], (exch, r)     # the step's WER is the cross-rank rate on every rank
+            assert r["bytes"] == r["numel"] * (2 if exch == "bf16" else 4), (exch, r)
+    for p in ps:
+        assert p.exitcode == 0

@@ -64,3 +64,32 @@ def test_reference_config_yaml_parses_with_overrides(tmp_path):
     cfg = override_config_with_args(cfg, ["--cl_config.e_lambda", "5", "--mixed_precision", "true", "--batch_size", "32"])
     assert cfg.cl_config.e_lambda == 5 and cfg.mixed_precision is True and cfg.batch_size == 32
     assert cfg.model.freeze_encoder_till == 12
+
+
+def test_mixed_precision_key_selects_the_compute_dtype_and_the_scaler_is_scale_one():
+    """R/config.yaml `mixed_precision` -> compute dtype (amp.py), and the GradScaler calls of R/cl_baseline.py:181-196 with
+    scale 1 (identity on the loss, step == optimizer.step)."""
+    import pytest
+    from indic_cl_asr_amd import amp
+    from indic_cl_asr_amd.config import AttrDict, model_config
+    assert amp.compute_dtype_from(AttrDict(mixed_precision=True)) == "bf16"
+    assert amp.compute_dtype_from(AttrDict(mixed_precision=False)) == "fp32"
+    assert amp.compute_dtype_from({}) == "fp32"
+    assert model_config("tiny", compute_dtype=amp.compute_dtype_from({"mixed_precision": True})).compute_dtype == "bf16"
+    sc = amp.GradScaler()
+    x = torch.tensor(3.0, requires_grad=True)
+    assert sc.scale(x) is x and sc.get_scale() == 1.0
+
+    class Opt:
+        n = 0
+
+        def step(self):
+            self.n += 1
+            return "stepped"
+    o = Opt()
+    assert sc.step(o) == "stepped" and o.n == 1
+    sc.update(); sc.unscale_(o)
+    with amp.autocast(device_type="cuda", enabled=True):
+        pass
+    with pytest.raises(ValueError):
+        amp.GradScaler(init_scale=65536.0)

@@ -128,6 +128,30 @@ def test_config2_medium_bf16_step_matches_oracle():
     assert int(bp.num_batches_tracked) == int(bo.num_batches_tracked) == 1
 
 
+def test_config2_full_benchmarked_batch_32x15s_matches_oracle():
+    """BASELINE configs[1] AT ITS FULL SIZE: the batch bench.py times (32 utterances x 15 s from bench.synth_batch's recipe,
+    Conformer-medium, layers <= 12 frozen, bf16 projections, f16 fused joint, 8 sub-batches of 4) against the fp32 oracle on the
+    same weights -- losses and every trainable tensor's gradient (the oracle needs about a minute of the box's host cores)."""
+    o, m = _pair('medium', freeze=12)
+    batch = _synth(32, 15.0, seed=1234)
+    o.train(); m.train()
+    lo, mo = o.training_step(batch, ['hi'] * 32)
+    lo.backward()
+    cb = tuple(t.cuda() for t in batch)
+    lp, mp = m.training_step(cb, ['hi'] * 32)
+    lp.backward()
+    torch.cuda.synchronize()
+    errs = _check_losses(mp, mo, 1e-3)            # north_star bound at the benchmarked size and dtype
+    assert max(errs.values()) <= 3e-4, errs       # (the 4-utterance test observes 1e-5 .. 5e-5)
+    rows = _grad_table(m, o, min_checked=3 * 30 + 8)
+    print("worst gradient tensors (relative L2 vs fp32 oracle), 32 x 15 s:")
+    for e, n in rows[:6]:
+        print(f"  {e:.3e}  {n}")
+    print("median", f"{rows[len(rows) // 2][0]:.3e}")
+    assert rows[0][0] <= 0.04, rows[0]
+    assert rows[len(rows) // 2][0] <= 0.01
+
+
 # ------------------------------------------------------------------------------------------------ configs[2]
 def test_config3_mas_importance_pass_medium_dims():
     from indic_cl_asr_amd import cl

@@ -22,3 +22,30 @@ def test_conv_subsampling_matches_the_module(C, d, B, Tm):
         out = fast.conv_subsampling(x, m.conv[0], m.conv[2], m.out).view(ref.shape)
     err = (out - ref).abs().max().item()
     assert err <= 2e-2 * ref.abs().max().item(), (err, ref.abs().max().item())   # bf16 operands through two convolutions + Linear
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_conv_subsampling_hip_matches_reference_file_outputs(tag):
+    """The HIP path against what the REFERENCE's own subsampling.py returned on seeded inputs (tests/golden/
+    subsampling_cases.npz, made by tests/golden/make_golden.py: the file loaded unmodified behind empty package stubs)."""
+    import os
+
+    import numpy as np
+    from conftest import GOLDEN
+    from indic_cl_asr_amd.encoder import ConvSubsampling, subsampled_length
+    from indic_cl_asr_amd.ops import fast
+    Z = np.load(os.path.join(GOLDEN, "subsampling_cases.npz"))
+    pre = f"sub/{tag}/param/"
+    sd = {k[len(pre):]: torch.tensor(Z[k]) for k in Z.files if k.startswith(pre)}
+    C, d = sd["conv.0.weight"].shape[0], sd["out.weight"].shape[0]
+    x, want = torch.tensor(Z[f"sub/{tag}/x"]), torch.tensor(Z[f"sub/{tag}/y"])
+    m = ConvSubsampling(x.shape[-1], d, C)
+    m.load_state_dict(sd)
+    m = m.cuda()
+    assert fast.subsample_supported(C, d, x.shape[-1])
+    with torch.no_grad():
+        out = fast.conv_subsampling(x.transpose(1, 2).contiguous().cuda(), m.conv[0], m.conv[2], m.out).view(want.shape)
+    err = (out.cpu() - want).abs().max().item()
+    assert err <= 2e-2 * want.abs().max().item(), (err, want.abs().max().item())   # bf16 operands (see the test above)
+    lens = torch.tensor(Z[f"sub/{tag}/lens"])
+    assert torch.equal(subsampled_length(lens), torch.tensor(Z[f"sub/{tag}/ylen"]).long())
