@@ -229,6 +229,11 @@ int ia_gemm_bf16(const void* A, int lda, const void* W, int ldw, int M, int N, i
 int ia_gemm_bf16_ex(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const float* bias, int act,
                     float dropout_p, unsigned seed, float alpha, const float* R, int ldr, float* outF, int ldof, void* outH,
                     int ldoh, void* out_pre, int ldpre, const void* aux, int ldaux, ia_stream_t stream);
+/* ... with `flags`: bit 0 = outH holds IEEE half instead of bf16 (the joint's f16 operands f = enc(x), g = pred(dec) come
+ * straight out of their projections, rnnt.py:1590-1596: no cast pass). */
+int ia_gemm_bf16_ex2(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const float* bias, int act,
+                     float dropout_p, unsigned seed, float alpha, const float* R, int ldr, float* outF, int ldof, void* outH,
+                     int ldoh, void* out_pre, int ldpre, const void* aux, int ldaux, int flags, ia_stream_t stream);
 /* ConvSubsampling 'striding' x4 (A/parts/submodules/subsampling.py:217-253,385-437), channels-last, no transposes:
  *   ia_subsample_conv1: feats [B,Fm,Tm] f32 (preprocessor layout) -> relu(conv 1->C, 3x3, s2, p1) as [B,T1,F1,C] bf16
  *                       (w1 [C,9] f32 = conv.0.weight, b1 [C]); T1 = (Tm-1)/2+1, F1 = (Fm-1)/2+1.
@@ -704,6 +709,70 @@ int ia_adamw_step_segmented(float* theta, const float* grad, float* exp_avg, flo
                             int nchunks, int32_t* seg_active, int32_t* seg_step, int nseg, int all_active, float lr,
                             float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* shadow_bf16,
                             ia_stream_t stream);
+
+/* ---- CTC head + loss on RAW logits (ConvASRDecoder.forward + CTCLoss.forward, A/modules/conv_asr.py:459-490 and
+ * A/losses/ctc.py:68-82, without the [B,T,V] log-prob tensor and without a softmax backward pass): logits [B*T, ld] f32 with V
+ * valid columns (the head GEMM's padded output), lse [B*T] = per-frame log-sum-exp over the V columns (ia_ctc_row_lse).
+ * ia_ctc_backward_logits writes grad_scale * nll_grad[b] * (softmax - occupancy) as bf16 [B*T, ldg] with zero padding columns
+ * (the A operand of the head's data / weight gradient GEMMs); same workspace as ia_ctc_forward. */
+int ia_ctc_row_lse(const float* logits, int ld, int64_t M, int V, float* lse, ia_stream_t stream);
+int ia_ctc_forward_logits(const float* logits, int ld, const float* lse, const int64_t* targets, const int64_t* input_lens,
+                          const int64_t* target_lens, int B, int T, int V, int S, int blank, int zero_infinity, float* nll,
+                          void* workspace, size_t workspace_bytes, ia_stream_t stream);
+int ia_ctc_backward_logits(const float* logits, int ld, const float* lse, const int64_t* targets, const int64_t* input_lens,
+                           const int64_t* target_lens, int B, int T, int V, int S, int blank, const float* nll_grad,
+                           float grad_scale, void* grad_bf16, int ldg, void* workspace, size_t workspace_bytes, ia_stream_t stream);
+
+/* ---- Glue of the step's tail (csrc/tail_ops.hip): each replaces a handful of small ATen launches.
+ * ia_select_rows_cast  rows [row0, row0+nrows) (+ extra_row if >= 0) of W [*, K] f32 (row stride ldw), times `scale`, as a 16-bit
+ *                      operand out [rows_out, K] (bf16, or f16 when out_f16; rows beyond the selection zero); optionally the
+ *                      transpose outT [K, ldt] (ldt >= rows_out, padding zero) and the selected bias entries bias_out [rows_out]:
+ *                      the language's 256 + blank rows of the 5633-wide CTC head (conv_asr.py:469-480) / the language head of the
+ *                      joint with the dropout scale folded in (rnnt.py:1632-1640).
+ * ia_rows_scatter_add  dst[row] += scale * src[i] over the same row selection (+ bias): the backward of that selection.
+ * ia_loss_combine      out4 = [mean(costs), mean(nll), (1-w) mean(costs) + w mean(nll), #non-zero flag words]; `total` (optional,
+ *                      one float) receives out4[2] as well (the autograd-visible scalar)
+ *                      (hybrid_rnnt_ctc_models.py:899-913; flags: the persistent LSTM's sticky timeout words, may be NULL).
+ * ia_loss_combine_bwd  g_costs[b] = gout (1-w)/B, g_nll[b] = gout w/B  (gout NULL = 1).
+ * ia_embed_sos         prediction-network input (rnnt.py:734-751): out[(b,0)] = 0, out[(b,u)] = E[tokens[b,u-1]]; time_major
+ *                      selects [U+1,B,H] (LSTM operand) or [B,U+1,H]; f32 or bf16.
+ * ia_embed_sos_bwd     dE[row] += scale * sum of the dX (f32, or bf16 when dx_bf16) rows that read it (tokens scanned in order: deterministic; rows >=
+ *                      n_rows never referenced; pad_row skipped as nn.Embedding(padding_idx) does).
+ * ia_multi_axpy        dst_i += scale_i * src_i for a HOST array of ia_axpy_row (device pointers inside; the rows travel as kernel
+ *                      arguments, 24 per launch): AccumulateGrad of several parameters in one launch. */
+typedef struct ia_axpy_row {
+    float* dst; const float* src; long long n; float scale; int pad;
+} ia_axpy_row;
+/* ia_transpose16_multi  out_i [cols, rows] = in_i [rows, cols]^T for up to 8 matrices of 16-bit elements (bf16 / f16; rows, cols
+ *                      multiples of 8) in ONE launch: the weight images W^T the data-gradient GEMMs of the tail read.
+ * ia_swap01_cast       out[j][i][:] = in[i][j][:] for in [n0, n1, H] f32 -> out [n1, n0, H] (bf16 when out_bf16 else f32), or
+ *                      with in_bf16 a bf16 input: the prediction network's time-major <-> the joint's batch-major layout. */
+typedef struct ia_tr_job { const void* in; void* out; int rows, cols; } ia_tr_job;
+int ia_transpose16_multi(const ia_tr_job* jobs_host, int njobs, ia_stream_t stream);
+int ia_swap01_cast(const void* in, int in_bf16, int n0, int n1, int H, void* out, int out_bf16, ia_stream_t stream);
+int ia_select_rows_cast(const float* W, int ldw, const float* bias, int row0, int nrows, int extra_row, int K, int rows_out,
+                        float scale, int out_f16, void* out, void* outT, int ldt, float* bias_out, ia_stream_t stream);
+int ia_rows_scatter_add(float* dst, int ldd, const float* src, int lds, int row0, int nrows, int extra_row, int K, float scale,
+                        float* bias_dst, const float* bias_src, ia_stream_t stream);
+int ia_loss_combine(const float* costs, const float* nll, int B, float ctc_weight, const int* flag0, const int* flag1,
+                    const int* flag2, const int* flag3, float* out4, float* total, ia_stream_t stream);
+int ia_loss_combine_bwd(const float* gout, int B, float ctc_weight, float* g_costs, float* g_nll, ia_stream_t stream);
+int ia_embed_sos(const float* E, const int64_t* tokens, int B, int U, int H, int n_rows, int time_major, int out_bf16, void* out,
+                 ia_stream_t stream);
+int ia_embed_sos_bwd(const void* dX, int dx_bf16, const int64_t* tokens, int B, int U, int H, int n_rows, int pad_row,
+                     int time_major, float scale, float* dE, ia_stream_t stream);
+int ia_multi_axpy(const ia_axpy_row* rows_host, int nrows, int max_blocks_per_row, ia_stream_t stream);
+
+/* ---- Peaks measured on the box ("peaks measured on the box with a streaming-copy and an MFMA
+ * microbenchmark"); no reference counterpart -- bench.py prices its roofline fractions against these and the datasheet.
+ * ia_peak_stream_copy   16-byte-per-lane copy src -> dst (bytes % 16 == 0): 2 x bytes of HBM traffic per launch.
+ * ia_peak_mfma_bf16     `workgroups` x 4 waves, each `iters` x 8 back-to-back v_mfma_f32_16x16x32_bf16 on register operands
+ *                       (non-trivial values); sink: >= workgroups * 256 floats (never written in practice).
+ * ia_peak_mfma_bf16_flops  FLOPs one such launch performs (pure host function).
+ */
+int ia_peak_stream_copy(const void* src, void* dst, size_t bytes, ia_stream_t stream);
+int ia_peak_mfma_bf16(float* sink, int workgroups, int iters, ia_stream_t stream);
+double ia_peak_mfma_bf16_flops(int workgroups, int iters);
 
 #ifdef __cplusplus
 }

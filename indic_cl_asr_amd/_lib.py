@@ -54,6 +54,22 @@ class BlockGrads(_c.Structure):
 
 SIGNATURES = {
     "ia_version": (_c.c_char_p, []),
+    "ia_gemm_bf16_ex2": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _f, _c.c_uint, _f, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp]),
+    "ia_transpose16_multi": (_i, [_vp, _i, _vp]),
+    "ia_swap01_cast": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    "ia_ctc_row_lse": (_i, [_vp, _i, _i64, _i, _vp, _vp]),
+    "ia_ctc_forward_logits": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "ia_ctc_backward_logits": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _f, _vp, _i, _vp, _sz, _vp]),
+    "ia_select_rows_cast": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _i, _vp, _vp]),
+    "ia_rows_scatter_add": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
+    "ia_loss_combine": (_i, [_vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ia_loss_combine_bwd": (_i, [_vp, _i, _f, _vp, _vp, _vp]),
+    "ia_embed_sos": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "ia_embed_sos_bwd": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp]),
+    "ia_multi_axpy": (_i, [_vp, _i, _i, _vp]),
+    "ia_peak_stream_copy": (_i, [_vp, _vp, _sz, _vp]),
+    "ia_peak_mfma_bf16": (_i, [_vp, _i, _i, _vp]),
+    "ia_peak_mfma_bf16_flops": (_c.c_double, [_i, _i]),
     "ia_rnnt_workspace_bytes": (_sz, [_i, _i, _i]),
     "ia_rnnt_loss": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _sz, _vp]),
     "ia_rnnt_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _sz, _vp]),

@@ -40,6 +40,7 @@ class FlatParams:
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
         if not named:
             raise ValueError("model has no trainable parameters")
+        named = _qkv_adjacent(named)
         dev = named[0][1].device
         self.model = model
         self.entries, off = [], 0
@@ -112,6 +113,28 @@ class FlatParams:
             for n, p in zip(self.names, self.params):
                 p.data = self._theta_views[n]
             fast.bump_weight_epoch()
+
+
+def _qkv_adjacent(named):
+    """Layout order of the flat buffers: as named_parameters(), except that each attention module's linear_q | linear_k | linear_v
+    weights (and then their biases) are placed back to back, so the [3d, d] operand of the fused Q/K/V projection and its bias
+    are VIEWS of the flat weight / bf16 shadow buffers (ops/fast.bf16_shadow, f32_cat) instead of three-way concatenations
+    rebuilt after every optimizer step.  The dict-of-names surface (FlatDict) does not depend on the order."""
+    by_name = dict(named)
+    order, done = [], set()
+    for n, p in named:
+        if n in done:
+            continue
+        if n.endswith("linear_q.weight") or n.endswith("linear_q.bias"):
+            kind = n.rsplit(".", 1)[1]
+            stem = n[: -len("linear_q." + kind)]
+            group = [stem + f"linear_{x}.{kind}" for x in ("q", "k", "v")]
+            if all(g in by_name for g in group):
+                for g in group:
+                    order.append((g, by_name[g])); done.add(g)
+                continue
+        order.append((n, p)); done.add(n)
+    return order
 
 
 def flat_of(model) -> FlatParams:

@@ -33,6 +33,7 @@ struct GemmArgs {
                         // to the rounded value: what a separate elementwise pass over outPre would compute)
     const __bf16* aux;  // act == 3: out = bf16(acc) * SiLU'(aux) -- the data gradient through dropout(SiLU(.)) in one pass
     int M, N, K, lda, ldw, ldr, ldof, ldoh, ldpre, ldaux;
+    int out_f16;        // outH holds IEEE half instead of bf16 (the joint's f16 operands come straight out of its projections)
     int act;            // 0 none, 1 SiLU, 2 ReLU, 3 SiLU backward against aux
     float alpha;
     unsigned seed, thr; // dropout keep if byte >= thr (thr = round(256 p)); scale 1/(1-thr/256) folded in `alpha_keep`
@@ -259,10 +260,17 @@ __global__ __launch_bounds__(G_THREADS, (BM == 128 ? 3 : 4)) void gemm_bf16_nt_k
             *reinterpret_cast<float4*>(a.outF + (size_t)gm * a.ldof + gn + 4) = make_float4(v[4], v[5], v[6], v[7]);
         }
         if (a.outH) {
-            union { uint4 u; __bf16 h[8]; } o;
+            if (a.out_f16) {
+                union { uint4 u; _Float16 h[8]; } o;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o.h[j] = (__bf16)v[j];
-            *reinterpret_cast<uint4*>(a.outH + (size_t)gm * a.ldoh + gn) = o.u;
+                for (int j = 0; j < 8; ++j) o.h[j] = (_Float16)v[j];
+                *reinterpret_cast<uint4*>(a.outH + (size_t)gm * a.ldoh + gn) = o.u;
+            } else {
+                union { uint4 u; __bf16 h[8]; } o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o.h[j] = (__bf16)v[j];
+                *reinterpret_cast<uint4*>(a.outH + (size_t)gm * a.ldoh + gn) = o.u;
+            }
         }
     }
     }
@@ -295,6 +303,14 @@ extern "C" int ia_gemm_bf16_ex(const void* A, int lda, const void* W, int ldw, i
                                int act, float dropout_p, unsigned seed, float alpha, const float* R, int ldr, float* outF,
                                int ldof, void* outH, int ldoh, void* outPre, int ldpre, const void* aux, int ldaux,
                                ia_stream_t stream) {
+    return ia_gemm_bf16_ex2(A, lda, W, ldw, M, N, K, bias, act, dropout_p, seed, alpha, R, ldr, outF, ldof, outH, ldoh, outPre, ldpre, aux,
+                            ldaux, 0, stream);
+}
+
+extern "C" int ia_gemm_bf16_ex2(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const float* bias,
+                                int act, float dropout_p, unsigned seed, float alpha, const float* R, int ldr, float* outF,
+                                int ldof, void* outH, int ldoh, void* outPre, int ldpre, const void* aux, int ldaux, int flags,
+                                ia_stream_t stream) {
     if (!A || !W || (!outF && !outH) || M <= 0 || N <= 0 || K <= 0) return IA_INVALID_VALUE;
     if ((act == 3) != (aux != nullptr)) return IA_INVALID_VALUE;
     if ((outPre && (ldpre % 8 != 0 || !ia_is_aligned(outPre, 16))) || (aux && (ldaux % 8 != 0 || !ia_is_aligned(aux, 16)))) return IA_UNSUPPORTED;
@@ -310,6 +326,8 @@ extern "C" int ia_gemm_bf16_ex(const void* A, int lda, const void* W, int ldw, i
     a.outPre = (__bf16*)outPre; a.aux = (const __bf16*)aux; a.ldpre = ldpre; a.ldaux = ldaux;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldr = ldr; a.ldof = ldof; a.ldoh = ldoh;
     a.act = act; a.alpha = alpha; a.seed = seed;
+    a.out_f16 = (flags & 1) ? 1 : 0;
+    if (a.out_f16 && act == 4) return IA_INVALID_VALUE;
     a.thr = (unsigned)(dropout_p * 256.f + 0.5f);
     a.keep_scale = a.thr > 0 ? 256.f / (256.f - (float)a.thr) : 1.f;
     a.cT1 = a.cF1 = a.cC = a.cT2 = a.cF2 = 0;
@@ -418,6 +436,6 @@ extern "C" int ia_subsample_conv2(const void* in_cl, int B, int T1, int F1, int 
     a.outPre = nullptr; a.aux = nullptr; a.ldpre = 0; a.ldaux = 0;
     a.cT1 = T1; a.cF1 = F1; a.cC = C; a.cT2 = (T1 - 1) / 2 + 1; a.cF2 = (F1 - 1) / 2 + 1;
     a.M = B * a.cT2 * a.cF2; a.N = N; a.K = 9 * C; a.lda = 0; a.ldw = 9 * C; a.ldr = 0; a.ldof = 0; a.ldoh = N;
-    a.act = 2; a.alpha = 1.f; a.seed = 0; a.thr = 0; a.keep_scale = 1.f;
+    a.act = 2; a.alpha = 1.f; a.seed = 0; a.thr = 0; a.keep_scale = 1.f; a.out_f16 = 0;
     return launch_gemm<128, 128, true>(a, (hipStream_t)stream);
 }

@@ -83,6 +83,18 @@ class RNNTDecoder(nn.Module):
     def forward(self, targets, target_length, states=None):
         _flush_pending()
         y = label_collate(targets)
+        rnn, emb = self.prediction["dec_rnn"], self.prediction["embed"]
+        from .ops import lstm as hip_lstm
+        if (states is None and rnn.use_hip and y.is_cuda and y.shape[1] > 0
+                and hip_lstm.lstm_supported(emb.weight, rnn.lstm.hidden_size)):
+            # training step on the MI355X: zero SOS row + embedding rows written time-major in bf16 by one launch (ops/tail.py),
+            # straight into the persistent LSTM; its output [U+1,B,H] is handed on as a [B,H,U+1] VIEW (no transpose copy)
+            from .ops import tail
+            xb = tail.embed_sos(emb.weight, y, pad_row=emb.padding_idx if emb.padding_idx is not None else -1)
+            g = hip_lstm.lstm_forward(xb, rnn.lstm)                  # [U+1, B, H] f32
+            if rnn.dropout:
+                g = rnn.dropout(g)
+            return g.permute(1, 2, 0), target_length, None           # (B, H, U+1)
         g, states = self.predict(y, state=states, add_sos=True, need_state=False)  # (B, U+1, H)
         return g.transpose(1, 2), target_length, states          # (B, H, U+1)
 
@@ -112,6 +124,10 @@ class RNNTJoint(nn.Module):
         self.use_fused = True
         self.loss_scale_hint = 1.0   # expected |d loss / d cost_b| (set by the model: (1-ctc_w)/B)
         self.dropout_seed = 0
+        # training_step sets return_costs: the fused path then leaves the per-utterance costs [B] in last_costs and returns no
+        # reduced loss -- ops/tail.loss_combine forms (1-w) mean(costs) + w mean(nll) and the monitor's values in one launch
+        self.return_costs = False
+        self.last_costs = None
 
     @property
     def loss(self):
@@ -230,18 +246,34 @@ class RNNTJoint(nn.Module):
             if isinstance(m, nn.Dropout) and self.training:
                 p = float(m.p)
         from .ops import fast
-        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
-            # (fast.linear: HIP GEMM forward, weight + bias gradient on csrc/gemm_tn.hip instead of a 16-workgroup library
-            # TN GEMM and a bf16 column reduction; falls back to F.linear outside its shape limits)
-            f = fast.linear(enc[:, :max_t], self.enc.weight, self.enc.bias)
-            g = fast.linear(dec[:, :max_u + 1], self.pred.weight, self.pred.bias)
         lk = self._loss._loss
-        costs = fused_joint_rnnt(f, g, head.weight, head.bias, transcripts[:, :max_u].contiguous().long(),
-                                 encoder_lengths.long(), transcript_lengths.long(), lk.blank, dropout_p=p,
-                                 seed=self.dropout_seed, fastemit_lambda=lk.fastemit_lambda,
-                                 scale_hint=self.loss_scale_hint, stash_req=req)
+        encn, decn = enc[:, :max_t], dec[:, :max_u + 1]
+        d_in, h_in = self.enc.weight.shape[1], self.pred.weight.shape[1]
+        if (encn.is_contiguous() and encn.dtype == torch.float32 and decn.shape[1] == dec.shape[1]
+                and decn.dtype in (torch.float32, torch.bfloat16) and fast.gemm_supported(d_in, self.enc.weight.shape[0])
+                and fast.gemm_supported(h_in, self.pred.weight.shape[0]) and self.enc.bias is not None and self.pred.bias is not None):
+            # the two projections run INSIDE the fused node (ops/joint.py, projection mode): f16 operands straight out of the
+            # HIP GEMMs, the prediction network's time-major output gathered by one launch, no casts / copies in between
+            costs = fused_joint_rnnt(encn, decn, head.weight, head.bias, transcripts[:, :max_u].contiguous().long(),
+                                     encoder_lengths.long(), transcript_lengths.long(), lk.blank, dropout_p=p,
+                                     seed=self.dropout_seed, fastemit_lambda=lk.fastemit_lambda,
+                                     scale_hint=self.loss_scale_hint, stash_req=req,
+                                     enc_proj=(self.enc.weight, self.enc.bias), pred_proj=(self.pred.weight, self.pred.bias))
+        else:
+            with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+                # (fast.linear: HIP GEMM forward, weight + bias gradient on csrc/gemm_tn.hip instead of a 16-workgroup library
+                # TN GEMM and a bf16 column reduction; falls back to F.linear outside its shape limits)
+                f = fast.linear(encn, self.enc.weight, self.enc.bias)
+                g = fast.linear(decn, self.pred.weight, self.pred.bias)
+            costs = fused_joint_rnnt(f, g, head.weight, head.bias, transcripts[:, :max_u].contiguous().long(),
+                                     encoder_lengths.long(), transcript_lengths.long(), lk.blank, dropout_p=p,
+                                     seed=self.dropout_seed, fastemit_lambda=lk.fastemit_lambda,
+                                     scale_hint=self.loss_scale_hint, stash_req=req)
         if req is not None:
             self.store_list = req["out"]
+        if self.return_costs and self._loss.reduction == 'mean_batch':
+            self.last_costs = costs
+            return None
         return self._loss.reduce([costs], [transcript_lengths])
 
 
@@ -313,11 +345,35 @@ class ConvASRDecoder(nn.Module):
         self.return_logits_ = False
         self.decoder_logits = None
         self.temperature = 1.0
+        self._rows_cache = {}
 
     def _rows(self, lang, device):
-        i = self.lang_index[lang]
-        v = self.vocab_per_lang
-        return torch.cat([torch.arange(i * v, (i + 1) * v, device=device), torch.tensor([self._num_classes - 1], device=device)])
+        key = (lang, str(device))
+        r = self._rows_cache.get(key)
+        if r is None:
+            i = self.lang_index[lang]
+            v = self.vocab_per_lang
+            r = self._rows_cache[key] = torch.cat([torch.arange(i * v, (i + 1) * v, device=device),
+                                                   torch.tensor([self._num_classes - 1], device=device)])
+        return r
+
+    def fused_loss_supported(self, encoder_output, language_ids, targets):
+        """The head + CTC loss as ONE autograd node on raw logits (ops/tail.ctc_head_loss): single-language batch, bf16 mode,
+        nothing asks for the log-probs / logits tensors themselves (LwF's return_probs, MAS's return_logits_)."""
+        from .ops import tail
+        return (self.cfg.compute_dtype == "bf16" and language_ids is not None and len(set(language_ids)) == 1
+                and not self.return_logits_ and self.temperature == 1.0
+                and tail.ctc_head_loss_supported(encoder_output, targets, self.cfg.d_model))
+
+    def forward_loss(self, encoder_output, language_ids, targets, input_lengths, target_lengths, zero_infinity=True, keep=None):
+        """nll [B] (reduction 'none') of ConvASRDecoder.forward + CTCLoss.forward for a single-language batch."""
+        _flush_pending()
+        from .ops import tail
+        conv = self.decoder_layers[0]
+        i, v = self.lang_index[language_ids[0]], self.vocab_per_lang
+        x = encoder_output.transpose(1, 2)   # [B,T,d]
+        return tail.ctc_head_loss(x, conv.weight, conv.bias, targets, input_lengths, target_lengths, i * v, v, self._num_classes - 1,
+                                  blank=v, zero_infinity=zero_infinity, keep=keep)
 
     def forward(self, encoder_output, language_ids=None):
         _flush_pending()

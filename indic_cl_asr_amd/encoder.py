@@ -69,15 +69,17 @@ class RelPositionalEncoding(nn.Module):
         if self.pe.size(1) < 2 * length - 1:
             self.pe = self._table(length).to(device)
 
-    def forward(self, x):
-        if self.xscale:
-            x = x * self.xscale
-        T = x.size(1)
+    def pos_emb_for(self, T):
         centre = self.pe.size(1) // 2 + 1
         pos_emb = self.pe[:, centre - T: centre + T - 1]
         if self.dropout_emb is not None:
             pos_emb = self.dropout_emb(pos_emb)
-        return self.dropout(x), pos_emb
+        return pos_emb
+
+    def forward(self, x):
+        if self.xscale:
+            x = x * self.xscale
+        return self.dropout(x), self.pos_emb_for(x.size(1))
 
 
 class RelPositionMultiHeadAttention(nn.Module):
@@ -258,6 +260,7 @@ class ConformerEncoder(nn.Module):
         self.use_fast_path = True
         self.use_fused_blocks = True   # trainable blocks as single autograd nodes on the HIP kernels
         self.fast_seed = 0             # per-step dropout seed for the fused path (set by the model)
+        self._pos_cache = {}           # T -> bf16 images of the position table slice (plain dict: not a buffer, not copied state)
 
     def _amp(self, x):
         if self.cfg.compute_dtype == "bf16" and x.is_cuda:
@@ -275,10 +278,16 @@ class ConformerEncoder(nn.Module):
             with (torch.no_grad() if self.encoder_frozen_till > 0 else nullcontext()):
                 from .ops import fast
                 pe = self.pre_encode
+                scaled = False
                 if (self.use_fast_path and self.cfg.compute_dtype == "bf16" and audio_signal.is_cuda
                         and not (torch.is_grad_enabled() and any(p.requires_grad for p in pe.parameters()))
                         and fast.subsample_supported(pe.conv[0].weight.shape[0], self.d_model, self.cfg.feat_in)):
-                    x = fast.conv_subsampling(audio_signal, pe.conv[0], pe.conv[2], pe.out)
+                    # RelPositionalEncoding's x * sqrt(d) and its dropout ride in the epilogue of the subsampling's Linear
+                    pen = self.pos_enc
+                    p_pre = float(pen.dropout.p) if (self.training and pen.training) else 0.0
+                    x = fast.conv_subsampling(audio_signal, pe.conv[0], pe.conv[2], pe.out, alpha=pen.xscale or 1.0, dropout_p=p_pre,
+                                              seed=(self.fast_seed * 40503 + 977) & 0x7FFFFFFF)
+                    scaled = True
                     length = subsampled_length(length) if subsampled_len is None else subsampled_len
                 else:
                     x = audio_signal.transpose(1, 2)
@@ -290,8 +299,11 @@ class ConformerEncoder(nn.Module):
                 if x.is_cuda:   # lets the caller start side-stream work behind the subsampling instead of beside it (model.training_step)
                     ev = SUBSAMPLED_EVENT[x.device.index] = torch.cuda.Event()   # (module-level: models stay deep-copyable)
                     ev.record(torch.cuda.current_stream(x.device))
-                x, pos_emb = self.pos_enc(x)
-                pad_mask = torch.arange(T, device=x.device)[None, :] >= length[:, None]
+                if scaled:
+                    pos_emb = self.pos_enc.pos_emb_for(T)
+                else:
+                    x, pos_emb = self.pos_enc(x)
+                pad_mask = None    # (only the ATen composition below reads it: built there)
             lth = 0
             n_layers = len(self.layers)
             # no-autograd prefix (frozen layers, or everything under torch.no_grad()): fused HIP path
@@ -320,22 +332,41 @@ class ConformerEncoder(nn.Module):
                              for l in range(lth, n_layers))
             if blk_ok:
                 xr = x.float().reshape(B_ * T_, d_).contiguous()
-                pe16 = block.pad_pos_emb(pos_emb, d_)
+                pe16 = self._pos_bf16(pos_emb, d_)[1]
                 base = (self.fast_seed * 2654435761) & 0x7FFFFFFF
                 for l in range(lth, n_layers):
                     xr = block.conformer_block(xr, self.layers[l], length, pe16, B_, T_, base + 16 * l)
                 x = xr.view(B_, T_, d_)
             else:
+                if lth < n_layers:
+                    pad_mask = torch.arange(T, device=x.device)[None, :] >= length[:, None]
                 for l in range(lth, n_layers):
                     with (torch.no_grad() if self.encoder_frozen_till > l else nullcontext()):
                         x = self.layers[l](x, length, pos_emb, pad_mask)
         return x.transpose(1, 2), length
 
+    def _pos_bf16(self, pos_emb, d):
+        """(bf16 [2T-1, d], bf16 zero-padded to a multiple of 8 rows) of the position table slice: a pure function of T (and of
+        the table buffer), cached -- the cast and the padded copy used to be three launches per step."""
+        if self.pos_enc.dropout_emb is not None and self.training:
+            from .ops import block
+            return pos_emb.reshape(-1, d).to(torch.bfloat16).contiguous(), block.pad_pos_emb(pos_emb, d)
+        key = (pos_emb.shape[1], self.pos_enc.pe.data_ptr(), str(pos_emb.device))
+        hit = self._pos_cache.get(key)
+        if hit is None:
+            from .ops import block
+            if len(self._pos_cache) >= 8:
+                self._pos_cache.pop(next(iter(self._pos_cache)))
+            with torch.no_grad():
+                padded = block.pad_pos_emb(pos_emb, d)
+                hit = self._pos_cache[key] = (padded[:pos_emb.shape[1]], padded)
+        return hit
+
     def _fast_prefix(self, x, length, pos_emb, n_fast):
         from .ops import fast
         B, T, d = x.shape
         xr = x.float().reshape(B * T, d).contiguous()
-        pe = pos_emb.reshape(-1, d).to(torch.bfloat16).contiguous()
+        pe = self._pos_bf16(pos_emb, d)[0]
         base = (self.fast_seed * 2654435761) & 0x7FFFFFFF
         l0 = self.layers[0]
         bn_ok = all(l.conv.batch_norm.track_running_stats for l in self.layers[:n_fast])

@@ -289,44 +289,82 @@ class EncDecHybridRNNTCTCModel(TranscriptionMixin, nn.Module):
         # BEFORE the joint: autograd then replays its backward (on the same side stream) after the joint's backward has
         # been enqueued, i.e. concurrently with it; a stream of its own, so that it never queues behind the LSTM backward.
         side2 = self._side_stream(signal.device, 1) if self.overlap_ctc and signal.is_cuda else None
+        if signal.is_cuda and self.cfg.compute_dtype == "bf16":
+            # ONE bf16 image of the encoder output for both heads, cast on the main stream before the CTC branch forks off
+            from .ops import tail
+            enc_btd = encoded.transpose(1, 2)
+            if enc_btd.is_contiguous() and enc_btd.dtype == torch.float32:
+                tail.share_bf16(enc_btd)      # (withdrawn below, once both heads have been issued)
+        want_wer = bool(self.compute_wer_in_step if self.compute_wer_in_step is not None else compute_wer)
+        # the CTC head and loss as one node on raw logits (no log-prob tensor, no softmax backward) unless a caller needs the
+        # log-probs themselves with a gradient path (LwF: return_probs) or the raw logits stash (MAS: return_logits_)
+        ctc_fused = (signal.is_cuda and not return_probs and self.ctc_loss.config_reduction == 'mean_batch'
+                     and self.ctc_decoder.fused_loss_supported(encoded, language_ids, transcript))
+        ctc_keep = {} if (ctc_fused and want_wer) else None
+
+        def ctc_branch():
+            if ctc_fused:
+                return None, self.ctc_decoder.forward_loss(encoded, language_ids, transcript, encoded_len, transcript_len,
+                                                           zero_infinity=self.ctc_loss.zero_infinity, keep=ctc_keep)
+            lp = self.ctc_decoder(encoder_output=encoded, language_ids=language_ids)
+            return lp, self.ctc_loss(log_probs=lp, targets=transcript, input_lengths=encoded_len, target_lengths=transcript_len)
+
         if side2 is not None:
             main = torch.cuda.current_stream(signal.device)
             enc_ready = torch.cuda.Event()
             enc_ready.record(main)
             side2.wait_event(enc_ready)
             with torch.cuda.stream(side2):
-                log_probs = self.ctc_decoder(encoder_output=encoded, language_ids=language_ids)
-                ctc_loss = self.ctc_loss(log_probs=log_probs, targets=transcript, input_lengths=encoded_len,
-                                         target_lengths=transcript_len)
+                log_probs, ctc_loss = ctc_branch()
             for t in (encoded, encoded_len, transcript, transcript_len):
                 t.record_stream(side2)
         self.joint.loss_scale_hint = (1.0 - self.ctc_loss_weight) / max(1, signal.shape[0])
         self.joint.dropout_seed = (self.seed * 2654435761 + self._step * 40503) & 0x7FFFFFFF
+        self.joint.return_costs = bool(signal.is_cuda)     # per-utterance costs: the combination kernel forms the means
         loss_value, wer, _, _ = self.joint(encoder_outputs=encoded, decoder_outputs=decoder, encoder_lengths=encoded_len,
                                            transcripts=transcript, transcript_lengths=transcript_len, compute_wer=False,
                                            language_ids=language_ids, host_lengths=(h_enc, h_tgt))
+        self.joint.return_costs = False
         if side2 is not None:
             main.wait_stream(side2)
             ctc_loss.record_stream(main)
-            log_probs.record_stream(main)
+            if log_probs is not None:
+                log_probs.record_stream(main)
         else:
-            log_probs = self.ctc_decoder(encoder_output=encoded, language_ids=language_ids)
-            ctc_loss = self.ctc_loss(log_probs=log_probs, targets=transcript, input_lengths=encoded_len,
-                                     target_lengths=transcript_len)
-        rnnt_only = loss_value
-        loss_value = (1 - self.ctc_loss_weight) * loss_value + self.ctc_loss_weight * ctc_loss
-        vals = [rnnt_only.detach().float(), ctc_loss.detach().float(), loss_value.detach().float()]
-        keys = ['train_rnnt_loss', 'train_ctc_loss', 'train_loss']
+            log_probs, ctc_loss = ctc_branch()
         if signal.is_cuda:
-            # a lost hand-off of the persistent LSTM (bounded spin) travels to the host with the loss values: the monitor
-            # raises when it is read instead of training on a silently wrong prediction network (csrc/lstm.hip)
+            from .ops import tail
+            tail.unshare(signal.device)
+        costs = getattr(self.joint, "last_costs", None)
+        self.joint.last_costs = None
+        if signal.is_cuda and ctc_fused and costs is not None and self.loss.reduction == 'mean_batch':
+            # loss = (1-w) mean(costs) + w mean(nll), the monitor's three values and the persistent LSTM's timeout flag: one launch
             from .ops import lstm as hip_lstm
-            flag = hip_lstm.timeout_flags(signal.device)
-            if flag is not None:
-                vals.append(flag); keys.append('_lstm_timeout')
-        monitor = StepMonitor({'training_batch_wer': torch.tensor(float('nan')), 'training_batch_wer_ctc': float('nan')},
-                              tuple(keys), torch.stack(vals))
-        if (self.compute_wer_in_step if self.compute_wer_in_step is not None else compute_wer):
+            from .ops import tail
+            loss_value, vals = tail.loss_combine(costs, ctc_loss, self.ctc_loss_weight, hip_lstm.timeout_words(signal.device))
+            keys = ('train_rnnt_loss', 'train_ctc_loss', 'train_loss', '_lstm_timeout')
+            monitor = StepMonitor({'training_batch_wer': torch.tensor(float('nan')), 'training_batch_wer_ctc': float('nan')}, keys, vals)
+        else:
+            if costs is not None:
+                loss_value = self.loss.reduce([costs], [transcript_len])
+            if ctc_fused:      # per-utterance nll from the fused head + loss node: the wrapper's 'mean_batch'
+                ctc_loss = ctc_loss.mean()
+            rnnt_only = loss_value
+            loss_value = (1 - self.ctc_loss_weight) * loss_value + self.ctc_loss_weight * ctc_loss
+            vals = [rnnt_only.detach().float(), ctc_loss.detach().float(), loss_value.detach().float()]
+            keys = ['train_rnnt_loss', 'train_ctc_loss', 'train_loss']
+            if signal.is_cuda:
+                # a lost hand-off of the persistent LSTM (bounded spin) travels to the host with the loss values: the monitor
+                # raises when it is read instead of training on a silently wrong prediction network (csrc/lstm.hip)
+                from .ops import lstm as hip_lstm
+                flag = hip_lstm.timeout_flags(signal.device)
+                if flag is not None:
+                    vals.append(flag); keys.append('_lstm_timeout')
+            monitor = StepMonitor({'training_batch_wer': torch.tensor(float('nan')), 'training_batch_wer_ctc': float('nan')},
+                                  tuple(keys), torch.stack(vals))
+        if want_wer:
+            if log_probs is None:   # greedy CTC reads the raw logits: argmax over the valid columns == argmax of the log-probs
+                log_probs = ctc_keep["logits"][:, :, :ctc_keep["V"]]
             wer, wer_ctc = self.batch_wer(encoded, encoded_len, log_probs, transcript, transcript_len, language_ids)
             monitor['training_batch_wer'], monitor['training_batch_wer_ctc'] = wer, wer_ctc
         self._step += 1

@@ -1,5 +1,6 @@
 """Python faces of the Conformer-block HIP kernels (csrc/gemm_bf16.hip, csrc/encoder_ops.hip) and the bf16 weight
 shadow cache used by the no-autograd (frozen-prefix / teacher / eval) encoder path."""
+import ctypes
 import weakref
 
 import torch
@@ -66,8 +67,14 @@ def bf16_shadow(*params):
         return hit[1]
     with torch.no_grad():
         flat16 = [_flat_shadow(p) for p in params]
-        if all(v is not None for v in flat16):  # emitted by ia_adamw_step: no cast kernels at all (one cat for q|k|v)
-            w = flat16[0] if len(params) == 1 else torch.cat(flat16, 0)
+        if all(v is not None for v in flat16):  # emitted by ia_adamw_step: no cast kernels at all
+            # (cl.FlatParams lays linear_q | linear_k | linear_v out back to back: their concatenation is a VIEW, not a cat)
+            if len(params) == 1:
+                w = flat16[0]
+            else:
+                w = _adjacent_rows_view(flat16)
+                if w is None:
+                    w = torch.cat(flat16, 0)
         else:
             w = torch.cat([p.detach().reshape(p.shape[0], -1) for p in params], 0) if len(params) > 1 \
                 else params[0].detach().reshape(params[0].shape[0], -1)
@@ -100,7 +107,29 @@ def glu_regrouped(weight, bias):
     return w, b
 
 
+def _adjacent_rows_view(ts):
+    """[rows_i, cols] tensors lying back to back in one storage -> their row-wise concatenation as a view, else None."""
+    t0 = ts[0]
+    if t0.dim() not in (1, 2) or not all(t.is_contiguous() and t.dtype == t0.dtype and t.dim() == t0.dim() for t in ts):
+        return None
+    cols = t0.shape[1] if t0.dim() == 2 else 1
+    off = t0.storage_offset()
+    st = t0.untyped_storage().data_ptr()
+    rows = 0
+    for t in ts:
+        tc = t.shape[1] if t.dim() == 2 else 1
+        if t.untyped_storage().data_ptr() != st or t.storage_offset() != off + rows * cols or tc != cols:
+            return None
+        rows += t.shape[0]
+    out = t0.new_empty(0).set_(t0.untyped_storage(), off, (rows, cols) if t0.dim() == 2 else (rows,), (cols, 1) if t0.dim() == 2 else (1,))
+    return out
+
+
 def f32_cat(*params):
+    if len(params) > 1 and all(p.dtype == torch.float32 for p in params):
+        v = _adjacent_rows_view([p.detach() for p in params])     # biases back to back in the flat weight buffer: a view
+        if v is not None:
+            return v
     key = ("f32",) + tuple(id(p) for p in params)
     ver = tuple(p._version for p in params) + tuple(p.data_ptr() for p in params) + \
         ((WEIGHT_EPOCH,) if any(p.requires_grad for p in params) else ())
@@ -133,12 +162,21 @@ def gemm_supported(K, N):
 
 
 def gemm(a_bf16, w_bf16, bias=None, act=0, dropout_p=0.0, seed=0, alpha=1.0, residual=None, out_f32=None,
-         want_bf16=True):
+         want_bf16=True, out_f16=False):
     """out = alpha*dropout(act(a @ w^T + bias)) + residual.  a [M,K] bf16, w [N,K] bf16.  Returns (out_f32, out_bf16);
-    `out_f32` may be the residual tensor itself (in-place residual update)."""
+    `out_f32` may be the residual tensor itself (in-place residual update).  out_f16: the 16-bit output is IEEE half (the
+    joint's operands) instead of bf16."""
     M, K = a_bf16.shape
     N = w_bf16.shape[0]
-    outH = torch.empty(M, N, dtype=torch.bfloat16, device=a_bf16.device) if want_bf16 else None
+    outH = torch.empty(M, N, dtype=torch.float16 if out_f16 else torch.bfloat16, device=a_bf16.device) if want_bf16 else None
+    if out_f16:
+        st = _lib.lib().ia_gemm_bf16_ex2(_lib.ptr(a_bf16), a_bf16.stride(0), _lib.ptr(w_bf16), w_bf16.stride(0), M, N, K,
+                                         _lib.ptr(bias), int(act), float(dropout_p), int(seed) & 0xFFFFFFFF, float(alpha),
+                                         _lib.ptr(residual), residual.stride(0) if residual is not None else 0,
+                                         _lib.ptr(out_f32), out_f32.stride(0) if out_f32 is not None else 0,
+                                         _lib.ptr(outH), N, None, 0, None, 0, 1, _lib.stream_ptr())
+        _lib.check(st, "ia_gemm_bf16_ex2")
+        return out_f32, outH
     st = _lib.lib().ia_gemm_bf16(_lib.ptr(a_bf16), a_bf16.stride(0), _lib.ptr(w_bf16), w_bf16.stride(0), M, N, K,
                                  _lib.ptr(bias), int(act), float(dropout_p), int(seed) & 0xFFFFFFFF, float(alpha),
                                  _lib.ptr(residual), residual.stride(0) if residual is not None else 0,
@@ -146,6 +184,34 @@ def gemm(a_bf16, w_bf16, bias=None, act=0, dropout_p=0.0, seed=0, alpha=1.0, res
                                  _lib.ptr(outH), N, _lib.stream_ptr())
     _lib.check(st, "ia_gemm_bf16")
     return out_f32, outH
+
+
+class _TrJob(ctypes.Structure):
+    _fields_ = [("inp", ctypes.c_void_p), ("out", ctypes.c_void_p), ("rows", ctypes.c_int), ("cols", ctypes.c_int)]
+
+
+def transpose16_multi(mats):
+    """[M_i [rows, cols] 16-bit contiguous] (<= 8) -> [M_i^T contiguous] in ONE launch (csrc/tail_ops.hip)."""
+    n = len(mats)
+    arr = (_TrJob * n)()
+    outs = []
+    for i, m in enumerate(mats):
+        assert m.is_contiguous() and m.element_size() == 2 and m.dim() == 2
+        o = torch.empty(m.shape[1], m.shape[0], dtype=m.dtype, device=m.device)
+        outs.append(o)
+        arr[i].inp, arr[i].out, arr[i].rows, arr[i].cols = m.data_ptr(), o.data_ptr(), m.shape[0], m.shape[1]
+    _lib.check(_lib.lib().ia_transpose16_multi(ctypes.addressof(arr), n, _lib.stream_ptr()), "ia_transpose16_multi")
+    return outs
+
+
+def swap01_cast(x, out_dtype):
+    """x [n0, n1, H] contiguous (f32 or bf16) -> [n1, n0, H] contiguous in `out_dtype` (f32 or bf16): one launch."""
+    n0, n1, H = x.shape
+    assert x.is_contiguous() and x.dtype in (torch.float32, torch.bfloat16) and out_dtype in (torch.float32, torch.bfloat16)
+    out = torch.empty(n1, n0, H, dtype=out_dtype, device=x.device)
+    _lib.check(_lib.lib().ia_swap01_cast(_lib.ptr(x), int(x.dtype == torch.bfloat16), n0, n1, H, _lib.ptr(out),
+                                         int(out_dtype == torch.bfloat16), _lib.stream_ptr()), "ia_swap01_cast")
+    return out
 
 
 def quantize_fp8_rows(x):
@@ -521,8 +587,15 @@ class _LinearHip(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         shp = x.shape
-        x2 = x.reshape(-1, shp[-1])
-        xb = x2.to(torch.bfloat16).contiguous()
+        if x.dtype == torch.bfloat16 and x.is_contiguous():
+            xb = x.detach().view(-1, shp[-1])
+        elif x.is_contiguous():
+            from . import tail
+            xb = tail.bf16_of(x)                   # shared with the other consumers of the same activation (CTC head)
+        else:   # strided view (the prediction network's time-major output seen batch-major): ONE cast-and-gather launch
+            xb = torch.empty(shp, dtype=torch.bfloat16, device=x.device)
+            xb.copy_(x.detach())
+            xb = xb.view(-1, shp[-1])
         wb = bf16_shadow(weight)
         _, y = gemm(xb, wb, bias.detach().float() if bias is not None else None)
         ctx.save_for_backward(xb, wb)
@@ -582,9 +655,10 @@ def subsample_supported(C, d, feat_in):
             and (C * (((feat_in - 1) // 2 + 1 - 1) // 2 + 1)) % 8 == 0)
 
 
-def conv_subsampling(feats_bft, conv1, conv2, lin):
+def conv_subsampling(feats_bft, conv1, conv2, lin, alpha=1.0, dropout_p=0.0, seed=0):
     """feats [B,feat_in,Tm] f32 -> [B*T2, d] f32 (ConvSubsampling.forward, subsampling.py:385-437) on the HIP path:
-    direct conv1+ReLU (channels-last), implicit-GEMM conv2+ReLU on the matrix cores, Linear on the bf16 GEMM."""
+    direct conv1+ReLU (channels-last), implicit-GEMM conv2+ReLU on the matrix cores, Linear on the bf16 GEMM.
+    alpha / dropout_p: RelPositionalEncoding's `dropout(x * xscale)` (multi_head_attention.py:968-979) in the Linear's epilogue."""
     L = _lib.lib()
     x = feats_bft.float().contiguous()
     B, Fm, Tm = x.shape
@@ -606,7 +680,7 @@ def conv_subsampling(feats_bft, conv1, conv2, lin):
     wl = _cached(("sub_wl", id(lin.weight)), [lin.weight],
                  lambda: lin.weight.detach().view(d, N, F2).permute(0, 2, 1).reshape(d, F2 * N).to(torch.bfloat16).contiguous())
     y = torch.empty(B * T2, d, dtype=torch.float32, device=dev)
-    gemm(o2.view(B * T2, F2 * N), wl, lin.bias, out_f32=y, want_bf16=False)
+    gemm(o2.view(B * T2, F2 * N), wl, lin.bias, out_f32=y, want_bf16=False, alpha=float(alpha), dropout_p=float(dropout_p), seed=seed)
     return y.view(B, T2, d)
 
 

@@ -164,21 +164,52 @@ def lattice_kd_term(stash: LatticeStash, teacher: LatticeStash):
 
 class _FusedJointRNNT(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, f, g, W, bias, labels, act_lens, label_lens, blank, dropout_p, seed, fastemit, scale_hint, stash_req):
+    def forward(ctx, f, g, W, bias, labels, act_lens, label_lens, blank, dropout_p, seed, fastemit, scale_hint, stash_req,
+                We=None, be=None, Wg=None, bg=None):
+        """Projection mode (We .. bg given): `f` is the encoder output x [B,T,d] (f32, contiguous) and `g` the prediction
+        network's output [B,U1,Hp] (f32; a batch-major VIEW of the LSTM's time-major [U1,B,Hp] buffer, or contiguous); the
+        joint's two projections (rnnt.py:1590-1596) run inside this node on the HIP GEMM with f16 outputs, so that no cast /
+        gather / transpose launches sit between them and the lattice kernels, forward or backward."""
         from ..losses import rnnt as rl
+        from . import fast
         L = _lib.lib()
         ctx.set_materialize_grads(False)
-        B, T, H = f.shape
-        U1 = g.shape[1]
-        V = W.shape[0]
+        proj = We is not None
         dev = f.device
-        need = any(ctx.needs_input_grad[:4])
-        f16 = f.detach().to(torch.float16).contiguous()
-        g16 = g.detach().to(torch.float16).contiguous()
+        need = any(ctx.needs_input_grad[:4]) or (proj and any(ctx.needs_input_grad[13:17]))
         p = float(dropout_p)
+        V = W.shape[0]
+        ctx.proj = None
+        if proj:
+            from . import tail
+            B, T, d = f.shape
+            U1, Hp = g.shape[1], g.shape[2]
+            H = We.shape[0]
+            xb = tail.bf16_of(f if f.is_contiguous() else f.contiguous())                       # [B*T, d] (shared with the CTC head)
+            gd = g.detach()
+            tm = gd.transpose(0, 1)
+            if (not gd.is_contiguous()) and tm.is_contiguous() and gd.dtype in (torch.float32, torch.bfloat16):
+                gb, g_time_major = fast.swap01_cast(tm, torch.bfloat16).view(B * U1, Hp), True    # [U1,B,Hp] -> [B,U1,Hp] bf16
+            else:
+                gb, g_time_major = gd.contiguous().to(torch.bfloat16).view(B * U1, Hp), False
+            We16, Wg16 = fast.bf16_shadow(We), fast.bf16_shadow(Wg)
+            f16 = fast.gemm(xb, We16, be.detach(), out_f16=True)[1].view(B, T, H)
+            g16 = fast.gemm(gb, Wg16, bg.detach(), out_f16=True)[1].view(B, U1, H)
+            ctx.proj = (xb, gb, We16, Wg16, g_time_major, d, Hp, We, be, Wg, bg)
+        else:
+            B, T, H = f.shape
+            U1 = g.shape[1]
+            f16 = f.detach().to(torch.float16).contiguous()
+            g16 = g.detach().to(torch.float16).contiguous()
         LD = L.ia_joint_ld(V)
-        Wp = torch.zeros(JOINT_MAX_V, H, dtype=torch.float16, device=dev)
-        Wp[:V] = (W.detach().float() / (1.0 - p)).to(torch.float16) if p > 0 else W.detach().to(torch.float16)
+        # head image: rows padded to 272, dropout scale folded in, f16 -- and its transpose for the hidden-gradient kernel -- by ONE
+        # launch (was zeros + div + cast + copy here and zeros + transposed copy in the backward)
+        Wp = torch.empty(JOINT_MAX_V, H, dtype=torch.float16, device=dev)
+        dhk = L.ia_joint_dh_k()
+        Wt = torch.empty(H, dhk, dtype=torch.float16, device=dev) if (need and dhk >= JOINT_MAX_V) else None
+        W32 = W.detach() if (W.dtype == torch.float32 and W.is_contiguous()) else W.detach().float().contiguous()
+        _lib.check(L.ia_select_rows_cast(_lib.ptr(W32), H, None, 0, V, -1, H, JOINT_MAX_V, 1.0 / (1.0 - p) if p > 0 else 1.0, 1,
+                                         _lib.ptr(Wp), _lib.ptr(Wt), dhk, None, _lib.stream_ptr()), "ia_select_rows_cast")
         bias32 = bias.detach().float().contiguous()
         nbytes = L.ia_rnnt_workspace_bytes(B, T, U1)
         if nbytes == 0:
@@ -202,6 +233,8 @@ class _FusedJointRNNT(torch.autograd.Function):
         ctx.stash = stash
         if need:
             ctx.saved = (f16, g16, Wp, logits, ws, labels, act_lens, label_lens)
+            ctx.Wt = Wt
+            ctx.head = (W, bias)
             ctx.meta = (B, T, U1, H, V, LD, int(blank), p, int(seed) & 0xFFFFFFFF, float(fastemit),
                         _kappa_for(scale_hint), f.dtype, g.dtype, W.dtype, bias.dtype, nbytes)
         # the second output is the autograd handle of the lattice: the CL terms hang their nodes on it (_LatticeTerm)
@@ -248,7 +281,7 @@ class _FusedJointRNNT(torch.autograd.Function):
         stash = ctx.stash
         E = stash.pending_E if (stash is not None and gtoken is not None) else None
         if gcosts is None and E is None:
-            return (None,) * 13
+            return (None,) * 17
         if ctx.saved is None:   # the gradient overwrites the saved logits in place: one backward per forward
             raise RuntimeError("fused joint+loss: trying to backward through the graph a second time -- the saved lattice "
                                "was overwritten in place by the first backward (the fused path does not support "
@@ -292,8 +325,10 @@ class _FusedJointRNNT(torch.autograd.Function):
         dg = torch.zeros(B, U1, H, dtype=torch.float32, device=dev)
         if USE_FUSED_DH and L.ia_joint_dh_fused_supported(U1, H, LD):
             # dH = G @ W, relu/dropout mask and both reductions in one MFMA kernel (dH never reaches memory)
-            Wt = torch.zeros(H, L.ia_joint_dh_k(), dtype=torch.float16, device=dev)
-            Wt[:, :JOINT_MAX_V] = Wp.t()
+            Wt = ctx.Wt
+            if Wt is None:
+                Wt = torch.zeros(H, L.ia_joint_dh_k(), dtype=torch.float16, device=dev)
+                Wt[:, :JOINT_MAX_V] = Wp.t()
             scr = torch.empty(L.ia_joint_dh_fused_scratch_bytes(B, T, U1, H), dtype=torch.uint8, device=dev)
             ev = MFMA_PROFILE_HOOK(2.0 * cells * H * LD) if MFMA_PROFILE_HOOK is not None else None   # bench.py: torch events
             if ev is not None:
@@ -319,8 +354,8 @@ class _FusedJointRNNT(torch.autograd.Function):
                                      H, LD, p, seed, _lib.ptr(dWk),
                                      _lib.ptr(scr), _lib.stream_ptr())
             _lib.check(st, "ia_joint_dw_fused")
-            dW = dWk[:V] * (1.0 / (kappa * (1.0 - p)))
-            db = dbk[:V] * (1.0 / kappa)
+            dW_src, dW_scale = dWk[:V], 1.0 / (kappa * (1.0 - p))
+            db_src, db_scale = dbk[:V], 1.0 / kappa
         else:
             HT = torch.empty(S, LDH, Kc, dtype=torch.float16, device=dev)
             st = L.ia_joint_hidden_t(_lib.ptr(f16), _lib.ptr(g16), _lib.ptr(HT), B, T, U1, H, LDH, S, Kc, p, seed,
@@ -328,9 +363,37 @@ class _FusedJointRNNT(torch.autograd.Function):
             _lib.check(st, "ia_joint_hidden_t")
             # dW (+dbias in column H): batched split-K library GEMM over the chunks, f32 partials summed
             dWx = torch.bmm(GT, HT.transpose(1, 2), out_dtype=torch.float32).sum(0)  # [LD, LDH]
-            dW = dWx[:V, :H] * (1.0 / (kappa * (1.0 - p)))
-            db = dWx[:V, H] * (1.0 / kappa)
-        return df.to(fdt), dg.to(gdt), dW.to(wdt), db.to(bdt), None, None, None, None, None, None, None, None, None
+            dW_src, dW_scale = dWx[:V, :H].contiguous(), 1.0 / (kappa * (1.0 - p))
+            db_src, db_scale = dWx[:V, H].contiguous(), 1.0 / kappa
+        from . import fast, tail
+        Wh, bh = ctx.head
+        need = ctx.needs_input_grad
+        plist = [(Wh, dW_src if need[2] else None, dW_scale), (bh, db_src if need[3] else None, db_scale)]
+        if ctx.proj is None:
+            outs = tail.accumulate_or_return(plist)
+            return (df.to(fdt), dg.to(gdt)) + outs + (None,) * 13
+        # ---- projection mode: the two projections' backward on the HIP GEMMs, every parameter gradient in one accumulation launch
+        xb, gb, We16, Wg16, g_time_major, d, Hp, We, be, Wg, bg = ctx.proj
+        ctx.proj = None
+        dfb = df.view(B * T, H).to(torch.bfloat16)
+        dgb = dg.view(B * U1, H).to(torch.bfloat16)
+        WeT, WgT = fast.transpose16_multi([We16, Wg16])                  # [d, H], [Hp, H]: "weights" of dX = dY W
+        dx = dgin = None
+        if need[0]:
+            dx = torch.empty(B * T, d, dtype=torch.float32, device=dev)
+            fast.gemm(dfb, WeT, out_f32=dx, want_bf16=False)
+            dx = dx.view(B, T, d).to(fdt)
+        if need[1]:
+            dgm = fast.gemm(dgb, WgT)[1].view(B, U1, Hp)                    # batch-major bf16
+            if g_time_major:   # hand the gradient back in the layout the prediction network's output has: [U1,B,Hp] storage
+                dgin = fast.swap01_cast(dgm, torch.float32 if gdt == torch.float32 else torch.bfloat16).transpose(0, 1).to(gdt)
+            else:
+                dgin = dgm.to(gdt)
+        (dWe, dbe), (dWg, dbg) = fast.gemm_tn_grouped([(dfb, xb), (dgb, gb)])
+        plist += [(We, dWe if need[13] else None, 1.0), (be, dbe if need[14] else None, 1.0),
+                  (Wg, dWg if need[15] else None, 1.0), (bg, dbg if need[16] else None, 1.0)]
+        outs = tail.accumulate_or_return(plist)
+        return (dx, dgin) + outs[:2] + (None,) * 9 + outs[2:]
 
 
 def _make_stash(req, logits, geom, dev):
@@ -359,12 +422,17 @@ def _make_stash(req, logits, geom, dev):
 
 
 def fused_joint_rnnt(f, g, W, bias, labels, act_lens, label_lens, blank, dropout_p=0.0, seed=0, fastemit_lambda=0.0,
-                     scale_hint=1.0, stash_req=None):
+                     scale_hint=1.0, stash_req=None, enc_proj=None, pred_proj=None):
     """f [B,T,H], g [B,U1,H] (any float dtype), W [V,H], bias [V] -> costs [B] f32 (differentiable).
     stash_req = {"sub": fused_batch_size, "h_enc": [...], "h_tgt": [...], "detach": bool}: also keeps the logits of every
-    sub-batch box and leaves a LatticeStash in stash_req["out"]."""
+    sub-batch box and leaves a LatticeStash in stash_req["out"].
+    enc_proj = (weight [H,d], bias [H]) and pred_proj = (weight [H,Hp], bias [H]): projection mode -- `f` is then the encoder
+    output x [B,T,d] and `g` the prediction network's output [B,U1,Hp]; the joint's enc / pred Linear layers run inside the node."""
+    extra = (None, None, None, None)
+    if enc_proj is not None:
+        extra = (enc_proj[0], enc_proj[1], pred_proj[0], pred_proj[1])
     costs, token = _FusedJointRNNT.apply(f, g, W, bias, labels.contiguous(), act_lens.contiguous(), label_lens.contiguous(),
-                                         blank, dropout_p, seed, fastemit_lambda, scale_hint, stash_req)
+                                         blank, dropout_p, seed, fastemit_lambda, scale_hint, stash_req, *extra)
     if stash_req is not None and not stash_req.get("detach") and token is not None and token.requires_grad:
         stash_req["out"].token = token
     return costs

@@ -47,6 +47,12 @@ def timeout_flags(dev):
     return torch.stack(words).ne(0).sum().float()
 
 
+def timeout_words(dev):
+    """The sticky timeout words themselves (0-dim int32 views) of the scratch buffers on `dev` (at most 4): the loss
+    combination kernel counts the non-zero ones (ops/tail.loss_combine) -- no stack / ne / sum launches."""
+    return [b.view(torch.int32)[_STICKY_WORD] for k, b in _SCRATCH.items() if k[0] == dev.index][:4]
+
+
 def raise_if_timed_out(dev=None):
     """Synchronous check (tests, end of an epoch): RuntimeError if a hand-off spin of the persistent LSTM ever gave up."""
     for k, b in _SCRATCH.items():
@@ -64,9 +70,8 @@ class _LSTMHip(torch.autograd.Function):
         L = _lib.lib()
         U, B, H = x.shape
         dev = x.device
-        xb = x.detach().to(torch.bfloat16).contiguous()
-        wih = w_ih.detach().to(torch.bfloat16).contiguous()
-        whh = w_hh.detach().to(torch.bfloat16).contiguous()
+        xb = x.detach().to(torch.bfloat16).contiguous()            # (no launch when ops/tail.embed_sos produced it)
+        wih, whh = fast.bf16_shadow(w_ih), fast.bf16_shadow(w_hh)  # the optimizer kernel's bf16 images: no cast launches
         bias = (b_ih.detach().float() + b_hh.detach().float()).contiguous()
         Gx = torch.empty(U * B, 4 * H, dtype=torch.float32, device=dev)
         fast.gemm(xb.view(U * B, H), wih, bias, out_f32=Gx, want_bf16=False)
@@ -95,6 +100,7 @@ class _LSTMHip(torch.autograd.Function):
         if need:
             ctx.save_for_backward(xb, wih, whh, Hout, gates, Cs)
             ctx.dt = (x.dtype, w_ih.dtype, w_hh.dtype, b_ih.dtype, b_hh.dtype)
+            ctx.params = (w_ih, w_hh, b_ih, b_hh)
         return Hout
 
     @staticmethod
@@ -104,7 +110,7 @@ class _LSTMHip(torch.autograd.Function):
         U, B, H = xb.shape
         dev = xb.device
         dH = dH.float().contiguous()
-        whhT = whh.t().contiguous()
+        whhT, wihT = fast.transpose16_multi([whh, wih])   # one launch: W_hh^T for the recurrence, W_ih^T for dX = dG W_ih
         dG = torch.empty(U, B, 4 * H, dtype=torch.float32, device=dev)
         for b0 in range(0, B, MAXB):
             b1 = min(B, b0 + MAXB)
@@ -123,15 +129,20 @@ class _LSTMHip(torch.autograd.Function):
         # the three dense contractions on the HIP GEMMs (a library TN GEMM took 0.29 ms for dW_ih alone: 16-40 workgroups)
         dx = None
         if ctx.needs_input_grad[0]:
-            wihT = wih.t().contiguous()                      # [H, 4H]: dX = dG W_ih = dG (W_ih^T)^T
-            dx = fast.gemm(dGb, wihT)[1].view(U, B, H).to(xdt)
+            dx = fast.gemm(dGb, wihT)[1].view(U, B, H).to(xdt)   # [H, 4H] weight image: dX = dG W_ih = dG (W_ih^T)^T
         dWih, db = fast.gemm_tn(dGb, xb.view(U * B, H))      # bias gradient = the column sums the same kernel returns
         if U > 1:
             hprev = Hout[:-1].reshape((U - 1) * B, H).to(torch.bfloat16)
             dWhh, _ = fast.gemm_tn(dGb[B:], hprev)
         else:
             dWhh = torch.zeros(4 * H, H, dtype=torch.float32, device=dev)
-        return dx, dWih.to(wihdt), dWhh.to(whhdt), db.to(bihdt), db.to(bhhdt)
+        # parameter gradients: added into the flat .grad buffers by ONE launch where they exist (ops/tail.py), returned otherwise
+        from . import tail
+        w_ih, w_hh, b_ih, b_hh = ctx.params
+        need = ctx.needs_input_grad
+        outs = tail.accumulate_or_return([(w_ih, dWih if need[1] else None, 1.0), (w_hh, dWhh if need[2] else None, 1.0),
+                                          (b_ih, db if need[3] else None, 1.0), (b_hh, db if need[4] else None, 1.0)])
+        return (dx,) + outs
 
 
 def lstm_forward(x, lstm: torch.nn.LSTM):

@@ -85,7 +85,64 @@ def test_training_step_monitor_carries_batch_wer_when_asked():
     sl = torch.tensor([8000, 6000, 4000]); tr = torch.randint(0, 16, (3, 6), generator=g); tl = torch.tensor([6, 3, 1])
     batch = tuple(t.cuda() for t in (sig, sl, tr, tl))
     loss, mon = m.training_step(batch, ['hi'] * 3, compute_wer=True)
+    # the reference's types: a 0-dim tensor from WER.compute for the transducer rate, a python float for the CTC rate
+    assert torch.is_tensor(mon['training_batch_wer']) and mon['training_batch_wer'].dim() == 0
+    assert isinstance(mon['training_batch_wer_ctc'], float)
     for key in ('training_batch_wer', 'training_batch_wer_ctc'):
-        assert isinstance(mon[key], float) and mon[key] >= 0.0 and mon[key] == mon[key]
+        assert float(mon[key]) >= 0.0 and float(mon[key]) == float(mon[key])
     loss2, mon2 = m.training_step(batch, ['hi'] * 3)
     assert mon2['training_batch_wer_ctc'] != mon2['training_batch_wer_ctc']     # NaN when not requested
+
+
+def test_wer_metric_objects_follow_the_reference_surface():
+    """model.wer / model.ctc_wer: update / compute / reset (A/metrics/wer.py:293-360) -- word units through the
+    detokenizer, update REPLACES the state, compute returns (rate, edits, words) tensors, grouped() is the fused joint's
+    mean over sub-batch rates (A/modules/rnnt.py:1548-1553)."""
+    o, m = _models()
+    words = {i: w for i, w in enumerate("the cat sat on a mat with one red hat and two big dogs too".split())}
+    m.detokenize = lambda ids: " ".join(words[int(i)] for i in ids)
+    V = 17
+    def lp_for(seqs, T):          # log-probs whose greedy CTC path spells `seqs` (blank between the symbols)
+        lp = torch.full((len(seqs), T, V), -20.0)
+        for b, seq in enumerate(seqs):
+            path = []
+            for k in seq:
+                path += [k, V - 1]
+            path += [V - 1] * (T - len(path))
+            for t, k in enumerate(path):
+                lp[b, t, k] = 0.0
+        return lp
+    hyp = [[0, 1, 2], [3, 4]]
+    tgt = torch.tensor([[0, 1, 5, 0], [3, 4, 0, 0]]); tl = torch.tensor([3, 2])          # "the cat mat" / "on a"
+    m.ctc_wer.log_prediction = False
+    m.ctc_wer.update(predictions=lp_for(hyp, 9), predictions_lengths=torch.tensor([9, 9]), targets=tgt, targets_lengths=tl,
+                     lang_ids=['hi', 'hi'])
+    wer, s, w = m.ctc_wer.compute()
+    assert (float(s), float(w)) == (1.0, 5.0) and abs(float(wer) - 0.2) < 1e-7 and wer.dim() == 0
+    m.ctc_wer.update(predictions=lp_for([[0]], 4), predictions_lengths=torch.tensor([4]), targets=torch.tensor([[0, 1]]),
+                     targets_lengths=torch.tensor([2]), lang_ids=['hi'])
+    assert [float(v) for v in m.ctc_wer.compute()[1:]] == [1.0, 2.0]       # replaced, not accumulated (wer.py:359-360)
+    m.ctc_wer.reset()
+    assert int(m.ctc_wer.scores) == 0 and int(m.ctc_wer.words) == 0
+    # character error rate switch
+    m.ctc_wer.use_cer = True
+    m.ctc_wer.update(predictions=lp_for([[1]], 4), predictions_lengths=torch.tensor([4]), targets=torch.tensor([[5]]),
+                     targets_lengths=torch.tensor([1]), lang_ids=['hi'])
+    assert [float(v) for v in m.ctc_wer.compute()[1:]] == [1.0, 3.0]       # "cat" vs "mat"
+    m.ctc_wer.use_cer = False
+    # grouped: sub-batches of 2 -> mean of (1/5, 2/2)
+    g, gs, gw = m.wer.grouped([[0, 1, 2], [3, 4], [6], []], [[0, 1, 5], [3, 4], [7, 8], []][:3] + [[9]], ['hi'] * 4, 2)
+    assert (float(gs), float(gw)) == (1.0 + 3.0, 5.0 + 3.0)
+    assert abs(float(g) - 0.5 * (1 / 5 + 3 / 3)) < 1e-7
+    # the transducer metric decodes through the model: same ids as decoding.greedy_rnnt_decode, scored as strings
+    from indic_cl_asr_amd.decoding import greedy_rnnt_decode
+    gen = torch.Generator().manual_seed(3)
+    enc = torch.randn(2, 32, 12, generator=gen); lens = torch.tensor([12, 7])
+    ids = greedy_rnnt_decode(m, enc, lens, ['hi'] * 2)
+    m.wer.log_prediction = False
+    m.wer.update(predictions=enc, predictions_lengths=lens, targets=torch.tensor([[1, 2, 3], [4, 0, 0]]),
+                 targets_lengths=torch.tensor([3, 1]), lang_ids=['hi'] * 2)
+    _, s2, w2 = m.wer.compute()
+    from indic_cl_asr_amd.decoding import word_error_rate
+    _, es, ew = word_error_rate(ids, [[1, 2, 3], [4]], m.detokenize)
+    assert (float(s2), float(w2)) == (float(es), float(ew))

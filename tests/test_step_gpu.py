@@ -118,7 +118,7 @@ def test_ewc_penalty_fisher_and_adamw_match_reference_arithmetic():
     opt = cl.FusedAdamW(flat, lr=1e-3)
     oref = torch.optim.AdamW([p for p in o.parameters() if p.requires_grad], lr=1e-3)
     names = [n for n, p in o.named_parameters() if p.requires_grad]
-    assert names == flat.names
+    assert sorted(names) == sorted(flat.names)     # (the flat layout orders q | k | v back to back: cl._qkv_adjacent)
     # EWC state: random Fisher, checkpoint = perturbed weights
     g = torch.Generator().manual_seed(3)
     fish_o = {n: torch.rand(p.shape, generator=g) for n, p in S.get_params(o).items()}
