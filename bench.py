@@ -34,6 +34,40 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
+MFMA_BF16_PEAK_TFS = 2500.0   # same guide: dense bf16 / f16 MFMA peak (the 5 PF headline includes 2:1 sparsity)
+
+
+def measure_peaks(dev):
+    """peaks MEASURED on this box -- a 16-byte-per-lane streaming copy of 1 GiB (read + write bytes / time) and
+    back-to-back v_mfma_f32_16x16x32_bf16 on register operands (csrc/peaks.hip), both timed with events over 10 launches after
+    2 warm-up launches.  Returns {"hbm_copy_GBs", "mfma_bf16_TFs"}; roofline fractions are reported against these AND the
+    datasheet figures."""
+    from indic_cl_asr_amd import _lib
+    L = _lib.lib()
+    n = 1 << 30
+    src = torch.full((n,), 1, dtype=torch.uint8, device=dev)
+    dst = torch.empty_like(src)
+    sp = _lib.stream_ptr()
+
+    def timed(fn, reps=10):
+        for _ in range(2):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        b.synchronize()
+        return a.elapsed_time(b) * 1e-3 / reps
+    t_copy = timed(lambda: _lib.check(L.ia_peak_stream_copy(_lib.ptr(src), _lib.ptr(dst), n, sp), "ia_peak_stream_copy"))
+    del src, dst
+    wgs, iters = 256 * 8, 4096
+    sink = torch.empty(wgs * 256, dtype=torch.float32, device=dev)
+    t_mfma = timed(lambda: _lib.check(L.ia_peak_mfma_bf16(_lib.ptr(sink), wgs, iters, sp), "ia_peak_mfma_bf16"))
+    flops = float(L.ia_peak_mfma_bf16_flops(wgs, iters))
+    return {"hbm_copy_GBs": round(2.0 * n / t_copy / 1e9, 1), "mfma_bf16_TFs": round(flops / t_mfma / 1e12, 1),
+            "how": "1 GiB float4 copy (read+write bytes); 2048 workgroups x 4 waves x 4096 x 8 back-to-back 16x16x32 bf16 MFMAs on "
+                   "non-trivial register operands; 10 launches each after 2 warm-up launches"}
 
 
 def synth_batch(B, seconds, device, seed=1234, vocab=256, sr=16000):
@@ -185,6 +219,9 @@ def main():
                          "R/cl_baseline_mas.py:258-270); LwF teacher + student step (configs[3], R/cl_baseline_lwf.py:212-264)")
     ap.add_argument("--fp8-prefix", action="store_true", help="e4m3 projections in the frozen prefix (BASELINE configs[4]; never the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-wer-leg", action="store_true", help="skip the extra leg that decodes every batch for the monitor's WER")
+    ap.add_argument("--no-peaks", action="store_true", help="skip the on-box copy / MFMA peak microbenchmarks")
+    ap.add_argument("--grad-exchange", default="fp32", choices=["fp32", "bf16"], help="dtype of the data-parallel gradient all-reduce")
     ap.add_argument("--cpu-sample-bs", type=int, default=4)
     args = ap.parse_args()
 
@@ -221,7 +258,7 @@ def main():
         model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
     model.train()
     flat = cl.FlatParams(model)
-    opt = cl.FusedAdamW(flat, lr=1e-4)
+    opt = cl.FusedAdamW(flat, lr=1e-4, grad_exchange_dtype=args.grad_exchange)
     # EWC state of "task > 0": Fisher from a previous task (synthetic, positive) and the previous optimum
     fisher = cl.get_zero_params(model)
     fisher.flat.copy_(torch.rand(flat.numel, device=dev) * 1e-3)
@@ -284,6 +321,9 @@ def main():
     torch.cuda.synchronize()
     events.enabled = True
     timing["on"] = True
+    opt.profile_exchange = world > 1       # events around the wait for the gradient all-reduce: exposed exchange time
+    from indic_cl_asr_amd.ops import fast as fast_mod
+    fast_mod.SYNC_BN_COLLECTIVES = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -294,6 +334,49 @@ def main():
     dt = time.perf_counter() - t0
     events.enabled = False
     timing["on"] = False
+    opt.profile_exchange = False
+    exchange = None
+    if world > 1:
+        ex_ms = [a.elapsed_time(b) for a, b in opt.exchange_events]
+        exchange = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rccl": dist.get_backend() == "nccl",
+                    "gradient_allreduce_bytes_per_step": int(opt.exchange_bytes), "gradient_dtype": args.grad_exchange,
+                    "exposed_wait_ms_per_step": round(sum(ex_ms) / max(1, len(ex_ms)), 4) if ex_ms else None,
+                    "syncbn_collectives_per_step": round(fast_mod.SYNC_BN_COLLECTIVES / max(1, args.steps), 1),
+                    "note": "one flat all-reduce per step on its own communicator, launched at optimizer.step() and waited for in "
+                            "front of the first trainable module of the NEXT forward (under the frozen prefix); exposed = how long "
+                            "the compute stream stalls there"}
+    # ---- the reference-complete step: every batch decoded greedily for the monitor's two WERs (compute_wer = True in
+    # hybrid_rnnt_ctc_models.py:875; device-resident decode + host edit distance + the 2-int cross-rank sums)
+    wer_leg = None
+    if args.cl == "ewc" and not args.no_wer_leg:
+        n3 = max(5, args.steps // 5)
+        m_.wer.log_prediction = False; m_.ctc_wer.log_prediction = False       # R/cl_baseline.py:127-128
+        for _ in range(2):
+            opt.zero_grad()
+            l3, mon3 = model.training_step(batch, langs, host_lengths=host_lens, compute_wer=True)
+            cl.ewc_penalty_into_grads(flat, fisher, checkpoint, e_lambda=10.0)
+            l3.backward(); opt.step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        for _ in range(n3):
+            opt.zero_grad()
+            l3, mon3 = model.training_step(batch, langs, host_lengths=host_lens, compute_wer=True)
+            cl.ewc_penalty_into_grads(flat, fisher, checkpoint, e_lambda=10.0)
+            l3.backward(); opt.step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        d3 = time.perf_counter() - t3
+        if world > 1:
+            t = torch.tensor([d3], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            d3 = float(t.item())
+        wer_leg = {"value": round(world * args.batch * n3 / d3, 1), "ms_per_step": round(d3 / n3 * 1e3, 3), "steps": n3,
+                   "training_batch_wer": float(mon3["training_batch_wer"]), "training_batch_wer_ctc": float(mon3["training_batch_wer_ctc"]),
+                   "note": "token-level rates on random-initialised weights (no tokenizer / checkpoint in the build); the decode loop "
+                           "blocks the host once per step for the hypotheses"}
     # ---- the same step fed from pinned host memory (one batch ahead on a copy stream): PCIe-inclusive rate, never `value`
     h2d = None
     if world == 1 and args.cl == "ewc":
@@ -344,15 +427,29 @@ def main():
                        "global_batch": world * args.batch, "parallelism": f"dp{world}",
                        "final_loss": round(float(loss.item()), 4),
                        "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 3),
-                       "with_h2d_prefetch": h2d},
+                       "with_h2d_prefetch": h2d, "with_wer": wer_leg, "exchange": exchange},
         }
+        peaks = None
+        if not args.no_peaks:
+            try:
+                peaks = measure_peaks(dev)
+            except Exception as e:   # never lose the line to a microbenchmark
+                peaks = {"error": repr(e)}
+            out["peaks_measured"] = peaks
+
+        def frac_vs(ach, key, sheet):
+            d = {"datasheet": round(ach / sheet, 4)}
+            if peaks and key in peaks:
+                d["measured"] = round(ach / peaks[key], 4)
+            return d
         s = events.summary()
         if s is not None:
             avg_ms, avg_bytes, n = s
             ach = avg_bytes / (avg_ms * 1e-3) / 1e9
             traffic = None
             try:  # HBM bytes per launch from this round's PMC passes of the same command (profiles/r02_pmc_traffic.json)
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+                pmc_file = "r03_pmc_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) else "r02_pmc_traffic.json"
+                pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
                 if args.batch == 32 and args.seconds == 15.0 and args.preset == "medium":
                     traffic = pmc["kernels"].get(events.kernel_name, {}).get("hbm_bytes_per_launch")
             except Exception:
@@ -364,15 +461,24 @@ def main():
                                # the same launch priced on ALL B*T'*(U+1) cells (what the kernel streamed before it left the
                                # tiles behind the utterances' ends alone): for comparison with earlier rounds only
                                "full_lattice_bytes_per_launch": int(avg_bytes * events.full_scale),
-                               "frac_if_full_lattice": round(ach * events.full_scale / HBM_PEAK_GBS, 4)}
+                               "frac_if_full_lattice": round(ach * events.full_scale / HBM_PEAK_GBS, 4),
+                               "frac_of": frac_vs(ach, "hbm_copy_GBs", HBM_PEAK_GBS)}
         if mfma_events:
             ms_l = [a.elapsed_time(b) for a, b, _ in mfma_events]
             fl = sum(f for _, _, f in mfma_events) / len(mfma_events)
             avg = sum(ms_l) / len(ms_l)
             tf = fl / (avg * 1e-3) / 1e12
-            out["roofline_mfma"] = {"kernel": "joint_dh_fused_kernel", "bound": "mfma", "achieved": round(tf, 1), "peak": 2500.0,
-                                    "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4), "traffic": None, "launches": len(ms_l),
-                                    "avg_launch_ms": round(avg, 4), "algorithmic_flops_per_launch": int(fl)}
+            out["roofline_mfma"] = {"kernel": "joint_dh_fused_kernel", "bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TFS,
+                                    "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TFS, 4), "traffic": None, "launches": len(ms_l),
+                                    "avg_launch_ms": round(avg, 4), "algorithmic_flops_per_launch": int(fl),
+                                    "frac_of": frac_vs(tf, "mfma_bf16_TFs", MFMA_BF16_PEAK_TFS)}
+        # per-kernel table of this round's committed profile passes (tools/make_rooflines.py: share of the step, bound, achieved,
+        # fraction) -- the dominant kernels carry the picture, not one 2 % kernel
+        try:
+            if args.batch == 32 and args.seconds == 15.0 and args.preset == "medium" and args.cl == "ewc":
+                out["rooflines"] = json.load(open(os.path.join(ROOT, "profiles", "r03_rooflines.json")))["kernels"]
+        except Exception:
+            pass
         if not args.no_cpu_baseline and world == 1:
             kw = dict(d_model=cfg.d_model, n_layers=cfg.n_layers, n_heads=cfg.n_heads, pred_hidden=cfg.pred_hidden,
                       joint_hidden=cfg.joint_hidden)

@@ -438,6 +438,7 @@ class _ConformerBlockNativeFn(torch.autograd.Function):
             _lib.check(L.ia_conformer_block_bwd_a_phase(*a_args, 1, None, sp), "ia_conformer_block_bwd_a_phase")
             ob, og = rt.off["bn_b"][0], rt.off["bn_g"][0]
             Sg = torch.cat([rt.arena[ob:ob + d], rt.arena[og:og + d], torch.full((1,), float(N), dtype=torch.float32, device=dev)])
+            fast.SYNC_BN_COLLECTIVES += 1
             dist.all_reduce(Sg, group=ctx.group)
             Sg = (Sg[:2 * d] * (float(N) / Sg[2 * d])).contiguous()
             _lib.check(L.ia_conformer_block_bwd_a_phase(*a_args, 2, _ptr(Sg), sp), "ia_conformer_block_bwd_a_phase")

@@ -355,10 +355,15 @@ def bn_module_ok(bn):
     return type(bn) in (torch.nn.BatchNorm1d, torch.nn.SyncBatchNorm)
 
 
+SYNC_BN_COLLECTIVES = 0   # bench.py: SyncBatchNorm exchanges issued (forward sums; the blocks' backward exchanges count themselves)
+
+
 def bn_sync_sums(sums_cnt, n_local, d, bn, group):
     """sums_cnt [2d+1] f32 = [sum | sumsq | -]: all-reduce over the ranks with the row count, running statistics from the
     global batch, sums rescaled so that sums / n_local are the GLOBAL moments (csrc/encoder_ops.hip bn_sync_finish)."""
     import torch.distributed as dist
+    global SYNC_BN_COLLECTIVES
+    SYNC_BN_COLLECTIVES += 1
     sums_cnt[2 * d:].fill_(float(n_local))
     dist.all_reduce(sums_cnt, group=group)
     track = bn.track_running_stats and bn.running_mean is not None
