@@ -120,8 +120,8 @@ def test_config2_medium_bf16_step_matches_oracle():
     for e, n in rows[:8]:
         print(f"  {e:.3e}  {n}")
     print("median", f"{rows[len(rows) // 2][0]:.3e}")
-    assert rows[0][0] <= 0.04, rows[0]               # observed 1.9e-2 (linear_pos of the first trainable layer)
-    assert rows[len(rows) // 2][0] <= 0.01           # observed 4.0e-3
+    assert rows[0][0] <= 0.03, rows[0]               # observed 2.0e-2 (linear_pos of the first trainable layer) + 50 %
+    assert rows[len(rows) // 2][0] <= 0.006          # observed 3.9e-3 + 50 %
     # encoder frame counts bit-exact, BatchNorm running stats of a frozen layer updated alike (reference quirk)
     bo, bp = o.encoder.layers[3].conv.batch_norm, m.encoder.layers[3].conv.batch_norm
     assert torch.allclose(bp.running_var.cpu(), bo.running_var, rtol=3e-2, atol=1e-4)
@@ -148,8 +148,8 @@ def test_config2_full_benchmarked_batch_32x15s_matches_oracle():
     for e, n in rows[:6]:
         print(f"  {e:.3e}  {n}")
     print("median", f"{rows[len(rows) // 2][0]:.3e}")
-    assert rows[0][0] <= 0.04, rows[0]
-    assert rows[len(rows) // 2][0] <= 0.01
+    assert rows[0][0] <= 0.023, rows[0]              # observed 1.5e-2 (more utterances average the rounding noise) + 50 %
+    assert rows[len(rows) // 2][0] <= 0.0055         # observed 3.6e-3 + 50 %
 
 
 # ------------------------------------------------------------------------------------------------ configs[2]
@@ -224,9 +224,11 @@ def test_config4_lwf_teacher_student_medium_dims():
     assert abs(ct_p.item() - ct_o.item()) <= 2e-3 * scale + 0.05 * abs(ct_o.item())
     assert math.isclose(tot_p.item(), tot_o.item(), rel_tol=5e-3)
     rows = _grad_table(m, o, min_checked=90)
-    print("worst", [(f"{e:.3e}", n) for e, n in rows[:5]])
-    assert rows[0][0] <= 0.10
-    assert rows[len(rows) // 2][0] <= 0.03
+    print("worst", [(f"{e:.3e}", n) for e, n in rows[:5]], "median", f"{rows[len(rows) // 2][0]:.3e}")
+    # observed worst 3.0e-2 (pos_bias_v / linear_pos of the first trainable layer: the KD terms add a second, f16-scaled lattice
+    # gradient); worst bound = observed + 50 %
+    assert rows[0][0] <= 0.045, rows[0]
+    assert rows[len(rows) // 2][0] <= 0.02
 
 
 # ------------------------------------------------------------------------------------------------ configs[0]
@@ -245,8 +247,10 @@ def test_config1_small_bf16_step_matches_oracle():
     _check_losses(mp, mo, 5e-3)
     rows = _grad_table(m, o, min_checked=90)
     print("worst", [(f"{e:.3e}", n) for e, n in rows[:5]], "median", f"{rows[len(rows) // 2][0]:.3e}")
-    assert rows[0][0] <= 0.08
-    assert rows[len(rows) // 2][0] <= 0.03
+    # d = 144: k-tiles straddle the 36-wide heads and the bf16 rounding is relatively larger on 5 s utterances (few frames to
+    # average over): observed worst 3.5e-2 (norm_conv / depthwise of layer 14), median 6.3e-3; bounds = observed + 50 %
+    assert rows[0][0] <= 0.053, rows[0]
+    assert rows[len(rows) // 2][0] <= 0.0095
 
 
 # ------------------------------------------------------------------------------------------------ configs[4]
@@ -265,5 +269,5 @@ def test_config5_large_30s_bf16_step_matches_oracle():
     _check_losses(mp, mo, 5e-3)
     rows = _grad_table(m, o, min_checked=90)
     print("worst", [(f"{e:.3e}", n) for e, n in rows[:5]], "median", f"{rows[len(rows) // 2][0]:.3e}")
-    assert rows[0][0] <= 0.08
-    assert rows[len(rows) // 2][0] <= 0.03
+    assert rows[0][0] <= 0.029, rows[0]              # observed 1.9e-2 (linear_pos of layer 16) + 50 %
+    assert rows[len(rows) // 2][0] <= 0.007          # observed 4.7e-3 + 50 %
