@@ -19,6 +19,9 @@
 // no cross-wave exchange, one barrier per pass.
 // (The first version partitioned the rows and reduced across waves with LDS float atomics: ~250 cycles per atomic
 // instruction under 4-way conflicts, and 5x re-read of G by the hidden-slice siblings -- 2.7 ms.)
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "joint_common.h"
 
 namespace {
@@ -27,10 +30,19 @@ constexpr int DH_KP = 288;               // vocabulary axis padded to 9 MFMA k-s
 constexpr int DH_KS = DH_KP / 32;
 constexpr int DH_AROW = DH_KP * 2 + 16;  // LDS bytes per G row (592: conflict-free ds_read_b128 A fragments)
 constexpr int DH_ROWS = 64;              // rows per pass: 4 frames x 16 labels
-constexpr int DH_NW = 80;                // hidden units per wave (5 column tiles)
-constexpr int DH_NB = 4 * DH_NW;         // hidden units per workgroup
-constexpr int DH_NT = DH_NW / 16;
+constexpr int DH_NB_MAX = 384;           // most hidden units a workgroup covers (sizes the d f accumulator in LDS)
 constexpr int DH_TT = 16;                // frames per workgroup (= the partial-row chunk of the d g finishing sum)
+// Two decompositions of the 320 units over the waves of a workgroup (template parameters NT = 16-unit column tiles per wave,
+// WAVES):
+//   NT 5, 4 waves  (80 units per wave, 180 resident W^T registers: ONE wave per SIMD) -- the round-2 kernel.  Its pass is
+//                  ~730 VALU instructions of mask-table generation + 180 MFMAs + ~950 VALU of epilogue, strictly one after the
+//                  other: nothing overlaps at one wave per SIMD (0.96 ms, 0.14 matrix-pipe busy).
+//   NT 2, 10 waves (32 units per wave, 72 resident registers: 168 registers per wave, 3 / 3 / 2 / 2 waves per SIMD) -- the waves
+//                  of a SIMD are at different points of their passes, so one wave's mask generation / epilogue issues under the
+//                  others' MFMAs; all ten read the same A fragments from LDS.  0.74 ms (A/B in one process: 0.977 -> 0.742).
+//   (NT 2 with 12 waves -- 384 units per workgroup, three waves on EVERY SIMD, four idle waves in the second workgroup of H = 640 --
+//    measured the same 0.74 ms: the 3 / 3 / 2 / 2 imbalance is not what limits the 10-wave form.)
+// IA_DH_WAVES=4 selects the first (A/B switch); results are bit-identical (same products, same summation order per unit).
 
 struct DhArgs {
     const _Float16* G; const _Float16* Wt; const _Float16* f; const _Float16* g;
@@ -49,8 +61,12 @@ __device__ __forceinline__ void dh_mfma(f4& acc, const h8& a_frag, const h8& b_f
     asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a_frag), "a"(b_frag));
 }
 
-template <bool DROPOUT>
-__global__ __launch_bounds__(256, 1) void joint_dh_fused_kernel(DhArgs a) {
+template <bool DROPOUT, int DH_NT, int DH_WAVES>
+__global__ __launch_bounds__(DH_WAVES * 64, (DH_WAVES + 3) / 4) void joint_dh_fused_kernel(DhArgs a) {
+    constexpr int DH_NW = 16 * DH_NT;            // hidden units per wave
+    constexpr int DH_NB = DH_NW * DH_WAVES;      // hidden units per workgroup
+    constexpr int DH_THREADS = DH_WAVES * 64;
+    static_assert(DH_NB <= DH_NB_MAX, "d f accumulator rows");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sA = smem;                                                      // 2 x [64 rows][592 B]
     float* sdf = reinterpret_cast<float*>(smem + 2 * DH_ROWS * DH_AROW);           // [16 frames][320]
@@ -83,8 +99,8 @@ __global__ __launch_bounds__(256, 1) void joint_dh_fused_kernel(DhArgs a) {
                 Bf[nt][ks] = *reinterpret_cast<const h8*>(a.Wt + (size_t)(nb + nt * 16 + c) * DH_KP + ks * 32 + q * 8);
     }
     // zero both A buffers once (the K tail columns LD..287 are never written again) and the d f accumulator
-    for (int i = tid; i < 2 * DH_ROWS * DH_AROW / 16; i += 256) reinterpret_cast<uint4*>(sA)[i] = make_uint4(0, 0, 0, 0);
-    for (int i = tid; i < DH_TT * DH_NB; i += 256) sdf[i] = 0.f;
+    for (int i = tid; i < 2 * DH_ROWS * DH_AROW / 16; i += DH_THREADS) reinterpret_cast<uint4*>(sA)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < DH_TT * DH_NB; i += DH_THREADS) sdf[i] = 0.f;
     __syncthreads();
 
     // ---- loader: the pass's 64 G rows go global -> LDS directly (global_load_lds_dwordx4: no staging registers, no
@@ -97,7 +113,7 @@ __global__ __launch_bounds__(256, 1) void joint_dh_fused_kernel(DhArgs a) {
     const int vpr = LD / 8;
 #define DH_ASYNC(ut_, pt_, buf_)                                                                                   \
     do {                                                                                                           \
-        for (int blk_ = wave; blk_ < DH_NBLK; blk_ += 4) {                                                         \
+        for (int blk_ = wave; blk_ < DH_NBLK; blk_ += DH_WAVES) {                                                  \
             const int P_ = blk_ * 64 + lane;                                                                       \
             const int row_ = P_ / DH_SLOTS, col_ = P_ - row_ * DH_SLOTS;                                           \
             int t_ = t0 + (pt_) * 4 + (row_ >> 4); t_ = t_ < T ? t_ : T - 1;                                       \
@@ -165,14 +181,16 @@ __global__ __launch_bounds__(256, 1) void joint_dh_fused_kernel(DhArgs a) {
 #pragma unroll
                 for (int nt = 0; nt < DH_NT; ++nt) acc[mt][nt] = (f4){0.f, 0.f, 0.f, 0.f};
             const unsigned char* sAl = sA + (ps & 1) * (DH_ROWS * DH_AROW) + c * DH_AROW + q * 16;
-#define DH_TIE_ACC                                                                                                  \
+#define DH_TIE_ACC5                                                                                                 \
     "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]), "+v"(acc[0][4]), "+v"(acc[1][0]), "+v"(acc[1][1]),  \
         "+v"(acc[1][2]), "+v"(acc[1][3]), "+v"(acc[1][4]), "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[2][2]), "+v"(acc[2][3]), \
         "+v"(acc[2][4]), "+v"(acc[3][0]), "+v"(acc[3][1]), "+v"(acc[3][2]), "+v"(acc[3][3]), "+v"(acc[3][4])
-            static_assert(DH_NT == 5, "DH_TIE_ACC lists 4 x 5 accumulators");
+#define DH_TIE_ACC2                                                                                                 \
+    "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[3][0]), "+v"(acc[3][1])
+            static_assert(DH_NT == 5 || DH_NT == 2, "the accumulator tie lists are written out for 5 and 2 column tiles");
             // The MFMAs below are inline asm: the compiler's hazard recogniser does not see them.  Both waits are tied to every
             // accumulator, so they sit after the VALU zero-fill / after the last MFMA and before any use.
-            asm volatile("s_nop 4" : DH_TIE_ACC);
+            if constexpr (DH_NT == 5) { asm volatile("s_nop 4" : DH_TIE_ACC5); } else { asm volatile("s_nop 4" : DH_TIE_ACC2); }
             // one wave per SIMD: the A fragments of k-step ks+1 are requested before the 20 MFMAs of k-step ks are issued
             h8 Af[2][4];
 #pragma unroll
@@ -190,8 +208,9 @@ __global__ __launch_bounds__(256, 1) void joint_dh_fused_kernel(DhArgs a) {
                     for (int mt = 0; mt < 4; ++mt)
                         dh_mfma(acc[mt][nt], Af[ks & 1][mt], Bf[nt][ks]);
             }
-            asm volatile("s_nop 15\n\ts_nop 15" : DH_TIE_ACC);
-#undef DH_TIE_ACC
+            if constexpr (DH_NT == 5) { asm volatile("s_nop 15\n\ts_nop 15" : DH_TIE_ACC5); } else { asm volatile("s_nop 15\n\ts_nop 15" : DH_TIE_ACC2); }
+#undef DH_TIE_ACC5
+#undef DH_TIE_ACC2
             // ---- epilogue on the accumulator layout: row = mt*16 + q*4 + r -> (t = tp+mt, u = u0+4q+r), col = nt*16+c
             __builtin_amdgcn_s_waitcnt(0xC07F);  // mask table written (wave-private, in-order LDS)
             float ssum[4][DH_NT];
@@ -293,7 +312,7 @@ __global__ __launch_bounds__(256) void joint_dh_dg_finish_kernel(const float* __
 }  // namespace
 
 extern "C" int ia_joint_dh_fused_supported(int U1, int H, int LD) {
-    return (U1 >= 1 && H >= DH_NW && H % DH_NW == 0 && LD % 8 == 0 && LD >= 8 && LD <= DH_KP) ? 1 : 0;
+    return (U1 >= 1 && H >= 80 && H % 80 == 0 && LD % 8 == 0 && LD >= 8 && LD <= DH_KP) ? 1 : 0;   // (80: either decomposition)
 }
 
 extern "C" int ia_joint_dh_k(void) { return DH_KP; }
@@ -315,24 +334,57 @@ extern "C" int ia_joint_dh_fused(const void* G, const void* Wt, const void* f, c
     a.G = (const _Float16*)G; a.Wt = (const _Float16*)Wt; a.f = (const _Float16*)f; a.g = (const _Float16*)g;
     a.act_lens = act_lens; a.label_lens = label_lens; a.df = df; a.part = (float*)scratch;
     a.B = B; a.T = T; a.U1 = U1; a.H = H; a.LD = LD;
-    a.nh = (H + DH_NB - 1) / DH_NB;
+    a.nh = 0;   // (set with the decomposition below)
     a.inv_kappa = inv_kappa; a.seed = seed;
     a.thr = (unsigned)(dropout_p * 256.f + 0.5f);
-    const size_t lds = 2 * (size_t)DH_ROWS * DH_AROW + (size_t)DH_TT * DH_NB * sizeof(float) + 4096;
+    const char* wv_env = getenv("IA_DH_WAVES");
+    int waves = (H % 32 == 0) ? 10 : 4;
+    if (wv_env && atoi(wv_env) == 4) waves = 4;
+    const bool ten = waves == 10;
+    const int nb = waves == 4 ? 320 : 32 * waves;
+    a.nh = (H + nb - 1) / nb;
+    const size_t lds = 2 * (size_t)DH_ROWS * DH_AROW + (size_t)DH_TT * nb * sizeof(float) + (size_t)waves * 1024;
     const int ntt = (T + DH_TT - 1) / DH_TT;
-    const dim3 grid((unsigned)(B * ntt * a.nh)), blk(256);
+    const dim3 grid((unsigned)(B * ntt * a.nh)), blk(waves * 64);
     hipStream_t st = (hipStream_t)stream;
-    if (a.thr > 0) {
-        IA_SET_MAX_LDS_ONCE((joint_dh_fused_kernel<true>), (int)lds);
-        hipLaunchKernelGGL((joint_dh_fused_kernel<true>), grid, blk, lds, st, a);
+#define DH_LAUNCH(DROP_, NT_, WV_)                                                                  \
+    do {                                                                                            \
+        static int granted_ = -1;                                                                   \
+        if ((int)lds > granted_) {                                                                  \
+            const hipError_t ea_ = hipFuncSetAttribute((const void*)joint_dh_fused_kernel<DROP_, NT_, WV_>,                     \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
+            if (ea_ != hipSuccess) {                                                                \
+                if (getenv("IA_DEBUG")) fprintf(stderr, "ia_joint_dh_fused: hipFuncSetAttribute(%d waves, %zu B): %s\n", WV_, lds, hipGetErrorString(ea_)); \
+                (void)hipGetLastError();                                                            \
+                return IA_LAUNCH_FAILED;                                                            \
+            }                                                                                       \
+            granted_ = (int)lds;                                                                    \
+        }                                                                                           \
+        hipLaunchKernelGGL((joint_dh_fused_kernel<DROP_, NT_, WV_>), grid, blk, lds, st, a);         \
+    } while (0)
+    if (ten) {
+        if (a.thr > 0) DH_LAUNCH(true, 2, 10); else DH_LAUNCH(false, 2, 10);
     } else {
-        IA_SET_MAX_LDS_ONCE((joint_dh_fused_kernel<false>), (int)lds);
-        hipLaunchKernelGGL((joint_dh_fused_kernel<false>), grid, blk, lds, st, a);
+        if (a.thr > 0) DH_LAUNCH(true, 5, 4); else DH_LAUNCH(false, 5, 4);
     }
-    IA_RETURN_IF_LAUNCH_FAILED();
+#undef DH_LAUNCH
+    {
+        const hipError_t e_ = hipGetLastError();
+        if (e_ != hipSuccess) {
+            if (getenv("IA_DEBUG")) {
+                hipFuncAttributes fa;
+                const hipError_t e2 = ten ? hipFuncGetAttributes(&fa, (const void*)joint_dh_fused_kernel<true, 2, 10>)
+                                          : hipFuncGetAttributes(&fa, (const void*)joint_dh_fused_kernel<true, 5, 4>);
+                fprintf(stderr, "ia_joint_dh_fused: launch failed: %s (waves %d, lds %zu; attr rc %d maxThreadsPerBlock %d numRegs %d "
+                                "maxDynShared %d sharedSizeBytes %zu localSizeBytes %zu)\n", hipGetErrorString(e_), waves, lds, (int)e2,
+                        fa.maxThreadsPerBlock, fa.numRegs, fa.maxDynamicSharedSizeBytes, fa.sharedSizeBytes, fa.localSizeBytes);
+            }
+            return IA_LAUNCH_FAILED;
+        }
+    }
     const int64_t n4 = (int64_t)B * U1 * H / 4;
     const int fgrid = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
-    hipLaunchKernelGGL(joint_dh_dg_finish_kernel, dim3(fgrid < 1 ? 1 : fgrid), blk, 0, st, (const float*)scratch, dg, act_lens,
+    hipLaunchKernelGGL(joint_dh_dg_finish_kernel, dim3(fgrid < 1 ? 1 : fgrid), dim3(256), 0, st, (const float*)scratch, dg, act_lens,
                        label_lens, B, T, U1, H, inv_kappa);
     IA_RETURN_IF_LAUNCH_FAILED();
     return IA_OK;
