@@ -182,6 +182,13 @@ size_t ia_joint_dh_fused_scratch_bytes(int B, int T, int U1, int H);
 int ia_joint_dh_fused(const void* G, const void* Wt, const void* f, const void* g, const int64_t* act_lens,
                       const int64_t* label_lens, float* df, float* dg, int B, int T, int U1, int H, int LD,
                       float inv_kappa, float dropout_p, unsigned seed, void* scratch, ia_stream_t stream);
+/* ... with optional bf16 images of both results (df_bf16 [B,T,H], dg_bf16 [B,U1,H]: the A operands of the joint's enc / pred
+ * projection backward GEMMs; the f32 outputs may then be NULL) and zero_dead_df != 0: the finishing kernel zeroes the rows of
+ * d f in the 16-frame chunks the main kernel skips, so the caller does not have to clear d f beforehand. */
+int ia_joint_dh_fused_ex(const void* G, const void* Wt, const void* f, const void* g, const int64_t* act_lens,
+                         const int64_t* label_lens, float* df, float* dg, void* df_bf16, void* dg_bf16, int zero_dead_df, int B,
+                         int T, int U1, int H, int LD, float inv_kappa, float dropout_p, unsigned seed, void* scratch,
+                         ia_stream_t stream);
 /* ia_joint_dw_fused: weight gradient of the per-language Linear(H -> V) of the joint (A/modules/rnnt.py:1694-1703,
  * applied in joint_after_projection :1633-1647) straight from G and the encoder / prediction projections:
  *   dW[v*H + h] = sum_cells G[cell,v] * keep*relu(f[b,t,h] + g[b,u,h])          ([LD, H] f32)

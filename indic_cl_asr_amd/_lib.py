@@ -109,6 +109,7 @@ SIGNATURES = {
     "ia_joint_dh_fused_supported": (_i, [_i, _i, _i]),
     "ia_joint_dh_k": (_i, []),
     "ia_joint_dh_fused": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _c.c_uint, _vp, _vp]),
+    "ia_joint_dh_fused_ex": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _c.c_uint, _vp, _vp]),
     "ia_joint_dh_fused_scratch_bytes": (_sz, [_i, _i, _i, _i]),
     "ia_joint_dw_fused_supported": (_i, [_i, _i, _i]),
     "ia_joint_dw_fused_scratch_elems": (_i64, [_i, _i, _i, _i, _i]),

@@ -19,6 +19,7 @@
 // no cross-wave exchange, one barrier per pass.
 // (The first version partitioned the rows and reduced across waves with LDS float atomics: ~250 cycles per atomic
 // instruction under 4-way conflicts, and 5x re-read of G by the hidden-slice siblings -- 2.7 ms.)
+#include <hip/hip_bf16.h>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -48,6 +49,7 @@ struct DhArgs {
     const _Float16* G; const _Float16* Wt; const _Float16* f; const _Float16* g;
     const int64_t* act_lens; const int64_t* label_lens;
     float* df; float* part;
+    __bf16* dfb;     // optional bf16 copy of d f (the A operand of the encoder projection's backward GEMMs)
     int B, T, U1, H, LD, nh;
     float inv_kappa;
     unsigned seed, thr;
@@ -279,14 +281,22 @@ __global__ __launch_bounds__(DH_WAVES * 64, (DH_WAVES + 3) / 4) void joint_dh_fu
     if (wave_on) {
         for (int i = lane; i < DH_TT * DH_NW; i += 64) {
             const int tr = i / DH_NW, n = i - tr * DH_NW;
-            if (t0 + tr < T)
-                a.df[((size_t)b * T + t0 + tr) * H + n0 + n] = sdf[(size_t)tr * DH_NB + wave * DH_NW + n] * a.inv_kappa;
+            if (t0 + tr < T) {
+                const float v = sdf[(size_t)tr * DH_NB + wave * DH_NW + n] * a.inv_kappa;
+                const size_t o = ((size_t)b * T + t0 + tr) * H + n0 + n;
+                if (a.df) a.df[o] = v;
+                if (a.dfb) a.dfb[o] = (__bf16)v;
+            }
         }
     }
 }
 
 // dg[b][u][:] = inv_kappa * sum over the utterance's live 16-frame chunks of part[b][chunk][u][:]  (u <= label_len)
+// (also: the rows of d f the main kernel never visits -- whole 16-frame chunks behind an utterance's end -- are zeroed here when
+//  zero_df is set, so the caller needs no 30 MB memset in front of the launch; dgb = optional bf16 copy of d g)
 __global__ __launch_bounds__(256) void joint_dh_dg_finish_kernel(const float* __restrict__ part, float* __restrict__ dg,
+                                                                 __bf16* __restrict__ dgb, float* __restrict__ df,
+                                                                 __bf16* __restrict__ dfb, int zero_df,
                                                                  const int64_t* __restrict__ act_lens,
                                                                  const int64_t* __restrict__ label_lens, int B, int T, int U1,
                                                                  int H, float inv_kappa) {
@@ -306,7 +316,26 @@ __global__ __launch_bounds__(256) void joint_dh_dg_finish_kernel(const float* __
                 acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
             }
         }
-        reinterpret_cast<float4*>(dg)[i] = make_float4(acc.x * inv_kappa, acc.y * inv_kappa, acc.z * inv_kappa, acc.w * inv_kappa);
+        const float4 o = make_float4(acc.x * inv_kappa, acc.y * inv_kappa, acc.z * inv_kappa, acc.w * inv_kappa);
+        if (dg) reinterpret_cast<float4*>(dg)[i] = o;
+        if (dgb) {
+            union { uint2 u; __bf16 h[4]; } pk;
+            pk.h[0] = (__bf16)o.x; pk.h[1] = (__bf16)o.y; pk.h[2] = (__bf16)o.z; pk.h[3] = (__bf16)o.w;
+            reinterpret_cast<uint2*>(dgb)[i] = pk.u;
+        }
+    }
+    if (zero_df) {
+        const int64_t frow4 = (int64_t)T * H / 4, m4 = (int64_t)B * frow4;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m4; i += (int64_t)gridDim.x * 256) {
+            const int64_t b = i / frow4, r = i - b * frow4;
+            const int t = (int)(r / (H / 4));
+            int Tb = (int)act_lens[b]; Tb = Tb < T ? Tb : T;
+            const int tlive = (Tb + DH_TT - 1) / DH_TT * DH_TT;     // the main kernel wrote every frame of the live chunks
+            if (t >= tlive) {
+                if (df) reinterpret_cast<float4*>(df)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (dfb) reinterpret_cast<uint2*>(dfb)[i] = make_uint2(0u, 0u);
+            }
+        }
     }
 }
 }  // namespace
@@ -325,14 +354,25 @@ extern "C" size_t ia_joint_dh_fused_scratch_bytes(int B, int T, int U1, int H) {
 extern "C" int ia_joint_dh_fused(const void* G, const void* Wt, const void* f, const void* g, const int64_t* act_lens,
                                  const int64_t* label_lens, float* df, float* dg, int B, int T, int U1, int H, int LD,
                                  float inv_kappa, float dropout_p, unsigned seed, void* scratch, ia_stream_t stream) {
-    if (!G || !Wt || !f || !g || !act_lens || !label_lens || !df || !dg || !scratch || B <= 0 || T <= 0) return IA_INVALID_VALUE;
+    if (!df || !dg) return IA_INVALID_VALUE;
+    return ia_joint_dh_fused_ex(G, Wt, f, g, act_lens, label_lens, df, dg, nullptr, nullptr, 0, B, T, U1, H, LD, inv_kappa, dropout_p, seed,
+                                scratch, stream);
+}
+
+extern "C" int ia_joint_dh_fused_ex(const void* G, const void* Wt, const void* f, const void* g, const int64_t* act_lens,
+                                    const int64_t* label_lens, float* df, float* dg, void* df_bf16, void* dg_bf16, int zero_dead_df,
+                                    int B, int T, int U1, int H, int LD, float inv_kappa, float dropout_p, unsigned seed,
+                                    void* scratch, ia_stream_t stream) {
+    if (!G || !Wt || !f || !g || !act_lens || !label_lens || (!df && !df_bf16) || (!dg && !dg_bf16) || !scratch || B <= 0 || T <= 0)
+        return IA_INVALID_VALUE;
     if (!ia_joint_dh_fused_supported(U1, H, LD)) return IA_UNSUPPORTED;
-    if (!ia_is_aligned(G, 16) || !ia_is_aligned(Wt, 16) || !ia_is_aligned(dg, 16) || !ia_is_aligned(scratch, 16) ||
-        dropout_p < 0.f || dropout_p >= 1.f)
+    if (!ia_is_aligned(G, 16) || !ia_is_aligned(Wt, 16) || (dg && !ia_is_aligned(dg, 16)) || (df && !ia_is_aligned(df, 16)) ||
+        (df_bf16 && !ia_is_aligned(df_bf16, 16)) || (dg_bf16 && !ia_is_aligned(dg_bf16, 16)) || !ia_is_aligned(scratch, 16) ||
+        dropout_p < 0.f || dropout_p >= 1.f || H % 4 != 0)
         return IA_INVALID_VALUE;
     DhArgs a;
     a.G = (const _Float16*)G; a.Wt = (const _Float16*)Wt; a.f = (const _Float16*)f; a.g = (const _Float16*)g;
-    a.act_lens = act_lens; a.label_lens = label_lens; a.df = df; a.part = (float*)scratch;
+    a.act_lens = act_lens; a.label_lens = label_lens; a.df = df; a.dfb = (__bf16*)df_bf16; a.part = (float*)scratch;
     a.B = B; a.T = T; a.U1 = U1; a.H = H; a.LD = LD;
     a.nh = 0;   // (set with the decomposition below)
     a.inv_kappa = inv_kappa; a.seed = seed;
@@ -384,8 +424,8 @@ extern "C" int ia_joint_dh_fused(const void* G, const void* Wt, const void* f, c
     }
     const int64_t n4 = (int64_t)B * U1 * H / 4;
     const int fgrid = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
-    hipLaunchKernelGGL(joint_dh_dg_finish_kernel, dim3(fgrid < 1 ? 1 : fgrid), dim3(256), 0, st, (const float*)scratch, dg, act_lens,
-                       label_lens, B, T, U1, H, inv_kappa);
+    hipLaunchKernelGGL(joint_dh_dg_finish_kernel, dim3(fgrid < 1 ? 1 : fgrid), dim3(256), 0, st, (const float*)scratch, dg,
+                       (__bf16*)dg_bf16, df, (__bf16*)df_bf16, zero_dead_df ? 1 : 0, act_lens, label_lens, B, T, U1, H, inv_kappa);
     IA_RETURN_IF_LAUNCH_FAILED();
     return IA_OK;
 }

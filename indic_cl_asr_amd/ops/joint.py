@@ -321,9 +321,19 @@ class _FusedJointRNNT(torch.autograd.Function):
             act_lens, label_lens = stash.box_t, stash.box_um1
         del E
         LDH = H + 8
-        df = torch.zeros(B, T, H, dtype=torch.float32, device=dev)
-        dg = torch.zeros(B, U1, H, dtype=torch.float32, device=dev)
-        if USE_FUSED_DH and L.ia_joint_dh_fused_supported(U1, H, LD):
+        dh_fused = bool(USE_FUSED_DH and L.ia_joint_dh_fused_supported(U1, H, LD))
+        proj_mode = ctx.proj is not None
+        dfb = dgb = None
+        if dh_fused and proj_mode:
+            # projection mode: only the bf16 images are needed (operands of the projections' backward GEMMs); the finishing
+            # kernel zeroes the dead rows itself: no fp32 d f / d g tensors, no memsets, no casts
+            df = dg = None
+            dfb = torch.empty(B * T, H, dtype=torch.bfloat16, device=dev)
+            dgb = torch.empty(B * U1, H, dtype=torch.bfloat16, device=dev)
+        else:
+            df = torch.zeros(B, T, H, dtype=torch.float32, device=dev)
+            dg = torch.zeros(B, U1, H, dtype=torch.float32, device=dev)
+        if dh_fused:
             # dH = G @ W, relu/dropout mask and both reductions in one MFMA kernel (dH never reaches memory)
             Wt = ctx.Wt
             if Wt is None:
@@ -333,10 +343,11 @@ class _FusedJointRNNT(torch.autograd.Function):
             ev = MFMA_PROFILE_HOOK(2.0 * cells * H * LD) if MFMA_PROFILE_HOOK is not None else None   # bench.py: torch events
             if ev is not None:
                 ev[0].record()
-            st = L.ia_joint_dh_fused(_lib.ptr(G), _lib.ptr(Wt), _lib.ptr(f16), _lib.ptr(g16), _lib.ptr(act_lens),
-                                     _lib.ptr(label_lens), _lib.ptr(df), _lib.ptr(dg), B, T, U1, H, LD, 1.0 / kappa, p, seed,
-                                     _lib.ptr(scr), _lib.stream_ptr())
-            _lib.check(st, "ia_joint_dh_fused")
+            st = L.ia_joint_dh_fused_ex(_lib.ptr(G), _lib.ptr(Wt), _lib.ptr(f16), _lib.ptr(g16), _lib.ptr(act_lens),
+                                        _lib.ptr(label_lens), _lib.ptr(df), _lib.ptr(dg), _lib.ptr(dfb), _lib.ptr(dgb),
+                                        1 if dfb is not None else 0, B, T, U1, H, LD, 1.0 / kappa, p, seed, _lib.ptr(scr),
+                                        _lib.stream_ptr())
+            _lib.check(st, "ia_joint_dh_fused_ex")
             if ev is not None:
                 ev[1].record()
         else:
@@ -375,8 +386,9 @@ class _FusedJointRNNT(torch.autograd.Function):
         # ---- projection mode: the two projections' backward on the HIP GEMMs, every parameter gradient in one accumulation launch
         xb, gb, We16, Wg16, g_time_major, d, Hp, We, be, Wg, bg = ctx.proj
         ctx.proj = None
-        dfb = df.view(B * T, H).to(torch.bfloat16)
-        dgb = dg.view(B * U1, H).to(torch.bfloat16)
+        if dfb is None:
+            dfb = df.view(B * T, H).to(torch.bfloat16)
+            dgb = dg.view(B * U1, H).to(torch.bfloat16)
         WeT, WgT = fast.transpose16_multi([We16, Wg16])                  # [d, H], [Hp, H]: "weights" of dX = dY W
         dx = dgin = None
         if need[0]:
