@@ -30,15 +30,24 @@ constexpr int LS_STICKY_WORD = 32;  // scratch word that survives launches: set 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
 // All workgroups have published phase `phase` (counter counts arrivals monotonically within the launch).
+// Publish form R1 of the CDNA guide (Guideline 16): the exchanged values are stored WRITE-THROUGH (sc1: agent-scope relaxed
+// atomic stores of packed dwords, ls_store_pair below), every storing wave drains its stores, the workgroup meets, ONE lane
+// arrives on the counter -- no release fence (a buffer_wbl2 costs ~1.7 us per step on the serial chain of ~100 steps; the
+// first version fenced).  The consumer side keeps its agent-scope acquire in front of its plain loads.
 __device__ __forceinline__ void grid_arrive(unsigned* counter) {
-    // every storing wave drains its stores, the workgroup meets, ONE lane releases at agent scope and arrives
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // EVERY storing wave (Pitfall 14)
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Two bf16 values of neighbouring units (lanes 2i, 2i+1 hold consecutive elements of one row) leave as ONE write-through dword
+// store from the even lane.  `p` = address of this lane's element (2-byte units, even lanes 4-byte aligned).
+__device__ __forceinline__ void ls_store_pair(__bf16* p, float v, bool live) {
+    union { __bf16 h; unsigned short u; } me;
+    me.h = (__bf16)v;
+    const unsigned mine = me.u;
+    const unsigned other = (unsigned)__shfl_down((int)mine, 1, 64);
+    if (live && !(threadIdx.x & 1))
+        __hip_atomic_store((gu32*)(unsigned*)(void*)p, mine | (other << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void grid_wait(unsigned* counter, unsigned target, unsigned* status, unsigned spin_limit) {
     if (threadIdx.x == 0) {
@@ -148,9 +157,12 @@ __global__ __launch_bounds__(LS_THREADS, 1) void lstm_fwd_kernel(
                 const float go = sigmoidf_(sG[(3 * LS_MAXB + b) * 16 + ul] + gxp[k][3]);
                 cst[k] = gf * cst[k] + gi * gg;
                 const float h = go * tanhf(cst[k]);
-                hdst[(size_t)b * H + u0 + ul] = (__bf16)h;
                 kg[k][0] = gi; kg[k][1] = gf; kg[k][2] = gg; kg[k][3] = go; kh[k] = h;
+            } else {
+                kh[k] = 0.f;
             }
+            // (outside the branch: the pair exchange needs both lanes; rows b >= B store nothing)
+            ls_store_pair(hdst + (size_t)(b < B ? b : 0) * H + u0 + ul, kh[k], b < B);
         }
         if (t + 1 < U) grid_arrive(sync);
         // off the chain: what only the caller / the backward reads, and the next step's input projections
@@ -259,9 +271,14 @@ __global__ __launch_bounds__(LS_THREADS, 1) void lstm_bwd_kernel(
                 const float dgg = dct * gi * (1.f - gg * gg);
                 const float dout = dh * tc * go * (1.f - go);
                 dcc[k] = dct * gf;
-                const size_t xo = (size_t)b * H4 + u0 + ul;
-                dst[xo] = (__bf16)di; dst[xo + H] = (__bf16)dfg; dst[xo + 2 * H] = (__bf16)dgg; dst[xo + 3 * H] = (__bf16)dout;
                 kd[k][0] = di; kd[k][1] = dfg; kd[k][2] = dgg; kd[k][3] = dout;
+            } else {
+                kd[k][0] = kd[k][1] = kd[k][2] = kd[k][3] = 0.f;
+            }
+            {
+                __bf16* xo = dst + (size_t)(b < B ? b : 0) * H4 + u0 + ul;
+#pragma unroll
+                for (int gte = 0; gte < 4; ++gte) ls_store_pair(xo + (size_t)gte * H, kd[k][gte], b < B);
             }
         }
         if (t > 0) grid_arrive(sync);
