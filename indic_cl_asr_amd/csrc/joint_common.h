@@ -9,14 +9,12 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-constexpr int JS = 3;           // t per wave: 3 x 17 accumulator tiles = 204 registers (the AGPR half), everything else in VGPRs
-constexpr int JT = 4 * JS;      // t per workgroup (4 waves)
+// (frames per wave / waves per workgroup of the forward kernel are template parameters of joint_fwd_kernel: csrc/joint_fwd.hip)
 constexpr int JU = 16;          // u per workgroup (= MFMA M)
 constexpr int JNT = 17;         // 16-wide column tiles: V <= 272
 constexpr int JVP = JNT * 16;   // 272
 constexpr int JKC = 64;         // K chunk staged in LDS
 constexpr int JWROW = JKC * 2 + 16;  // bytes per W row in LDS (padded)
-constexpr int J_THREADS = 256;
 
 __device__ __forceinline__ unsigned hash32(unsigned x) {  // murmur3 finaliser
     x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;

@@ -18,6 +18,8 @@
 // side arrays that rnnt_alpha_beta consumes.
 #include <hip/hip_fp16.h>
 
+#include <stdlib.h>
+
 #include "ia_common.h"
 #include "rnnt_ws.h"
 #include "joint_common.h"
@@ -40,8 +42,13 @@ struct JointFwdArgs {
     unsigned seed, thr;
 };
 
-template <bool DROPOUT>
-__global__ __launch_bounds__(J_THREADS, 1) void joint_fwd_kernel(JointFwdArgs a) {
+// Template parameters: JS = frames (row sub-tiles) per wave, NWAVES = waves per workgroup (JS x NWAVES frames per workgroup).
+//   <3, 4>  one wave per SIMD, 204 accumulator registers (the round-2 form);
+//   <2, 8>  two waves per SIMD: while one wave runs its operand construction / epilogue, the SIMD's other wave issues MFMAs.
+template <bool DROPOUT, int JS, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64, (NWAVES + 3) / 4) void joint_fwd_kernel(JointFwdArgs a) {
+    constexpr int JT = JS * NWAVES;
+    constexpr int J_THREADS = NWAVES * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int H = a.H;
     const int frow = H * 2 + 16;                       // bytes per f/g row in LDS (padded)
@@ -88,7 +95,7 @@ __global__ __launch_bounds__(J_THREADS, 1) void joint_fwd_kernel(JointFwdArgs a)
     const unsigned wsrc_lane = (unsigned)((lane >> 3) * H * 2 + 16 * ((lane & 7) ^ (lane >> 3)));   // byte offset inside a block's 8 rows
 #define J_W_ASYNC(kc_, buf_)                                                                             \
     do {                                                                                                 \
-        for (int blk_ = wave; blk_ < WBLK; blk_ += 4) {                                                  \
+        for (int blk_ = wave; blk_ < WBLK; blk_ += NWAVES) {                                             \
             const unsigned char* src_ = reinterpret_cast<const unsigned char*>(a.W + (size_t)(8 * blk_) * H + (kc_) * JKC) + wsrc_lane; \
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,        \
                                              (__attribute__((address_space(3))) void*)(sW + (buf_) * WBUF + blk_ * 1024), 16, 0, 0); \
@@ -271,18 +278,27 @@ extern "C" int ia_joint_fwd_box(const void* f, const void* g, const void* W, con
     a.seed = seed;
     a.thr = (unsigned)(dropout_p * 256.f + 0.5f);
     const int frow = H * 2 + 16;
-    const size_t lds = (size_t)(JT + JU) * frow + 2 * (size_t)JVP * JKC * 2;
+    const char* wv_env = getenv("IA_JFWD_WAVES");       // A/B switch: 4 = one wave per SIMD x 3 frames, 8 = two waves per SIMD x 2 frames
+    const int waves = (wv_env && atoi(wv_env) == 4) ? 4 : 8;
+    const int js = waves == 4 ? 3 : 2, jt = js * waves;
+    constexpr int LDT_H = JVP * 2 + 16;
+    const size_t wbytes = 2 * (size_t)JVP * JKC * 2, tbytes = (size_t)waves * 16 * LDT_H;   // W double buffer, reused as the transpose scratch
+    const size_t lds = (size_t)(jt + JU) * frow + (wbytes > tbytes ? wbytes : tbytes);
     if (lds > 160 * 1024) return IA_UNSUPPORTED;
-    const int nut = (U1 + JU - 1) / JU, ntt = (T + JT - 1) / JT;
-    const dim3 grid((unsigned)((int64_t)B * ntt * nut)), blk(J_THREADS);
+    const int nut = (U1 + JU - 1) / JU, ntt = (T + jt - 1) / jt;
+    const dim3 grid((unsigned)((int64_t)B * ntt * nut)), blk(waves * 64);
     hipStream_t st = (hipStream_t)stream;
-    if (a.thr > 0) {
-        IA_SET_MAX_LDS_ONCE((joint_fwd_kernel<true>), (int)lds);
-        hipLaunchKernelGGL((joint_fwd_kernel<true>), grid, blk, lds, st, a);
+#define JF_LAUNCH(DROP_, JS_, WV_)                                                          \
+    do {                                                                                    \
+        IA_SET_MAX_LDS_ONCE((joint_fwd_kernel<DROP_, JS_, WV_>), (int)lds);                  \
+        hipLaunchKernelGGL((joint_fwd_kernel<DROP_, JS_, WV_>), grid, blk, lds, st, a);      \
+    } while (0)
+    if (waves == 4) {
+        if (a.thr > 0) JF_LAUNCH(true, 3, 4); else JF_LAUNCH(false, 3, 4);
     } else {
-        IA_SET_MAX_LDS_ONCE((joint_fwd_kernel<false>), (int)lds);
-        hipLaunchKernelGGL((joint_fwd_kernel<false>), grid, blk, lds, st, a);
+        if (a.thr > 0) JF_LAUNCH(true, 2, 8); else JF_LAUNCH(false, 2, 8);
     }
+#undef JF_LAUNCH
     IA_RETURN_IF_LAUNCH_FAILED();
     return IA_OK;
 }
