@@ -101,7 +101,15 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ffn_fused_kernel(FfnArgs a) {
     auto issue_slot = [&](int g) {
         const int c = g >> 2, p = g & 3;
         unsigned char* dst = sRing + p * SLOT;
-        if (p < 2) {
+        if (a.mode & 8) {   // diagnostics: the same bytes per slot from CONTIGUOUS addresses (is the strided row pattern what paces the stream?)
+            const unsigned char* base = reinterpret_cast<const unsigned char*>(p < 2 ? a.W1 : a.W2) + (size_t)(c * 2 + (p & 1)) * SLOT;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int blk = wave * 4 + i;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + blk * 1024 + lane * 16),
+                                                 (__attribute__((address_space(3))) void*)(dst + blk * 1024), 16, 0, 0);
+            }
+        } else if (p < 2) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int blk = wave * 4 + i;
