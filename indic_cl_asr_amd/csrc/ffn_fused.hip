@@ -22,6 +22,7 @@
 //
 // Roofline (d = 256, 4d = 1024): 2*2*256*1024 = 1.05 MFLOP per frame -> 12.6 GFLOP per launch at 12 032 frames (5.0 us at
 // 2.5 PF dense); each workgroup also pulls the full 1 MB of weights through its CU's L2 port, the actual bound.
+#include <type_traits>
 #include <hip/hip_bf16.h>
 
 #include <stdlib.h>
@@ -73,8 +74,11 @@ __device__ __forceinline__ float half_wave_sum(float v) {   // sum over the 32 l
 // vmcnt for exactly the slot it is about to read (never vmcnt(0), never __syncthreads() inside the loop: both would
 // drain the queue).  b1 sits in LDS and is read through inline asm: hipcc waits vmcnt(0) in front of an ordinary vector load
 // and of a compiler-visible LDS read while LDS-DMA is in flight.
-template <int D>
+// DIAG: the timing-only variants of tools/bench_ffn.py (a.mode) are compiled into a separate instantiation: their branches
+// would split the loop body into basic blocks, and the MFMA / VALU interleaving below only happens inside one block.
+template <int D, bool DROP_FF, bool DIAG>
 __global__ __launch_bounds__(FF_THREADS, 2) void ffn_fused_kernel(FfnArgs a) {
+    const int mode = DIAG ? a.mode : 0;
     static_assert(D == 256, "wave decomposition below is written for d_model = 256");
     constexpr int SLOT = 32768;
     constexpr int YROW = D * 2;           // bytes per LN(x) row in the prologue staging (512)
@@ -93,54 +97,65 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ffn_fused_kernel(FfnArgs a) {
     const int m0 = blockIdx.x * FF_M;
     const int nchunks = a.dff / FF_JC;
     const int total = nchunks * 4;
-    if ((a.mode & 4) && (blockIdx.x & 1)) return;   // diagnostics: half of the workgroups (is the weight stream a per-CU or a chip limit?)
+    if ((mode & 4) && (blockIdx.x & 1)) return;   // diagnostics: half of the workgroups (is the weight stream a per-CU or a chip limit?)
 
-    // slot g = 4 c + p.  One LDS-DMA instruction moves 1 KB (lane l -> 16 bytes at position l): W1 half-rows are 256 B
-    // (4 rows per instruction, 16-byte slot XOR row & 15), W2 half-rows 128 B (8 rows per instruction, slot XOR (row >> 1) & 7:
-    // two rows share a 256-byte bank window).  Wave w issues instructions 4 w .. 4 w + 3 of a slot's 32.
-    auto issue_slot = [&](int g) {
-        const int c = g >> 2, p = g & 3;
-        unsigned char* dst = sRing + p * SLOT;
-        if (a.mode & 8) {   // diagnostics: the same bytes per slot from CONTIGUOUS addresses (is the strided row pattern what paces the stream?)
-            const unsigned char* base = reinterpret_cast<const unsigned char*>(p < 2 ? a.W1 : a.W2) + (size_t)(c * 2 + (p & 1)) * SLOT;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int blk = wave * 4 + i;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + blk * 1024 + lane * 16),
-                                                 (__attribute__((address_space(3))) void*)(dst + blk * 1024), 16, 0, 0);
-            }
-        } else if (p < 2) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int blk = wave * 4 + i;
-                const int row = 4 * blk + (lane >> 4);
-                const int cs = (lane & 15) ^ (row & 15);
-                const unsigned char* src = reinterpret_cast<const unsigned char*>(a.W1 + (size_t)(c * FF_JC + row) * D + p * 128) + cs * 16;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(dst + blk * 1024), 16, 0, 0);
-            }
+    // Slot stream.  The three stages of a chunk -- phase A (MFMA), SiLU / dropout (VALU + transcendentals), phase B (MFMA) --
+    // are software-pipelined over the chunks: iteration j multiplies A(j) and B(j-2) while the SAME wave's VALU works on
+    // chunk j-1 (independent instruction streams inside one wave: the matrix pipe runs under the activation arithmetic
+    // instead of idling while all eight waves sit in the SiLU between two barriers).  Stream order of the 32 KB slots
+    // (sequence number s, ring position s & 3):
+    //   A0(0) A1(0) | A0(1) A1(1) | A0(j) A1(j) B0(j-2) B1(j-2)  for j = 2 .. n-1 | B0(n-2) B1(n-2) | B0(n-1) B1(n-1)
+    // One LDS-DMA instruction moves 1 KB (lane l -> 16 bytes at position l): W1 half-rows are 256 B (4 rows per instruction,
+    // 16-byte slot XOR row & 15), W2 half-rows 128 B (8 rows per instruction, slot XOR (row >> 1) & 7: two rows share a
+    // 256-byte bank window).  Wave w issues instructions 4 w .. 4 w + 3 of a slot's 32.
+    // Lane part of the source address of a slot's first instruction (rows 16 w + (lane >> 4) of a W1 slot, 32 w + (lane >> 3)
+    // of a W2 slot); instruction i of the wave is four (eight) rows further down and its 16-byte slot XOR differs by 4 i
+    // (4 (i & 1)), i.e. by an XOR of the byte offset with 64 i (64 (i & 1)): two VALU operations per instruction, no branch
+    // (kind, chunk and half of slot sq are wave-uniform scalar selects) -- the whole interval stays ONE basic block.
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned off1 = (unsigned)((16 * wv + (lane >> 4)) * (D * 2) + (((lane & 15) ^ (lane >> 4)) * 16));
+    const unsigned off2 = (unsigned)((32 * wv + (lane >> 3)) * (a.dff * 2) + (((lane & 7) ^ (lane >> 4)) * 16));
+    auto issue_slot = [&](int sq) {
+        int kindB, c, h;
+        if (sq < 4) { kindB = 0; c = sq >> 1; h = sq & 1; }
+        else if (sq < total - 4) { const int r = sq - 4, j = 2 + (r >> 2), k = r & 3; kindB = k >> 1; c = kindB ? j - 2 : j; h = k & 1; }
+        else { const int r = sq - (total - 4); kindB = 1; c = nchunks - 2 + (r >> 1); h = r & 1; }
+        unsigned char* dst = sRing + (sq & 3) * SLOT + wv * 4096;
+        const unsigned char* base;
+        unsigned off, stride, xm1;
+        if (DIAG && (mode & 8)) {   // diagnostics: the same bytes per slot from CONTIGUOUS addresses (is the strided row pattern what paces the stream?)
+            base = reinterpret_cast<const unsigned char*>(kindB ? a.W2 : a.W1) + (size_t)(c * 2 + h) * SLOT;
+            off = (unsigned)(wv * 4096 + lane * 16); stride = 1024; xm1 = 0;
         } else {
+            base = kindB ? reinterpret_cast<const unsigned char*>(a.W2) + (size_t)(c * FF_JC + h * 64) * 2
+                         : reinterpret_cast<const unsigned char*>(a.W1) + ((size_t)c * FF_JC * D + h * 128) * 2;
+            off = kindB ? off2 : off1;
+            stride = kindB ? (unsigned)(16 * a.dff) : (unsigned)(4 * D * 2);
+            xm1 = kindB ? 0u : 64u;   // W1: XOR 64 i; W2: XOR 64 (i & 1)
+        }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int blk = wave * 4 + i;
-                const int row = 8 * blk + (lane >> 3);
-                const int cs = (lane & 7) ^ ((row >> 1) & 7);
-                const unsigned char* src = reinterpret_cast<const unsigned char*>(a.W2 + (size_t)row * a.dff + c * FF_JC + (p - 2) * 64) + cs * 16;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(dst + blk * 1024), 16, 0, 0);
-            }
+        for (int i = 0; i < 4; ++i) {
+            const unsigned xm = (unsigned)(i & 1) * 64u + (unsigned)(i >> 1) * 2u * xm1;
+            const unsigned vo = (off ^ xm) + (unsigned)i * stride;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + vo),
+                                             (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
         }
     };
-    // rendezvous in front of slot g: this wave's share of slot g has landed (later slots stay in flight), everybody is done
-    // with slot g - 1, whose space then takes slot g + 3
-    auto step_sync = [&](int g) {
-        const int rem = total - 1 - g;
-        if (rem >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    // rendezvous in front of slot sq: this wave's share of slot sq has landed (later slots stay in flight) and everybody is
+    // done with slot sq - 1, whose space then takes slot sq + 3 (issue_next(), called behind the interval's fragment reads)
+    // (vm = vector-memory operations that may stay in flight: 8 = the two slots behind sq, 4 / 0 at the end of the stream;
+    // literal at every call site, so that no branch survives)
+    int sq = 0;
+    auto step_sync = [&](int vm) {
+        if (vm == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (vm == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (g + 3 < total && !(a.mode & 1)) issue_slot(g + 3);
+    };
+    auto issue_next = [&](bool issue) {
+        if (issue && !(mode & 1)) issue_slot(sq + 3);
+        ++sq;
     };
 
     issue_slot(0); issue_slot(1); issue_slot(2);
@@ -189,82 +204,157 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ffn_fused_kernel(FfnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[nt][r] = 0.f;
 
-    const unsigned char* w1row = sRing + (q * 32 + l31) * 256;                    // + slot base, rows of 256 B
+    const unsigned char* w1row = sRing + (q * 32 + l31) * 256;                    // + ring position, rows of 256 B
     const int w2sw = (((q * 64 + l31) >> 1) & 7);                                  // (row >> 1) & 7, same for row + 32
-    const unsigned char* w2row = sRing + 2 * SLOT + (q * 64 + l31) * 128;          // rows of 128 B
+    const unsigned char* w2row = sRing + (q * 64 + l31) * 128;                     // + ring position, rows of 128 B
     const unsigned char* xrow = sX + (mi * 32 + l31) * XROW;
     const unsigned gm_drop = (unsigned)(m0 + mi * 32 + l31);
-    const bool do_mfma = !(a.mode & 2);
+    const bool do_mfma = !(mode & 2);
     const unsigned sm_ff = ia_dm_hash32(a.seed_ff);
 
-    for (int c = 0; c < nchunks; ++c) {
-        // ---------------------------------------------------------------- phase A: two k halves
-        f16v acc;
+    // Activation of one register group (4 consecutive units of one frame), cut into 8 stages so that a stage can follow
+    // each MFMA of an interval in program order (sched_barrier pins that order): stages 0-3 bias + SiLU of one value each
+    // (SiLU as v * rcp(1 + exp2(-v log2 e)): 6 VALU per element), stages 4-7 the dropout of one value each.
+    // b1 comes from LDS through inline asm: a compiler-visible LDS read here makes hipcc drain vmcnt(0) (it assumes the read
+    // may alias the LDS-DMA destinations) and stalls the weight stream; lane (hh) needs units 32 q + 8 g + 4 hh .. + 3.
+    struct Act { float v[4]; unsigned w; };
+    auto act_begin = [&](int c, int g, Act& st) {
+        // one cheap word per (frame, 4 units): this lane's 4 consecutive units are exactly one group
+        if (DROP_FF) st.w = ia_dm_word24(sm_ff, gm_drop * (unsigned)(a.dff >> 2) + (unsigned)((c * FF_JC + q * 32 + g * 8 + hh * 4) >> 2));
+    };
+    // the accumulators of a chunk start from its bias (b1 of the lane's 16 units: no add per element afterwards)
+    auto bias_init = [&](int c, f16v& acc) {
+        float4 b0, b1v, b2v, b3;
+        const unsigned baddr = (unsigned)(4 * SLOT + FF_M * XROW) + (unsigned)((c * FF_JC + q * 32 + hh * 4) * 4);
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:32\n\tds_read_b128 %2, %4 offset:64\n\t"
+                     "ds_read_b128 %3, %4 offset:96\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(b0), "=&v"(b1v), "=&v"(b2v), "=&v"(b3) : "v"(baddr) : "memory");
+        acc[0] = b0.x; acc[1] = b0.y; acc[2] = b0.z; acc[3] = b0.w; acc[4] = b1v.x; acc[5] = b1v.y; acc[6] = b1v.z; acc[7] = b1v.w;
+        acc[8] = b2v.x; acc[9] = b2v.y; acc[10] = b2v.z; acc[11] = b2v.w; acc[12] = b3.x; acc[13] = b3.y; acc[14] = b3.z; acc[15] = b3.w;
+    };
+    // (the empty asm statements are ordering anchors: volatile asms keep their source order, and a value passed through one
+    // can neither be computed earlier nor consumed later than it -- plain arithmetic and MFMA nodes float freely through a
+    // basic block otherwise, and sched_barrier only binds the machine scheduler, after the DAG has been linearised)
+    auto act_stage = [&](int g, const f16v& acc, Act& st, int k) {
+        if (k < 4) {
+            float t = acc[4 * g + k];
+            asm volatile("" : "+v"(t));
+            t = t * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(t * -1.44269504088896341f));
+            asm volatile("" : "+v"(t));
+            st.v[k] = t;
+        } else if (DROP_FF) {   // keep or zero; the 1 / (1 - p) scale is applied once to the module output (it commutes with W2)
+            const int i = k - 4;
+            float t = st.v[i];
+            asm volatile("" : "+v"(t));
+            t = (((st.w >> (8 * i)) & 0xFFu) >= a.thr_ff) ? t : 0.f;   // byte i keeps unit i
+            asm volatile("" : "+v"(t));
+            st.v[i] = t;
+        }
+    };
+    auto act_end = [&](const Act& st) -> uint2 {
+        union { uint2 u; __bf16 h[4]; } pk;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            step_sync(4 * c + p);
-            if (do_mfma) {
-                bf8 wf[8];   // all fragments of the slot are requested before the first MFMA (one LDS latency per slot, not per pair)
-#pragma unroll
-                for (int s = 0; s < 8; ++s) wf[s] = *reinterpret_cast<const bf8*>(w1row + p * SLOT + ((s * 32) ^ t16));
-#pragma unroll
-                for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s], yf[p * 8 + s], acc, 0, 0, 0);
+        for (int i = 0; i < 4; ++i) pk.h[i] = (__bf16)st.v[i];
+        return pk.u;
+    };
+    // One interval = the 8 MFMAs of a slot (phase A: acc^T[32 units][32 frames] += W1 slot . y^T out of ring position pos,
+    // k half p; phase B: out^T += W2 slot . X, j half p) with the activation of NG register groups g0 .. of chunk c (source
+    // accumulators accS) interleaved: all LDS fragments of the slot are requested first (one LDS latency per slot), then
+    // MFMA, 8 NG / 8 activation stages, MFMA, ...  NG = 0: MFMAs only.
+    auto interval = [&](auto isB, auto ngc, int pos, int p, f16v& accT, int c, int g0, const f16v& accS, uint2* out, bool issue = true, int cinit = -1) {
+        constexpr bool IS_B = decltype(isB)::value;
+        constexpr int NG = decltype(ngc)::value;
+        // fragments in four batches of two MFMAs, two batches in flight (16 / 24 registers instead of 32 / 48: the
+        // activation stages between the MFMAs cover the LDS latency of the batch after next)
+        bf8 fa[4][2], fb[4];
+        auto load_batch = [&](int b) {
+            if (!do_mfma) return;
+            if (!IS_B) {
+                fa[b][0] = *reinterpret_cast<const bf8*>(w1row + pos * SLOT + (((2 * b) * 32) ^ t16));
+                fa[b][1] = *reinterpret_cast<const bf8*>(w1row + pos * SLOT + (((2 * b + 1) * 32) ^ t16));
+            } else {
+                const int woff = pos * SLOT + (((b * 2 + hh) ^ w2sw) * 16);
+                fb[b] = *reinterpret_cast<const bf8*>(xrow + (((p * 8 + b * 2 + hh) ^ sw) * 16));
+                fa[b][0] = *reinterpret_cast<const bf8*>(w2row + woff);
+                fa[b][1] = *reinterpret_cast<const bf8*>(w2row + 32 * 128 + woff);
             }
+        };
+        load_batch(0); load_batch(1);
+        issue_next(issue);
+        if (cinit >= 0) bias_init(cinit, accT);   // (its LDS wait coincides with the fragments')
+        Act st[NG > 0 ? NG : 1];
+#pragma unroll
+        for (int i = 0; i < NG; ++i) act_begin(c, g0 + i, st[i]);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            if (do_mfma) {
+                if (!IS_B) { accT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s >> 1][s & 1], yf[p * 8 + s], accT, 0, 0, 0); asm volatile("" : "+v"(accT)); }
+                else { o[s & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s >> 1][s & 1], fb[s >> 1], o[s & 1], 0, 0, 0); asm volatile("" : "+v"(o[s & 1])); }
+            }
+            if (NG == 1) act_stage(g0, accS, st[0], s);
+            if (NG == 2) { act_stage(g0 + (s >> 2), accS, st[NG > 1 ? (s >> 2) : 0], 2 * (s & 3)); act_stage(g0 + (s >> 2), accS, st[NG > 1 ? (s >> 2) : 0], 2 * (s & 3) + 1); }
+            if ((s & 1) && (s >> 1) + 2 < 4) load_batch((s >> 1) + 2);
         }
-        // b1 from LDS through inline asm: a compiler-visible LDS read here makes hipcc drain vmcnt(0) (it assumes the read may
-        // alias the LDS-DMA destinations) and stalls the weight stream; lane (hh) needs units 32 q + 8 g + 4 hh .. + 3
-        float4 bias4[4];
-        {
-            const unsigned baddr = (unsigned)(4 * SLOT + FF_M * XROW) + (unsigned)((c * FF_JC + q * 32 + hh * 4) * 4);
-            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:32\n\tds_read_b128 %2, %4 offset:64\n\t"
-                         "ds_read_b128 %3, %4 offset:96\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&v"(bias4[0]), "=&v"(bias4[1]), "=&v"(bias4[2]), "=&v"(bias4[3]) : "v"(baddr) : "memory");
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            out[i] = act_end(st[i]);
+            // anchor: without a use inside this block the IR sink pass moves the whole activation down to the block of the
+            // X store (the next iteration), behind the MFMAs it is meant to run under
+            asm volatile("" :: "v"(out[i].x), "v"(out[i].y));
         }
+    };
+    const std::integral_constant<bool, false> PA{};
+    const std::integral_constant<bool, true> PB{};
+    const std::integral_constant<int, 0> G0{};
+    const std::integral_constant<int, 1> G1{};
+    const std::integral_constant<int, 2> G2{};
+    // X store through inline asm as well (a compiler-visible LDS store draws the same vmcnt(0))
+    auto store_x = [&](const uint2 (&xp)[4]) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 bia = bias4[g];
-            float v[4] = {acc[4 * g] + bia.x, acc[4 * g + 1] + bia.y, acc[4 * g + 2] + bia.z, acc[4 * g + 3] + bia.w};
-            // SiLU as v * rcp(1 + exp2(-v log2 e)): 6 VALU per element (the IEEE division of v / (1 + expf(-v)) alone was ~12;
-            // this epilogue, not the MFMAs, paced the first version of the kernel)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = v[i] * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(v[i] * -1.44269504088896341f));
-            if (a.thr_ff > 0) {   // one cheap word per (frame, 4 units): this lane's 4 consecutive units are exactly one group
-                const unsigned w = ia_dm_word24(sm_ff, gm_drop * (unsigned)(a.dff >> 2) + (unsigned)((c * FF_JC + q * 32 + g * 8 + hh * 4) >> 2));
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] *= (((w >> (8 * i)) & 0xFFu) >= a.thr_ff) ? a.ks_ff : 0.f;   // byte i keeps unit i
-            }
-            union { uint2 u; __bf16 h[4]; } pk;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) pk.h[i] = (__bf16)v[i];
-            {   // X store through inline asm as well (a compiler-visible LDS store draws the same vmcnt(0))
-                const unsigned xaddr = (unsigned)(4 * SLOT) + (unsigned)((mi * 32 + l31) * XROW + (((q * 4 + g) ^ sw) * 16) + hh * 8);
-                asm volatile("ds_write_b64 %0, %1" :: "v"(xaddr), "v"(pk.u) : "memory");
-            }
+            const unsigned xaddr = (unsigned)(4 * SLOT) + (unsigned)((mi * 32 + l31) * XROW + (((q * 4 + g) ^ sw) * 16) + hh * 8);
+            asm volatile("ds_write_b64 %0, %1" :: "v"(xaddr), "v"(xp[g]) : "memory");
         }
-        // ---------------------------------------------------------------- phase B: two j halves
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            step_sync(4 * c + 2 + p);
-            if (do_mfma) {
-                bf8 xb[4], w0[4], w1[4];
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const int woff = p * SLOT + (((s * 2 + hh) ^ w2sw) * 16);
-                    xb[s] = *reinterpret_cast<const bf8*>(xrow + (((p * 8 + s * 2 + hh) ^ sw) * 16));
-                    w0[s] = *reinterpret_cast<const bf8*>(w2row + woff);
-                    w1[s] = *reinterpret_cast<const bf8*>(w2row + 32 * 128 + woff);
-                }
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0[s], xb[s], o[0], 0, 0, 0);
-                    o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[s], xb[s], o[1], 0, 0, 0);
-                }
-            }
-        }
+    };
+
+    f16v acc, accn;
+    uint2 xp[4];
+    // j = 0: A(0)
+    step_sync(8); interval(PA, G0, 0, 0, acc, 0, 0, acc, nullptr, true, 0);
+    step_sync(8); interval(PA, G0, 1, 1, acc, 0, 0, acc, nullptr);
+    // j = 1: A(1) beside the activation of chunk 0
+    step_sync(8); interval(PA, G2, 2, 0, accn, 0, 0, acc, xp, true, 1);
+    step_sync(8); interval(PA, G2, 3, 1, accn, 0, 2, acc, xp + 2);
+    acc = accn;
+    // j = 2 .. n-1: A(j), activation of chunk j-1, B(j-2).  X(j-2) is written behind the first rendezvous of the
+    // iteration (every wave has finished reading X(j-3) in front of it) and published by the second one.
+    for (int j = 2; j < nchunks; ++j) {
+        step_sync(8); store_x(xp); interval(PA, G1, 0, 0, accn, j - 1, 0, acc, xp, true, j);
+        step_sync(8); interval(PA, G1, 1, 1, accn, j - 1, 1, acc, xp + 1);
+        step_sync(8); interval(PB, G1, 2, 0, accn, j - 1, 2, acc, xp + 2);
+        step_sync(8); interval(PB, G1, 3, 1, accn, j - 1, 3, acc, xp + 3);
+        acc = accn;
+    }
+    // j = n: activation of the last chunk beside B(n-2) (ring positions 0, 1)
+    {
+        uint2 xl[4];
+        step_sync(8); store_x(xp);                      // X(n-2) is read in this very interval: publish it with an extra barrier
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        interval(PB, G2, 0, 0, accn, nchunks - 1, 0, acc, xl, true);          // slot total - 4: requests the last slot
+        step_sync(8); interval(PB, G2, 1, 1, accn, nchunks - 1, 2, acc, xl + 2, false);
+        // j = n + 1: B(n-1) (ring positions 2, 3); X(n-1) goes in behind the rendezvous, one extra barrier publishes it
+        step_sync(4); store_x(xl);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        interval(PB, G0, 2, 0, accn, 0, 0, acc, nullptr, false);
+        step_sync(0); interval(PB, G0, 3, 1, accn, 0, 0, acc, nullptr, false);
     }
     __syncthreads();   // every wave is done with the ring and X; nothing is in flight
+    // (an opaque copy of the thread index: derived from `tid` itself the row addresses below are common subexpressions of the
+    // prologue's, and the compiler keeps ~20 address registers alive across the whole loop -- spilled to scratch)
+    int tide = tid;
+    asm volatile("" : "+v"(tide));
 
     // ---- epilogue: out^T accumulators -> sE[frame][channel] fp32 (lane = frame, 4 consecutive channels per register group)
 #pragma unroll
@@ -278,7 +368,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ffn_fused_kernel(FfnArgs a) {
     __syncthreads();
 #pragma unroll
     for (int pass = 0; pass < FF_M / 16; ++pass) {
-        const int r = pass * 16 + (tid >> 5), vec = tid & 31;
+        const int r = pass * 16 + (tide >> 5), vec = tide & 31;
         const int gm = m0 + r;
         const bool live = gm < a.N;
         const int gmc = live ? gm : (a.N - 1);
@@ -286,6 +376,10 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ffn_fused_kernel(FfnArgs a) {
         const float4 e1 = *reinterpret_cast<const float4*>(sE + r * EROW + vec * 32 + 16);
         float v[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
         const float4 b0 = *reinterpret_cast<const float4*>(a.b2 + vec * 8), b1 = *reinterpret_cast<const float4*>(a.b2 + vec * 8 + 4);
+        if (DROP_FF) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] *= a.ks_ff;   // inner dropout's 1 / (1 - p)
+        }
         v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
         float sc = a.alpha;
         if (a.thr_res > 0) {
@@ -337,7 +431,7 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ffn_fused_kernel(FfnArgs a) {
 
 }  // namespace
 
-extern "C" int ia_ffn_fused_supported(int d, int d_ff) { return (d == 256 && d_ff > 0 && d_ff % FF_JC == 0 && d_ff <= 2048) ? 1 : 0; }
+extern "C" int ia_ffn_fused_supported(int d, int d_ff) { return (d == 256 && d_ff >= 2 * FF_JC && d_ff % FF_JC == 0 && d_ff <= 2048) ? 1 : 0; }   // the chunk pipeline needs two chunks
 
 extern "C" int ia_ffn_fused(float* x, int N, int d, int d_ff, const float* ln_g, const float* ln_b, float eps, const void* W1,
                             const float* b1, const void* W2, const float* b2, float alpha, float p_ff, unsigned seed_ff,
@@ -363,8 +457,17 @@ extern "C" int ia_ffn_fused(float* x, int N, int d, int d_ff, const float* ln_g,
     const int LDS = 4 * 32768 + FF_M * FF_JC * 2 + d_ff * 4;   // ring + X + b1 = 151 552 B at d_ff = 1024
     static_assert(FF_M * (256 * 4 + 16) <= 4 * 32768, "epilogue tile aliases the ring");
     { const char* e = getenv("IA_FFN_MODE"); a.mode = (e && *e) ? atoi(e) : 0; }   // diagnostics only
-    IA_SET_MAX_LDS_ONCE((ffn_fused_kernel<256>), LDS);
-    hipLaunchKernelGGL((ffn_fused_kernel<256>), dim3((N + FF_M - 1) / FF_M), dim3(FF_THREADS), LDS, (hipStream_t)stream, a);
+    const dim3 grid((N + FF_M - 1) / FF_M), blk(FF_THREADS);
+    if (a.mode) {   // (DROP_FF with threshold 0 keeps every unit at scale 1)
+        IA_SET_MAX_LDS_ONCE((ffn_fused_kernel<256, true, true>), LDS);
+        hipLaunchKernelGGL((ffn_fused_kernel<256, true, true>), grid, blk, LDS, (hipStream_t)stream, a);
+    } else if (a.thr_ff > 0) {
+        IA_SET_MAX_LDS_ONCE((ffn_fused_kernel<256, true, false>), LDS);
+        hipLaunchKernelGGL((ffn_fused_kernel<256, true, false>), grid, blk, LDS, (hipStream_t)stream, a);
+    } else {
+        IA_SET_MAX_LDS_ONCE((ffn_fused_kernel<256, false, false>), LDS);
+        hipLaunchKernelGGL((ffn_fused_kernel<256, false, false>), grid, blk, LDS, (hipStream_t)stream, a);
+    }
     IA_RETURN_IF_LAUNCH_FAILED();
     return IA_OK;
 }

@@ -35,7 +35,7 @@ def main():
         fast.gemm(h, fast.bf16_shadow(l2.weight), l2.bias, dropout_p=0.1, seed=2, alpha=0.5, residual=x, out_f32=x, want_bf16=False)
 
     print("unfused LN + 2 GEMM: %.1f us" % timeit(unfused))
-    for mode in (0, 1, 2, 3, 6, 8, 10, 14):
+    for mode in (0, 1, 2, 3):
         os.environ["IA_FFN_MODE"] = str(mode)
         t = timeit(lambda: fast.ffn_fused(x, ln, l1, l2, 0.5, 0.1, 1, 0.1, 2, ln2=ln2))
         print("ffn_fused mode %d (%s): %.1f us" % (mode, {0: "full", 1: "no loads", 2: "no mfma", 3: "neither", 6: "half the workgroups, no mfma", 8: "contiguous slots", 10: "contiguous slots, no mfma", 14: "contiguous, half the workgroups, no mfma"}[mode], t))
