@@ -203,6 +203,14 @@ int ia_joint_dw_fused_supported(int U1, int H, int LD);
 int64_t ia_joint_dw_fused_scratch_elems(int B, int T, int U1, int H, int LD);
 int ia_joint_dw_fused(const void* G, const void* f, const void* g, const int64_t* act_lens, int B, int T, int U1, int H, int LD,
                       float dropout_p, unsigned seed, float* dW, float* scratch, ia_stream_t stream);
+/* The same with the label counts: when act_lens and label_lens are both given (and T >= 8, 8 <= U1 <= 256, T*U1 < 2^23,
+ * B <= 4096) a step is an 8-frame x 8-label tile and an utterance's steps cover its live frames x live labels only -- the
+ * labels u > label_lens[b] of a live frame hold zeros in G as well (A/parts/numba/rnnt_loss/utils/cuda_utils/
+ * gpu_rnnt_kernel.py:351-403 writes nothing there), so they are skipped like the frames behind the utterance's end.
+ * Other shapes run the flat 64-cell steps of ia_joint_dw_fused. */
+int ia_joint_dw_fused_ex(const void* G, const void* f, const void* g, const int64_t* act_lens, const int64_t* label_lens, int B,
+                         int T, int U1, int H, int LD, float dropout_p, unsigned seed, float* dW, float* scratch,
+                         ia_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Conformer block forward building blocks (bf16 projections, fp32 residual stream).

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_bf16.h>
 
+#include "dropout_mask.h"
 #include "ia_common.h"
 
 namespace {
@@ -11,14 +12,12 @@ typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 typedef short s4v __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ unsigned fa_hash32(unsigned x) {
-    x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
-    return x;
-}
-// attention-dropout randomness of this kernel: one hash per (head, query, group of 4 keys); key j uses byte j & 3
+// attention-dropout randomness of these kernels: one word per (head, query, group of 4 keys); key j uses byte j & 3.  The
+// word comes from dropout_mask.h's full-rate construction (24-bit multiplies, shifts, xors): the 32-bit multiplies of a
+// murmur-style finaliser are quarter rate on gfx950 and the forward regenerates 16 words per wave and key tile.
 __device__ __forceinline__ unsigned fa_keep_rand4(unsigned seed, int bh, int T, int i, int j4) {
     const unsigned idx = ((unsigned)bh * (unsigned)T + (unsigned)i) * (unsigned)((T + 3) >> 2) + (unsigned)j4;
-    return fa_hash32(idx * 0x9E3779B1u + seed);
+    return ia_dm_word24(ia_dm_hash32(seed), idx);   // (the seed hash is wave-uniform: hoisted to scalar code)
 }
 
 // 16-byte slot `slot` (8 elements) of a head row of `dk` elements starting at `row` (8-byte aligned), zero beyond dk

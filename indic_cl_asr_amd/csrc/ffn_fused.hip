@@ -235,13 +235,28 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ffn_fused_kernel(FfnArgs a) {
     // (the empty asm statements are ordering anchors: volatile asms keep their source order, and a value passed through one
     // can neither be computed earlier nor consumed later than it -- plain arithmetic and MFMA nodes float freely through a
     // basic block otherwise, and sched_barrier only binds the machine scheduler, after the DAG has been linearised)
+    // stages 0-3: SiLU of the value pairs (0,1) and (2,3) in two halves each, on packed fp32 arithmetic (v_pk_mul_f32 /
+    // v_pk_add_f32: one instruction per pair; the exponential and the reciprocal are per element); stages 4-7: dropout.
+    typedef float f2v __attribute__((ext_vector_type(2)));
     auto act_stage = [&](int g, const f16v& acc, Act& st, int k) {
         if (k < 4) {
-            float t = acc[4 * g + k];
-            asm volatile("" : "+v"(t));
-            t = t * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(t * -1.44269504088896341f));
-            asm volatile("" : "+v"(t));
-            st.v[k] = t;
+            const int pr = k >> 1;
+            if (!(k & 1)) {
+                f2v t = {acc[4 * g + 2 * pr], acc[4 * g + 2 * pr + 1]};
+                asm volatile("" : "+v"(t));
+                const f2v m = t * (f2v){-1.44269504088896341f, -1.44269504088896341f};
+                f2v e = {__builtin_amdgcn_exp2f(m.x), __builtin_amdgcn_exp2f(m.y)};
+                asm volatile("" : "+v"(e));
+                st.v[2 * pr] = e.x; st.v[2 * pr + 1] = e.y;
+            } else {
+                f2v e = {st.v[2 * pr], st.v[2 * pr + 1]};
+                asm volatile("" : "+v"(e));
+                const f2v d = e + (f2v){1.f, 1.f};
+                const f2v r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+                f2v o2 = (f2v){acc[4 * g + 2 * pr], acc[4 * g + 2 * pr + 1]} * r;
+                asm volatile("" : "+v"(o2));
+                st.v[2 * pr] = o2.x; st.v[2 * pr + 1] = o2.y;
+            }
         } else if (DROP_FF) {   // keep or zero; the 1 / (1 - p) scale is applied once to the module output (it commutes with W2)
             const int i = k - 4;
             float t = st.v[i];
@@ -252,9 +267,10 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ffn_fused_kernel(FfnArgs a) {
         }
     };
     auto act_end = [&](const Act& st) -> uint2 {
-        union { uint2 u; __bf16 h[4]; } pk;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) pk.h[i] = (__bf16)st.v[i];
+        typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
+        union { uint2 u; bf2v h[2]; } pk;
+        pk.h[0] = __builtin_convertvector((f2v){st.v[0], st.v[1]}, bf2v);   // one v_cvt_pk_bf16_f32 per pair
+        pk.h[1] = __builtin_convertvector((f2v){st.v[2], st.v[3]}, bf2v);
         return pk.u;
     };
     // One interval = the 8 MFMAs of a slot (phase A: acc^T[32 units][32 frames] += W1 slot . y^T out of ring position pos,

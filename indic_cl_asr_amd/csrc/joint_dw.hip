@@ -17,6 +17,8 @@
 // per utterance -- a step never straddles two utterances -- and the utterance's prediction-network rows g[b, :, h0:h0+128]
 // stay resident in LDS (27 KB at U+1 = 106): per step only the G tile (33 KB) and one or two 256-byte f rows are fetched,
 // instead of a full [64 x 128] f tile and g tile (another 32 KB of L2 traffic per step, 3.2 GB per launch).
+#include <cstdlib>
+
 #include "joint_common.h"
 #include "partials.h"
 
@@ -88,11 +90,42 @@ struct DwArgs {
     int steps_per_split;
     unsigned seed, thr, mU1, mV, mSpu;   // magic reciprocals of U1, LD/8 and spu
     const int64_t* act_lens;             // optional: frames >= act_lens[b] carry no gradient (G is zero there): their steps are skipped
+    const int64_t* label_lens;           // TILED only: labels > label_lens[b] carry no gradient either
 };
 
+constexpr int DW_TF = 8, DW_TU = 8;      // TILED: a step = 8 frames x 8 labels of one utterance
+// TILED step grid of utterance b: live frame tiles x live label tiles (at least one step), its clamped frame count
+// 64-bit load through the scalar unit (uniform address): inside the step loop a vector load of the lengths -- which is what
+// the compiler emits for them, uniform address or not -- is followed by s_waitcnt vmcnt(0) and drains every G load in flight
+__device__ __forceinline__ long long dw_sload64(const int64_t* p) {
+    long long v;
+    asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p));
+    return v;
+}
+template <bool UNIFORM>
+__device__ __forceinline__ void dw_tiles_of(const int64_t* act_lens, const int64_t* label_lens, int T, int U1, int b, int* n, int* nut,
+                                            int* tb) {
+    long long t = act_lens ? (UNIFORM ? dw_sload64(act_lens + b) : (long long)act_lens[b]) : T;
+    t = t < 0 ? 0 : (t > T ? T : t);
+    long long u = label_lens ? (UNIFORM ? dw_sload64(label_lens + b) : (long long)label_lens[b]) + 1 : U1;
+    u = u < 1 ? 1 : (u > U1 ? U1 : u);
+    int ntt = (int)((t + DW_TF - 1) / DW_TF);
+    ntt = ntt < 1 ? 1 : ntt;
+    *nut = (int)((u + DW_TU - 1) / DW_TU);
+    *n = ntt * *nut;
+    *tb = (int)t;
+}
+#define dw_tiles(a_, b_, n_, nut_, tb_) dw_tiles_of<true>((a_).act_lens, (a_).label_lens, (a_).T, (a_).U1, (b_), (n_), (nut_), (tb_))
+
+// TILED (T >= 8 and U+1 >= 8): the 64 cells of a step are an 8-frame x 8-label tile instead of 64 consecutive cells, and an
+// utterance's steps cover its live frames x live labels only (the flat steps skip dead frames but not dead labels: another
+// ~14 % of the lattice at label lengths 0.6-1.0 x U).  A tile's G rows are 8 runs of 8 contiguous rows: uniform base +
+// per-thread CONSTANT offsets, no index arithmetic per step; a tile that would overhang the tensor is shifted back inside
+// and the rows it shares with its neighbour are switched off through the (regenerated) hidden rows, like the frames
+// behind the utterance's end (G holds stale logits there: finite, times a zero hidden row).
 // GRES: the utterance's prediction rows stay resident in LDS (U+1 <= 128: the bench shapes); otherwise (30 s utterances:
 // U+1 = 211) each step fetches the g rows of its 64 cells next to the f rows -- more L2 traffic, same arithmetic.
-template <bool DROPOUT, bool GRES>
+template <bool DROPOUT, bool GRES, bool TILED>
 __global__ __launch_bounds__(DW_THREADS, 1) void joint_dw_fused_kernel(DwArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 x [G tile | hidden tile] | g rows of one utterance
     const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
@@ -111,11 +144,15 @@ __global__ __launch_bounds__(DW_THREADS, 1) void joint_dw_fused_kernel(DwArgs a)
     // Steps = 64 consecutive lattice cells of one utterance.  With the frame counts the steps of an utterance end behind its
     // last live frame (G is zero beyond: a fifth of the lattice at lengths 0.6-1.0 x T), and the splits share the LIVE steps.
     // live_spu(b) is uniform (scalar loads); the starting point of this split comes from a prefix pass through LDS.
-#define live_spu(b_) __builtin_amdgcn_readfirstlane(dw_live_spu(a.act_lens, (b_), T, U1, a.spu))   /* uniform b only */
+    auto live_steps = [&](int b_) -> int {
+        if (TILED) { int n_, nut_, tb_; dw_tiles_of<false>(a.act_lens, a.label_lens, T, U1, b_, &n_, &nut_, &tb_); return n_; }
+        return dw_live_spu(a.act_lens, b_, T, U1, a.spu);
+    };
+#define live_spu(b_) __builtin_amdgcn_readfirstlane(live_steps(b_))   /* uniform b only */
     int nsteps = a.B * a.spu, step_beg, step_end, b_first = 0, s_first = 0;
-    if (a.act_lens && a.B <= 4096) {
+    if ((a.act_lens || TILED) && a.B <= 4096) {
         int* s_spu = reinterpret_cast<int*>(smem);        // (the stages are free until the loop starts; re-zeroed below)
-        for (int i = tid; i < a.B; i += DW_THREADS) s_spu[i] = dw_live_spu(a.act_lens, i, T, U1, a.spu);
+        for (int i = tid; i < a.B; i += DW_THREADS) s_spu[i] = live_steps(i);
         __syncthreads();
         int total = 0;
         for (int i = 0; i < a.B; ++i) total += s_spu[i];
@@ -170,30 +207,58 @@ __global__ __launch_bounds__(DW_THREADS, 1) void joint_dw_fused_kernel(DwArgs a)
         // beyond the 64 rows: a private dump slot (logical chunks >= 36 of a row are never read)
         yoff[k] = (i < (unsigned)(DW_MS * vpr)) ? dw_off((int)yr, (int)yc, DW_YROW) : dw_off(tid & 63, 40 + (tid >> 6), DW_YROW);
     }
+    unsigned goff[TILED ? DW_NY : 1];   // TILED: byte offset of G chunk k from the tile's first row (run of 8 rows per frame)
+    if (TILED) {
+#pragma unroll
+        for (int k = 0; k < DW_NY; ++k) {
+            unsigned i = tid + DW_THREADS * k;
+            i = i < (unsigned)(DW_MS * vpr) ? i : 0u;     // (chunks beyond the tile land in the dump slot)
+            const unsigned run = i / (unsigned)(DW_TU * vpr), within = i - run * (unsigned)(DW_TU * vpr);
+            goff[k] = run * (unsigned)(U1 * LD * 2) + within * 16u;
+        }
+    }
     const int xrow0 = tid >> 4, xch = tid & 15;                    // rows xrow0 and xrow0 + 32
     int hcol = h0 + xch * 8; hcol = hcol <= H - 8 ? hcol : H - 8;  // columns >= H are never written out
     const int xoff0 = dw_off(xrow0, xch, DW_XROW), xoff1 = dw_off(xrow0 + 32, xch, DW_XROW);
     // two register sets: the loads of step n+2 and n+3 are in flight while step n is multiplied (a step is ~1.7 us, the
     // loaded-HBM latency is of the same order: one step of distance left the staging phase waiting)
-    uint4 py[2][DW_NY], pf[2][DW_NX], pg[2][DW_NX];
+    // (py as native vectors: HIP's uint4 struct is assigned by memcpy, which kept the whole array in scratch memory once
+    // the masking code -- the only member-wise access -- was compiled out of the tiled variant)
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    u4v py[2][DW_NY];
+    uint4 pf[2][DW_NX], pg[2][DW_NX];
     unsigned pu[2][DW_NX];                                         // label index u of the hidden rows in flight
     const unsigned nfull = (unsigned)(DW_MS * vpr);                // 16-byte chunks of a full G tile
     const h2 zero2 = {(_Float16)0, (_Float16)0};
 
     // step index -> (utterance b, step s inside it); b_, s_ are uniform
-#define DW_LOAD(R, b_, s_)                                                                                      \
+#define DW_LOAD(R, b_, s_, tt_, ut_, tb_)                                                                       \
     do {                                                                                                       \
+        if (TILED) {                                                                                           \
+            const int t0n_ = (tt_) * DW_TF, u0n_ = (ut_) * DW_TU;                                               \
+            const int t0_ = t0n_ < T - DW_TF ? t0n_ : T - DW_TF, u0_ = u0n_ < U1 - DW_TU ? u0n_ : U1 - DW_TU;   \
+            const char* src_ = reinterpret_cast<const char*>(a.G + ((size_t)(b_) * a.cpu + (size_t)t0_ * U1 + u0_) * LD); \
+            _Pragma("unroll") for (int k = 0; k < DW_NY; ++k) py[R][k] = *reinterpret_cast<const u4v*>(src_ + goff[k]); \
+            const _Float16* fb_ = a.f + (size_t)(b_) * T * H + hcol;                                           \
+            _Pragma("unroll") for (int k = 0; k < DW_NX; ++k) {                                                \
+                const int r_ = xrow0 + 32 * k, t_ = t0_ + (r_ >> 3), u_ = u0_ + (r_ & 7);                      \
+                pf[R][k] = *reinterpret_cast<const uint4*>(fb_ + (size_t)t_ * H);                                 \
+                const bool in_ = t_ >= t0n_ && t_ < (tb_) && u_ >= u0n_;                                       \
+                pu[R][k] = ((unsigned)(t_ * U1 + u_) << 8) | (unsigned)u_ | (in_ ? 0u : 0x80000000u);             \
+                if (!GRES) pg[R][k] = *reinterpret_cast<const uint4*>(a.g + ((size_t)(b_) * U1 + u_) * H + hcol); \
+            }                                                                                                  \
+        } else {                                                                                               \
         const unsigned ci0_ = (unsigned)(s_) * DW_MS;                       /* first cell of the step inside the utterance */ \
         const unsigned rows_ = (unsigned)a.cpu - ci0_ < (unsigned)DW_MS ? (unsigned)a.cpu - ci0_ : (unsigned)DW_MS; \
         const unsigned nvalid_ = rows_ * (unsigned)vpr;                                                        \
         const char* src_ = reinterpret_cast<const char*>(a.G + ((size_t)(b_) * a.cpu + ci0_) * LD);   /* uniform base + 32-bit lane offsets */ \
         if (rows_ == (unsigned)DW_MS) {                                                                        \
             _Pragma("unroll") for (int k = 0; k < DW_NY; ++k)                                                  \
-                py[R][k] = *reinterpret_cast<const uint4*>(src_ + 16u * (tid + DW_THREADS * k < nfull ? tid + DW_THREADS * k : nfull - 1)); \
+                py[R][k] = *reinterpret_cast<const u4v*>(src_ + 16u * (tid + DW_THREADS * k < nfull ? tid + DW_THREADS * k : nfull - 1)); \
         } else {   /* the utterance's last, partial step: clamped here, masked when it is stored */            \
             _Pragma("unroll") for (int k = 0; k < DW_NY; ++k) {                                                \
                 const unsigned i_ = tid + DW_THREADS * k;                                                      \
-                py[R][k] = *reinterpret_cast<const uint4*>(src_ + 16u * (i_ < nvalid_ ? i_ : nvalid_ - 1));       \
+                py[R][k] = *reinterpret_cast<const u4v*>(src_ + 16u * (i_ < nvalid_ ? i_ : nvalid_ - 1));       \
             }                                                                                                  \
         }                                                                                                      \
         const _Float16* fb_ = a.f + (size_t)(b_) * T * H + hcol;                                               \
@@ -205,6 +270,7 @@ __global__ __launch_bounds__(DW_THREADS, 1) void joint_dw_fused_kernel(DwArgs a)
             pf[R][k] = *reinterpret_cast<const uint4*>(fb_ + (size_t)t_ * H);                                     \
             if (!GRES) pg[R][k] = *reinterpret_cast<const uint4*>(a.g + ((size_t)(b_) * U1 + pu[R][k]) * H + hcol); \
         }                                                                                                      \
+        }                                                                                                      \
     } while (0)
     // chunks beyond the 64 rows of a tile are stored unconditionally too (yoff = a never-read slot of the tile)
 #define DW_STORE(R, b_, s_, stage_)                                                                             \
@@ -212,7 +278,7 @@ __global__ __launch_bounds__(DW_THREADS, 1) void joint_dw_fused_kernel(DwArgs a)
         unsigned char* sY_ = smem + (stage_) * DW_STAGE;                                                       \
         unsigned char* sX_ = sY_ + DW_YTILE;                                                                   \
         const unsigned ci0_ = (unsigned)(s_) * DW_MS;                                                          \
-        const unsigned rows_ = (unsigned)a.cpu - ci0_ < (unsigned)DW_MS ? (unsigned)a.cpu - ci0_ : (unsigned)DW_MS; \
+        const unsigned rows_ = TILED ? (unsigned)DW_MS : ((unsigned)a.cpu - ci0_ < (unsigned)DW_MS ? (unsigned)a.cpu - ci0_ : (unsigned)DW_MS); \
         const unsigned nvalid_ = rows_ * (unsigned)vpr;                                                        \
         if (rows_ != (unsigned)DW_MS) {   /* (uniform) last, partial step of the utterance */                  \
             _Pragma("unroll") for (int k = 0; k < DW_NY; ++k) {                                                \
@@ -220,17 +286,19 @@ __global__ __launch_bounds__(DW_THREADS, 1) void joint_dw_fused_kernel(DwArgs a)
                 py[R][k].x = ok_ ? py[R][k].x : 0u; py[R][k].y = ok_ ? py[R][k].y : 0u; py[R][k].z = ok_ ? py[R][k].z : 0u; py[R][k].w = ok_ ? py[R][k].w : 0u; \
             }                                                                                                  \
         }                                                                                                      \
-        _Pragma("unroll") for (int k = 0; k < DW_NY; ++k) *reinterpret_cast<uint4*>(sY_ + yoff[k]) = py[R][k];    \
-        const unsigned cellb_ = (unsigned)(b_) * (unsigned)a.cpu + ci0_;                                       \
+        _Pragma("unroll") for (int k = 0; k < DW_NY; ++k) *reinterpret_cast<u4v*>(sY_ + yoff[k]) = py[R][k];    \
+        const unsigned cellb_ = (unsigned)(b_) * (unsigned)a.cpu + (TILED ? 0u : ci0_);                        \
         _Pragma("unroll") for (int k = 0; k < DW_NX; ++k) {                                                    \
             const unsigned r_ = xrow0 + 32 * k;                                                                \
+            const unsigned u_ = TILED ? (pu[R][k] & 0xFFu) : pu[R][k];                                         \
+            const unsigned cell_ = TILED ? cellb_ + ((pu[R][k] >> 8) & 0x7FFFFFu) : cellb_ + r_;               \
             union { uint4 u; h8 v; h2 p[4]; } x_, y_, z_;                                                      \
             x_.u = pf[R][k];                                                                                      \
-            if (GRES) y_.u = *reinterpret_cast<const uint4*>(gtile + pu[R][k] * DW_XROW + xch * 16);              \
+            if (GRES) y_.u = *reinterpret_cast<const uint4*>(gtile + u_ * DW_XROW + xch * 16);                 \
             else y_.u = pg[R][k];                                                                              \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) z_.p[j] = __builtin_elementwise_max(x_.p[j] + y_.p[j], zero2); \
-            if (DROPOUT) z_.v = dropout_apply8(z_.v, a.seed, cellb_ + r_, (unsigned)((h0 >> 3) + xch), a.thr); \
-            const bool in_ = r_ < rows_;                                                                       \
+            if (DROPOUT) z_.v = dropout_apply8(z_.v, a.seed, cell_, (unsigned)((h0 >> 3) + xch), a.thr);       \
+            const bool in_ = TILED ? !(pu[R][k] >> 31) : r_ < rows_;                                           \
             z_.u.x = in_ ? z_.u.x : 0u; z_.u.y = in_ ? z_.u.y : 0u; z_.u.z = in_ ? z_.u.z : 0u; z_.u.w = in_ ? z_.u.w : 0u; \
             *reinterpret_cast<uint4*>(sX_ + (k ? xoff1 : xoff0)) = z_.u;                                       \
         }                                                                                                      \
@@ -246,9 +314,19 @@ __global__ __launch_bounds__(DW_THREADS, 1) void joint_dw_fused_kernel(DwArgs a)
     } while (0)
     // advance (b, s) by one step, stopping at the split's last step (re-staged once more at the end: harmless, and the
     // loop body stays free of divergent branches)
-#define DW_NEXT(b_, s_, idx_, n_)                                                                              \
+#define DW_NEXT(b_, s_, idx_, n_, tt_, ut_, nut_, tb_)                                                          \
     do {                                                                                                       \
-        if ((idx_) + 1 < step_end) { ++(idx_); if (++(s_) == (n_)) { (s_) = 0; ++(b_); (n_) = live_spu(b_); } } \
+        if ((idx_) + 1 < step_end) {                                                                           \
+            ++(idx_);                                                                                          \
+            if (TILED) { if (++(ut_) == (nut_)) { (ut_) = 0; ++(tt_); } }                                      \
+            if (++(s_) == (n_)) {                                                                              \
+                (s_) = 0; ++(b_);                                                                              \
+                if (TILED) { int n2_, nu2_, tb2_; dw_tiles(a, __builtin_amdgcn_readfirstlane(b_), &n2_, &nu2_, &tb2_);   /* scalar loads: a vector load here drains vmcnt */ \
+                    (n_) = __builtin_amdgcn_readfirstlane(n2_); (nut_) = __builtin_amdgcn_readfirstlane(nu2_); \
+                    (tb_) = __builtin_amdgcn_readfirstlane(tb2_); (tt_) = 0; (ut_) = 0; }                       \
+                else (n_) = live_spu(b_);                                                                      \
+            }                                                                                                  \
+        }                                                                                                      \
     } while (0)
 
     // fragment addresses of k-step 0 in the current stage; k-step 1 = 32 rows further (same swizzle phase: an immediate
@@ -262,12 +340,19 @@ __global__ __launch_bounds__(DW_THREADS, 1) void joint_dw_fused_kernel(DwArgs a)
     // (b, s) of the step being multiplied is implicit; sb/ss/si = the step being staged, lb/ls/li = the step being loaded
     int sb = __builtin_amdgcn_readfirstlane(b_first), ss = __builtin_amdgcn_readfirstlane(s_first), si = step_beg;
     int sn = live_spu(sb);            // live steps of the utterance being staged / loaded
+    int stt = 0, sut = 0, snut = 1, stb = T;   // TILED: frame tile, label tile, label tiles and frame count of that utterance
+    if (TILED) {
+        int n_, nut_, tb_;
+        dw_tiles(a, __builtin_amdgcn_readfirstlane(sb), &n_, &nut_, &tb_);
+        snut = __builtin_amdgcn_readfirstlane(nut_); stb = __builtin_amdgcn_readfirstlane(tb_);
+        stt = ss / snut; sut = ss - stt * snut;
+    }
     int gb = sb;                      // utterance whose prediction rows are resident
     __syncthreads();                  // zero fill done
     DW_GTILE(gb);
-    DW_LOAD(0, sb, ss);
+    DW_LOAD(0, sb, ss, stt, sut, stb);
     DW_STORE(0, sb, ss, 0);
-    int lb = sb, ls = ss, li = si, ln = sn;
+    int lb = sb, ls = ss, li = si, ln = sn, ltt = stt, lut = sut, lnut = snut, ltb = stb;
     int cur = 0;
 #define DW_KSTEP(KS)                                                                                           \
         {                                                                                                      \
@@ -298,14 +383,14 @@ __global__ __launch_bounds__(DW_THREADS, 1) void joint_dw_fused_kernel(DwArgs a)
 #define DW_MMA DW_KSTEP(0) DW_KSTEP(1)
     // stage the next step (register set R) into the other LDS stage -- nobody reads it before the barrier -- and refill R
 #define DW_STAGE_NEXT(R)                                                                                       \
-        DW_NEXT(sb, ss, si, sn);                                                                               \
+        DW_NEXT(sb, ss, si, sn, stt, sut, snut, stb);                                                          \
         if (sb != gb) {   /* (uniform) next utterance: its prediction rows replace the resident ones (all readers of the */ \
             gb = sb;      /* old rows finished before the previous step's barrier) */                          \
             DW_GTILE(gb);                                                                                      \
         }                                                                                                      \
         DW_STORE(R, sb, ss, cur ^ 1);                                                                          \
-        DW_NEXT(lb, ls, li, ln);                                                                               \
-        DW_LOAD(R, lb, ls);
+        DW_NEXT(lb, ls, li, ln, ltt, lut, lnut, ltb);                                                          \
+        DW_LOAD(R, lb, ls, ltt, lut, ltb);
 #define DW_BODY(FIRST, SECOND)                                                                                 \
     {                                                                                                          \
         FIRST SECOND                                                                                           \
@@ -321,15 +406,15 @@ __global__ __launch_bounds__(DW_THREADS, 1) void joint_dw_fused_kernel(DwArgs a)
     // one register set is enough.  Waves 4-7 multiply first: the loads of the step they stage next were issued only one
     // multiply phase earlier, so they keep two sets in flight (steps n+2 and n+3 while step n is multiplied).
     if (__builtin_amdgcn_readfirstlane(wave >> 2) == 0) {
-        DW_NEXT(lb, ls, li, ln);
-        DW_LOAD(0, lb, ls);
+        DW_NEXT(lb, ls, li, ln, ltt, lut, lnut, ltb);
+        DW_LOAD(0, lb, ls, ltt, lut, ltb);
         __syncthreads();
         for (int step = step_beg; step < step_end; ++step) DW_BODY(DW_STAGE_NEXT(0), DW_MMA)
     } else {
-        DW_NEXT(lb, ls, li, ln);
-        DW_LOAD(1, lb, ls);
-        DW_NEXT(lb, ls, li, ln);
-        DW_LOAD(0, lb, ls);
+        DW_NEXT(lb, ls, li, ln, ltt, lut, lnut, ltb);
+        DW_LOAD(1, lb, ls, ltt, lut, ltb);
+        DW_NEXT(lb, ls, li, ln, ltt, lut, lnut, ltb);
+        DW_LOAD(0, lb, ls, ltt, lut, ltb);
         __syncthreads();
         for (int step = step_beg; step < step_end; step += 2) {
             DW_BODY(DW_MMA, DW_STAGE_NEXT(1))
@@ -386,8 +471,9 @@ extern "C" int64_t ia_joint_dw_fused_scratch_elems(int B, int T, int U1, int H, 
     return (int64_t)dw_splits(dw_nsteps(B, T, U1), H) * ((int64_t)LD * H);
 }
 
-extern "C" int ia_joint_dw_fused(const void* G, const void* f, const void* g, const int64_t* act_lens, int B, int T, int U1, int H,
-                                 int LD, float dropout_p, unsigned seed, float* dW, float* scratch, ia_stream_t stream) {
+extern "C" int ia_joint_dw_fused_ex(const void* G, const void* f, const void* g, const int64_t* act_lens, const int64_t* label_lens,
+                                    int B, int T, int U1, int H, int LD, float dropout_p, unsigned seed, float* dW, float* scratch,
+                                    ia_stream_t stream) {
     if (!G || !f || !g || !dW || !scratch || B <= 0 || T <= 0 || U1 <= 0) return IA_INVALID_VALUE;
     if (!ia_joint_dw_fused_supported(U1, H, LD)) return IA_UNSUPPORTED;
     if (!ia_is_aligned(G, 16) || !ia_is_aligned(f, 16) || !ia_is_aligned(g, 16) || !ia_is_aligned(dW, 16) || !ia_is_aligned(scratch, 16) ||
@@ -397,7 +483,7 @@ extern "C" int ia_joint_dw_fused(const void* G, const void* f, const void* g, co
     if (cells >= (1ll << 31) || nsteps >= (1ll << 30)) return IA_UNSUPPORTED;
     DwArgs a;
     a.G = (const _Float16*)G; a.f = (const _Float16*)f; a.g = (const _Float16*)g; a.part = scratch;
-    a.B = B; a.T = T; a.U1 = U1; a.H = H; a.LD = LD; a.act_lens = act_lens;
+    a.B = B; a.T = T; a.U1 = U1; a.H = H; a.LD = LD; a.act_lens = act_lens; a.label_lens = label_lens;
     a.cpu = T * U1; a.spu = (a.cpu + DW_MS - 1) / DW_MS;
     const int S = dw_splits(nsteps, H);
     a.steps_per_split = (int)((nsteps + S - 1) / S);
@@ -411,16 +497,27 @@ extern "C" int ia_joint_dw_fused(const void* G, const void* f, const void* g, co
     const dim3 grid(8 * ((Seff + 7) / 8) * a.ntiles), blk(DW_THREADS);
     const int lds = 2 * DW_STAGE + DW_MAX_U1 * DW_XROW;
     const bool gres = U1 <= DW_MAX_U1;
-#define IA_DW_LAUNCH(D_, G_)                                                        \
-    do {                                                                            \
-        IA_SET_MAX_LDS_ONCE((joint_dw_fused_kernel<D_, G_>), lds);                  \
-        hipLaunchKernelGGL((joint_dw_fused_kernel<D_, G_>), grid, blk, lds, st, a); \
+    // tiled steps (live frames x live labels): the lengths must be there, a tile must fit the lattice, the packed
+    // (cell, label) word of a hidden row holds 23 + 8 bits, the prefix pass over the utterances' step counts runs in LDS
+    static const bool no_tiles = [] { const char* e = getenv("IA_DW_TILED"); return e && e[0] == '0'; }();
+    const bool tiled = !no_tiles && act_lens && label_lens && T >= DW_TF && U1 >= DW_TU && U1 <= 256 && a.cpu < (1 << 23) && B <= 4096;
+#define IA_DW_LAUNCH(D_, G_, T_)                                                        \
+    do {                                                                                \
+        IA_SET_MAX_LDS_ONCE((joint_dw_fused_kernel<D_, G_, T_>), lds);                  \
+        hipLaunchKernelGGL((joint_dw_fused_kernel<D_, G_, T_>), grid, blk, lds, st, a); \
     } while (0)
-    if (a.thr > 0) { if (gres) IA_DW_LAUNCH(true, true); else IA_DW_LAUNCH(true, false); }
-    else { if (gres) IA_DW_LAUNCH(false, true); else IA_DW_LAUNCH(false, false); }
+#define IA_DW_LAUNCH2(D_, G_) do { if (tiled) IA_DW_LAUNCH(D_, G_, true); else IA_DW_LAUNCH(D_, G_, false); } while (0)
+    if (a.thr > 0) { if (gres) IA_DW_LAUNCH2(true, true); else IA_DW_LAUNCH2(true, false); }
+    else { if (gres) IA_DW_LAUNCH2(false, true); else IA_DW_LAUNCH2(false, false); }
+#undef IA_DW_LAUNCH2
 #undef IA_DW_LAUNCH
     IA_RETURN_IF_LAUNCH_FAILED();
     ia_partials_finish_wide(scratch, Seff, (int64_t)a.row_stride, dW, st);
     IA_RETURN_IF_LAUNCH_FAILED();
     return IA_OK;
+}
+
+extern "C" int ia_joint_dw_fused(const void* G, const void* f, const void* g, const int64_t* act_lens, int B, int T, int U1, int H,
+                                 int LD, float dropout_p, unsigned seed, float* dW, float* scratch, ia_stream_t stream) {
+    return ia_joint_dw_fused_ex(G, f, g, act_lens, nullptr, B, T, U1, H, LD, dropout_p, seed, dW, scratch, stream);
 }

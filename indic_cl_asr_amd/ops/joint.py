@@ -361,10 +361,11 @@ class _FusedJointRNNT(torch.autograd.Function):
         if fused_dw:
             dWk = torch.empty(LD, H, dtype=torch.float32, device=dev)
             scr = torch.empty(L.ia_joint_dw_fused_scratch_elems(B, T, U1, H, LD), dtype=torch.float32, device=dev)
-            st = L.ia_joint_dw_fused(_lib.ptr(G), _lib.ptr(f16), _lib.ptr(g16), _lib.ptr(act_lens) if DW_SKIP_DEAD_FRAMES else None, B, T, U1,
-                                     H, LD, p, seed, _lib.ptr(dWk),
-                                     _lib.ptr(scr), _lib.stream_ptr())
-            _lib.check(st, "ia_joint_dw_fused")
+            # dead frames AND dead labels skipped (8 x 8-cell tiles over each utterance's live box) when the lengths are passed
+            st = L.ia_joint_dw_fused_ex(_lib.ptr(G), _lib.ptr(f16), _lib.ptr(g16), _lib.ptr(act_lens) if DW_SKIP_DEAD_FRAMES else None,
+                                        _lib.ptr(label_lens) if DW_SKIP_DEAD_FRAMES else None, B, T, U1, H, LD, p, seed,
+                                        _lib.ptr(dWk), _lib.ptr(scr), _lib.stream_ptr())
+            _lib.check(st, "ia_joint_dw_fused_ex")
             dW_src, dW_scale = dWk[:V], 1.0 / (kappa * (1.0 - p))
             db_src, db_scale = dbk[:V], 1.0 / kappa
         else:

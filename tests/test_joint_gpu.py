@@ -213,3 +213,37 @@ def test_joint_weight_gradient_skips_dead_frames_without_changing_the_result():
     scale = outs[0].abs().max().item()
     assert scale > 0
     assert (outs[0] - outs[1]).abs().max().item() < 1e-5 * scale + 1e-7
+
+
+@pytest.mark.parametrize("B,T,U1,p", [(5, 70, 23, 0.2), (3, 9, 8, 0.0), (4, 37, 106, 0.1)])
+def test_joint_weight_gradient_over_live_tiles_matches_the_flat_steps(B, T, U1, p):
+    """ia_joint_dw_fused_ex with frame AND label counts (8-frame x 8-label tiles over each utterance's live box: dead labels
+    skipped too, edge tiles shifted back inside the lattice) == the flat 64-cell steps over the whole lattice, when G is
+    zero at the dead labels of live frames -- and whatever G holds behind the last live frame (the gradient kernel leaves
+    stale logits there): those rows are switched off through the regenerated hidden rows."""
+    from indic_cl_asr_amd import _lib
+    L = _lib.lib()
+    H, LD = 320, 264
+    g = torch.Generator().manual_seed(11 + T)
+    tl = torch.randint(1, T + 1, (B,), generator=g); tl[0] = T; tl[-1] = min(T, 3)
+    ul = torch.randint(0, U1, (B,), generator=g); ul[0] = U1 - 1; ul[-1] = 0          # label counts (live labels = ul + 1)
+    G = torch.randn(B, T, U1, LD, generator=g) * 0.01
+    live = (torch.arange(T).view(1, T, 1, 1) < tl.view(B, 1, 1, 1)) & (torch.arange(U1).view(1, 1, U1, 1) <= ul.view(B, 1, 1, 1))
+    Gz = (G * live).half()
+    stale = torch.where(torch.arange(T).view(1, T, 1, 1) >= tl.view(B, 1, 1, 1), torch.full_like(Gz, 7.5), Gz)   # junk behind the end
+    f = torch.randn(B, T, H, generator=g).half().cuda()
+    gg = torch.randn(B, U1, H, generator=g).half().cuda()
+    scr = torch.empty(L.ia_joint_dw_fused_scratch_elems(B, T, U1, H, LD), device="cuda")
+    ref = torch.empty(LD, H, device="cuda")
+    Gd = Gz.view(B * T * U1, LD).contiguous().cuda()
+    _lib.check(L.ia_joint_dw_fused(_lib.ptr(Gd), _lib.ptr(f), _lib.ptr(gg), None, B, T, U1, H, LD, p, 7, _lib.ptr(ref),
+                                   _lib.ptr(scr), _lib.stream_ptr()), "ia_joint_dw_fused")
+    out = torch.empty(LD, H, device="cuda")
+    Gs = stale.view(B * T * U1, LD).contiguous().cuda()
+    tld, uld = tl.cuda(), ul.cuda()
+    _lib.check(L.ia_joint_dw_fused_ex(_lib.ptr(Gs), _lib.ptr(f), _lib.ptr(gg), _lib.ptr(tld), _lib.ptr(uld), B, T, U1, H,
+                                      LD, p, 7, _lib.ptr(out), _lib.ptr(scr), _lib.stream_ptr()), "ia_joint_dw_fused_ex")
+    torch.cuda.synchronize()
+    scale = ref.abs().max().item()
+    assert scale > 0
+    assert (ref - out).abs().max().item() < 2e-5 * scale + 1e-7   # same products, another summation order

@@ -40,6 +40,10 @@ def main():
         t = timeit(lambda: fast.ffn_fused(x, ln, l1, l2, 0.5, 0.1, 1, 0.1, 2, ln2=ln2))
         print("ffn_fused mode %d (%s): %.1f us" % (mode, {0: "full", 1: "no loads", 2: "no mfma", 3: "neither", 6: "half the workgroups, no mfma", 8: "contiguous slots", 10: "contiguous slots, no mfma", 14: "contiguous, half the workgroups, no mfma"}[mode], t))
     os.environ["IA_FFN_MODE"] = "0"
+    for dff2 in (256, 512, 1024, 2048):   # fixed cost (prologue / epilogue / launch) against the per-chunk cost
+        m1, m2 = torch.nn.Linear(d, dff2).cuda(), torch.nn.Linear(dff2, d).cuda()
+        t = timeit(lambda: fast.ffn_fused(x, ln, m1, m2, 0.5, 0.1, 1, 0.1, 2, ln2=ln2))
+        print("ffn_fused d_ff = %d (%d chunks): %.1f us" % (dff2, dff2 // 128, t))
     t = timeit(lambda: fast.ffn_fused(x, ln, l1, l2, 0.5, 0.0, 1, 0.0, 2))
     print("ffn_fused no dropout, no ln2: %.1f us  -> %.0f TFLOP/s" % (t, 4 * N * d * dff / t / 1e6))
 
