@@ -268,12 +268,12 @@ def main():
 
     events = HipEvents()
     rnnt_mod.PROFILE_HOOK = events.hook
-    try:   # cells the gradient kernel has to touch: frames < T_b + 4 of every utterance (+ the 64-cell tile that straddles the end)
+    try:   # cells the gradient kernel has to touch: frames < T_b + 8 of every utterance (+ the 64-cell tile that straddles the end)
         from indic_cl_asr_amd.encoder import subsampled_length
         from indic_cl_asr_amd.features import mel_frame_count
         h_enc = [int(subsampled_length(mel_frame_count(int(n), cfg.n_fft, cfg.n_window_stride))) for n in host_lens[0]]
         Tq, U1q = max(h_enc), max(int(u) for u in host_lens[1]) + 1
-        live = sum(min(Tq * U1q, (min(Tq, t + 4) * U1q + 63) // 64 * 64) for t in h_enc)
+        live = sum(min(Tq * U1q, (min(Tq, t + 8) * U1q + 63) // 64 * 64) for t in h_enc)
         events.touched_fraction = live / float(len(h_enc) * Tq * U1q)
     except Exception:
         events.touched_fraction = None

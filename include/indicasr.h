@@ -147,7 +147,7 @@ int ia_joint_backward_g(void* logits_inout, const int64_t* labels, const int64_t
                         size_t workspace_bytes, ia_stream_t stream, void* grad_kernel_start_event,
                         void* grad_kernel_stop_event);
 /* The same; skip_dead_frames != 0 (fused dbias variant only, i.e. dbias_out != NULL): the kernel neither reads nor zero-fills
- * the 64-cell tiles that lie entirely behind frame act_lens[b] + 3 of an utterance -- valid when G is consumed by
+ * the 64-cell tiles that lie entirely behind frame act_lens[b] + 7 of an utterance -- valid when G is consumed by
  * ia_joint_dh_fused and ia_joint_dw_fused (with act_lens), which read nothing there. */
 int ia_joint_backward_g_skip(void* logits_inout, const int64_t* labels, const int64_t* act_lens, const int64_t* label_lens, int B,
                              int T, int U1, int V, int LD, int blank, float fastemit, const float* cost_grad, float kappa,
@@ -207,7 +207,9 @@ int ia_joint_dw_fused(const void* G, const void* f, const void* g, const int64_t
  * B <= 4096) a step is an 8-frame x 8-label tile and an utterance's steps cover its live frames x live labels only -- the
  * labels u > label_lens[b] of a live frame hold zeros in G as well (A/parts/numba/rnnt_loss/utils/cuda_utils/
  * gpu_rnnt_kernel.py:351-403 writes nothing there), so they are skipped like the frames behind the utterance's end.
- * Other shapes run the flat 64-cell steps of ia_joint_dw_fused. */
+ * Other shapes run the flat 64-cell steps of ia_joint_dw_fused.  G must be finite on the frames act_lens[b] .. act_lens[b] + 7
+ * (the last frame tile of an utterance covers up to seven of them; their contribution is switched off through zeroed
+ * hidden rows, and 0 x NaN is NaN): ia_joint_backward_g_skip zero-fills exactly those and leaves the rest alone. */
 int ia_joint_dw_fused_ex(const void* G, const void* f, const void* g, const int64_t* act_lens, const int64_t* label_lens, int B,
                          int T, int U1, int H, int LD, float dropout_p, unsigned seed, float* dW, float* scratch,
                          ia_stream_t stream);

@@ -14,8 +14,11 @@
 
 #include <stdlib.h>
 
-#include "ia_common.h"
-#include "dropout_mask.h"
+#include "gemm_args.h"
+
+// gemm_big.hip: 256 x 256 tiles for the large shapes
+int ia_gemm_big_wanted(int M, int N, int K, int lda, int ldw, int act);
+int ia_gemm_big_launch(const void* gemm_args, hipStream_t st);
 
 namespace {
 
@@ -26,22 +29,6 @@ constexpr int G_BK = 64;
 constexpr int G_ROWB = G_BK * 2 + 16;  // LDS bytes per tile row (padded)
 constexpr int G_THREADS = 256;
 
-struct GemmArgs {
-    const __bf16* A; const __bf16* W; const float* bias; const float* R;
-    float* outF; __bf16* outH;
-    __bf16* outPre;     // optional: the bias-added value BEFORE act / dropout, rounded to bf16 (the activation is then applied
-                        // to the rounded value: what a separate elementwise pass over outPre would compute)
-    const __bf16* aux;  // act == 3: out = bf16(acc) * SiLU'(aux) -- the data gradient through dropout(SiLU(.)) in one pass
-    int M, N, K, lda, ldw, ldr, ldof, ldoh, ldpre, ldaux;
-    int out_f16;        // outH holds IEEE half instead of bf16 (the joint's f16 operands come straight out of its projections)
-    int act;            // 0 none, 1 SiLU, 2 ReLU, 3 SiLU backward against aux
-    float alpha;
-    unsigned seed, thr; // dropout keep if byte >= thr (thr = round(256 p)); scale 1/(1-thr/256) folded in `alpha_keep`
-    float keep_scale;
-    // implicit-GEMM mode (CONV): A is a channels-last image [cB, cT1, cF1, cC]; row m = (b, t2, f2) of the 3x3 / stride-2 /
-    // pad-1 convolution output [cB, cT2, cF2, N]; k = tap*cC + ci.
-    int cT1, cF1, cC, cT2, cF2;
-};
 
 __device__ __forceinline__ unsigned g_hash32(unsigned x) {
     x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
@@ -215,63 +202,7 @@ __global__ __launch_bounds__(G_THREADS, (BM == 128 ? 3 : 4)) void gemm_bf16_nt_k
         const float4 x0 = *reinterpret_cast<const float4*>(sc + row * LDC + cv * 8);
         const float4 x1 = *reinterpret_cast<const float4*>(sc + row * LDC + cv * 8 + 4);
         v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
-        if (a.bias) {
-            const float4 b0 = *reinterpret_cast<const float4*>(a.bias + gn), b1 = *reinterpret_cast<const float4*>(a.bias + gn + 4);
-            v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-        }
-        if (a.outPre) {
-            union { uint4 u; __bf16 h[8]; } o;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { o.h[j] = (__bf16)v[j]; v[j] = (float)o.h[j]; }
-            *reinterpret_cast<uint4*>(a.outPre + (size_t)gm * a.ldpre + gn) = o.u;
-        }
-        if (a.act == 1) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = ia_silu_fast(v[j]);
-        } else if (a.act == 2) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
-        } else if (a.act == 3) {
-            union { uint4 u; __bf16 h[8]; } x;
-            x.u = *reinterpret_cast<const uint4*>(a.aux + (size_t)gm * a.ldaux + gn);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float t = (float)x.h[j], sg = ia_sigmoid_fast(t);
-                v[j] = (float)(__bf16)v[j] * (sg * (1.f + t * (1.f - sg)));
-            }
-        }
-        float sc_all = a.alpha;
-        if (a.thr > 0) {
-            const unsigned m = ia_keep8(a.seed, (unsigned)gm, (unsigned)a.N, (unsigned)gn, a.thr);
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (!((m >> j) & 1u)) v[j] = 0.f;
-            sc_all *= a.keep_scale;
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] *= sc_all;
-        if (a.R) {
-            const float4 r0 = *reinterpret_cast<const float4*>(a.R + (size_t)gm * a.ldr + gn);
-            const float4 r1 = *reinterpret_cast<const float4*>(a.R + (size_t)gm * a.ldr + gn + 4);
-            v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
-        }
-        if (a.outF) {
-            *reinterpret_cast<float4*>(a.outF + (size_t)gm * a.ldof + gn) = make_float4(v[0], v[1], v[2], v[3]);
-            *reinterpret_cast<float4*>(a.outF + (size_t)gm * a.ldof + gn + 4) = make_float4(v[4], v[5], v[6], v[7]);
-        }
-        if (a.outH) {
-            if (a.out_f16) {
-                union { uint4 u; _Float16 h[8]; } o;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) o.h[j] = (_Float16)v[j];
-                *reinterpret_cast<uint4*>(a.outH + (size_t)gm * a.ldoh + gn) = o.u;
-            } else {
-                union { uint4 u; __bf16 h[8]; } o;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) o.h[j] = (__bf16)v[j];
-                *reinterpret_cast<uint4*>(a.outH + (size_t)gm * a.ldoh + gn) = o.u;
-            }
-        }
+        gemm_epilogue8(a, gm, gn, v);
     }
     }
 }
@@ -338,6 +269,7 @@ extern "C" int ia_gemm_bf16_ex2(const void* A, int lda, const void* W, int ldw, 
     // persistent prediction-network workgroups hold ~40 CUs while the encoder runs: many small workgroups then balance over the
     // CUs that are left, fat ones queue behind the slow CUs (step at 32 x 15 s: 64 rows 10.47 ms, 96 rows 10.52, 128 rows
     // 10.68, A/B on one box).  Large problems (long K or thousands of tiles) keep the 128-row tiles' operand reuse.
+    if (ia_gemm_big_wanted(M, N, K, lda, ldw, act)) return ia_gemm_big_launch(&a, st);
     const char* forced_env = getenv("IA_GEMM_BM");   // diagnostics (tools/bench_gemm_tiles.py)
     const int forced = forced_env ? atoi(forced_env) : 0;
     const long ntn = (N + 127) / 128;

@@ -273,7 +273,7 @@ __global__ __launch_bounds__(GD_THREADS, 4) void joint_grad_h_db_kernel(_Float16
                                                                         float* __restrict__ db_part,
                                                                         const unsigned char* __restrict__ far) {
     // far (optional): one byte per 64-cell tile, written by rnnt_cell_scalars: every cell of the tile lies behind frame
-    // T_b + 3 of its utterance.  The fused hidden- / weight-gradient kernels read nothing there (4-frame passes, 64-cell steps
+    // T_b + 7 of its utterance.  The fused hidden- / weight-gradient kernels read nothing there (4-frame passes, 64-cell steps
     // up to the last live frame), so such a tile is neither read nor zero-filled.
     __shared__ float4 scs[2][GT_CELLS];
     __shared__ __attribute__((aligned(16))) float red[GD_THREADS * 8];

@@ -78,7 +78,17 @@ __global__ __launch_bounds__(DH_WAVES * 64, (DH_WAVES + 3) / 4) void joint_dh_fu
     const int T = a.T, U1 = a.U1, H = a.H, LD = a.LD;
     const int ntt = (T + DH_TT - 1) / DH_TT;
     int bid = blockIdx.x;
-    const int half = bid % a.nh; bid /= a.nh;   // hidden-half siblings are neighbours: the second read of G hits L2
+    // Workgroup ids go round-robin over the 8 XCDs, each with its own L2: the hidden-half siblings of a tile (they read the
+    // same G rows) get ids CONGRUENT mod 8 -- same XCD, consecutive in its dispatch order -- so the second read of G hits
+    // that L2 (neighbouring ids put them on two XCDs: PMC fetch 1.55 x G).  Tiles beyond the last full group of 8 keep
+    // the neighbour order.
+    int half;
+    {
+        const int ntiles = (int)gridDim.x / a.nh, full = (ntiles / 8) * 8;
+        const int grp = bid / (8 * a.nh), r = bid - grp * (8 * a.nh);
+        if (grp * 8 < full) { half = r >> 3; bid = grp * 8 + (r & 7); }
+        else { const int r2 = bid - full * a.nh; half = r2 % a.nh; bid = full + r2 / a.nh; }
+    }
     const int tt = bid % ntt;
     const int b = bid / ntt;
     const int t0 = tt * DH_TT;

@@ -121,8 +121,10 @@ __device__ __forceinline__ void dw_tiles_of(const int64_t* act_lens, const int64
 // utterance's steps cover its live frames x live labels only (the flat steps skip dead frames but not dead labels: another
 // ~14 % of the lattice at label lengths 0.6-1.0 x U).  A tile's G rows are 8 runs of 8 contiguous rows: uniform base +
 // per-thread CONSTANT offsets, no index arithmetic per step; a tile that would overhang the tensor is shifted back inside
-// and the rows it shares with its neighbour are switched off through the (regenerated) hidden rows, like the frames
-// behind the utterance's end (G holds stale logits there: finite, times a zero hidden row).
+// and the rows it shares with its neighbour are switched off through the (regenerated) hidden rows, like the up to 7 frames
+// behind the utterance's end that its last frame tile covers: G must be FINITE there (a zero hidden row times NaN is NaN) --
+// the gradient kernel zero-fills the frames T_b .. T_b + 7 (rnnt_cell_scalars' far-tile flags), what lies behind them (never
+// written by anybody) is not read.
 // GRES: the utterance's prediction rows stay resident in LDS (U+1 <= 128: the bench shapes); otherwise (30 s utterances:
 // U+1 = 211) each step fetches the g rows of its 64 cells next to the f rows -- more L2 traffic, same arithmetic.
 template <bool DROPOUT, bool GRES, bool TILED>
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(DW_THREADS, 1) void joint_dw_fused_kernel(DwArgs a)
         }                                                                                                      \
     } while (0)
     // chunks beyond the 64 rows of a tile are stored unconditionally too (yoff = a never-read slot of the tile)
-#define DW_STORE(R, b_, s_, stage_)                                                                             \
+#define DW_STORE(R, b_, s_, stage_)                                                              \
     do {                                                                                                       \
         unsigned char* sY_ = smem + (stage_) * DW_STAGE;                                                       \
         unsigned char* sX_ = sY_ + DW_YTILE;                                                                   \

@@ -249,9 +249,10 @@ __global__ __launch_bounds__(256) void rnnt_cell_scalars(
         const int64_t cc = in ? c : cells - 1;
         const int64_t btq = cc / U1;
         const int tq = (int)(btq % T), bq = (int)(btq / T);
-        // a wave = one 64-cell tile of the gradient kernel: flag it when every cell lies behind frame T_b + 3 (nothing reads G
-        // there when the fused hidden- and weight-gradient kernels consume it: csrc/joint_bwd.hip skips such tiles on request)
-        const bool cell_far = !in || tq >= (int)act_lens[bq] + 4;
+        // a wave = one 64-cell tile of the gradient kernel: flag it when every cell lies behind frame T_b + 7 (nothing reads G
+        // there when the fused hidden- and weight-gradient kernels consume it -- 4-frame passes, 8-frame x 8-label tiles that
+        // start in front of T_b --: csrc/joint_bwd.hip skips such tiles on request; the frames T_b .. T_b + 7 are zero-filled)
+        const bool cell_far = !in || tq >= (int)act_lens[bq] + 8;
         const unsigned long long all_far = __ballot(cell_far);
         if (far && (threadIdx.x & 63) == 0 && in) far[c >> 6] = (all_far == ~0ull) ? 1 : 0;
         if (!in) continue;

@@ -29,7 +29,7 @@ static inline bool rnnt_ws_layout(int B, int T, int U1, RnntWs* w) {
     w->off_beta = o;  o = ia_align_up(o + side, 256);
     w->off_ll = o;    o = ia_align_up(o + (size_t)2 * B * sizeof(float), 256);
     w->off_cs = o;    o = ia_align_up(o + cells * sizeof(float4), 256);
-    w->off_far = o;   o = ia_align_up(o + (cells + 63) / 64, 256);   // one byte per 64-cell tile: all its cells lie behind frame T_b + 3
+    w->off_far = o;   o = ia_align_up(o + (cells + 63) / 64, 256);   // one byte per 64-cell tile: all its cells lie behind frame T_b + 7
     w->total = o;
     return true;
 }

@@ -1,0 +1,36 @@
+"""csrc/gemm_big.hip (256 x 256 tiles, 32x32x16 MFMAs, operands global -> LDS by DMA) against the 128-row projection GEMM
+it replaces for very large problems: same arguments, same epilogue; the two kernels add the k products in the same order
+inside a 64-deep stage, so the results agree to fp32 rounding of the accumulated sums."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("M,N,K", [(777, 256, 128), (2048 + 13, 512, 320), (256, 768, 1024)])
+def test_large_tile_gemm_matches_the_128_row_kernel(M, N, K):
+    from indic_cl_asr_amd.ops import fast
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    a = (torch.randn(M, K, device="cuda", generator=g) * 0.5).bfloat16()
+    w = (torch.randn(N, K, device="cuda", generator=g) * 0.05).bfloat16()
+    bias = torch.randn(N, device="cuda", generator=g)
+    res = torch.randn(M, N, device="cuda", generator=g)
+    outs = []
+    try:
+        for mode in ("0", "1"):
+            os.environ["IA_GEMM_BIG"] = mode
+            of, oh = fast.gemm(a, w, bias, act=1, dropout_p=0.1, seed=3, alpha=0.5, residual=res, out_f32=torch.empty_like(res))
+            outs.append((of, oh))
+    finally:
+        os.environ.pop("IA_GEMM_BIG", None)
+    torch.cuda.synchronize()
+    ref = (a.double() @ w.double().t() + bias.double())
+    ref = ref * torch.sigmoid(ref)
+    scale = ref.abs().max().item()
+    keep = outs[0][0] != res                                        # the dropped elements equal the residual in both
+    assert torch.equal(keep, outs[1][0] != res)
+    assert (outs[0][0] - outs[1][0]).abs().max().item() <= 2e-6 * scale
+    got = (outs[1][0].double() - res.double()) / (0.5 / 0.8984375)     # undo alpha and the keep scale 256 / (256 - 26)
+    assert ((got - ref).abs() * keep).max().item() <= 4e-3 * scale       # bf16 operands, fp32 accumulation

@@ -219,8 +219,9 @@ def test_joint_weight_gradient_skips_dead_frames_without_changing_the_result():
 def test_joint_weight_gradient_over_live_tiles_matches_the_flat_steps(B, T, U1, p):
     """ia_joint_dw_fused_ex with frame AND label counts (8-frame x 8-label tiles over each utterance's live box: dead labels
     skipped too, edge tiles shifted back inside the lattice) == the flat 64-cell steps over the whole lattice, when G is
-    zero at the dead labels of live frames -- and whatever G holds behind the last live frame (the gradient kernel leaves
-    stale logits there): those rows are switched off through the regenerated hidden rows."""
+    zero at the dead labels of live frames and on the frames T_b .. T_b + 7 (what ia_joint_backward_g_skip guarantees) --
+    and whatever G holds behind them (the forward never writes the cells outside an utterance's box and the gradient kernel
+    leaves those tiles alone: NaN patterns here)."""
     from indic_cl_asr_amd import _lib
     L = _lib.lib()
     H, LD = 320, 264
@@ -230,7 +231,7 @@ def test_joint_weight_gradient_over_live_tiles_matches_the_flat_steps(B, T, U1, 
     G = torch.randn(B, T, U1, LD, generator=g) * 0.01
     live = (torch.arange(T).view(1, T, 1, 1) < tl.view(B, 1, 1, 1)) & (torch.arange(U1).view(1, 1, U1, 1) <= ul.view(B, 1, 1, 1))
     Gz = (G * live).half()
-    stale = torch.where(torch.arange(T).view(1, T, 1, 1) >= tl.view(B, 1, 1, 1), torch.full_like(Gz, 7.5), Gz)   # junk behind the end
+    stale = torch.where(torch.arange(T).view(1, T, 1, 1) >= tl.view(B, 1, 1, 1) + 8, torch.full_like(Gz, float('nan')), Gz)   # never-written memory behind frame T_b + 7
     f = torch.randn(B, T, H, generator=g).half().cuda()
     gg = torch.randn(B, U1, H, generator=g).half().cuda()
     scr = torch.empty(L.ia_joint_dw_fused_scratch_elems(B, T, U1, H, LD), device="cuda")

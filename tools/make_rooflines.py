@@ -16,7 +16,7 @@ import sys
 HBM, MFMA = 8000.0, 2500.0          # GB/s, TFLOP/s
 B, T, U1, d, H, LD = 32, 376, 106, 256, 640, 264
 N, CELLS, NPARAM = B * T, B * T * U1, 17.3e6   # trainable parameters at freeze_encoder_till = 12 (FlatParams.numel)
-LIVE = 0.816                         # share of lattice cells in front of frame T_b + 3 (bench lengths, bench.py touched_fraction)
+LIVE = 0.827                         # share of lattice cells in front of frame T_b + 8 (bench lengths, bench.py touched_fraction)
 
 # substring of the kernel name -> (label, bound, algorithmic work per launch, unit, note)
 WORK = [
