@@ -12,7 +12,7 @@ layers <= 12 frozen as in the reference's config.yaml.  Weak scaling: every rank
 
 Rank 0 prints ONE JSON line (contract in the task statement) with these extra objects:
   roofline       the HBM-bound transducer gradient kernel timed with HIP events inside the timed steps; `traffic` = HBM
-                 bytes per launch from this round's PMC passes of the same command (profiles/r02_pmc_traffic.json)
+                 bytes per launch from this round's PMC passes of the same command (profiles/r03_pmc_traffic.json)
   roofline_mfma  the dominant MFMA kernel of the step (fused joint hidden-gradient kernel), timed the same way
   cpu_baseline   the CPU oracle (oracle/step_ref.py, fp32, torch intra-op threads = host cores) on a bounded sample of the
                  SAME workload + the GPU-vs-oracle loss error on that sample with identical weights (`loss_rel_err`) + the
@@ -442,12 +442,13 @@ def main():
             if peaks and key in peaks:
                 d["measured"] = round(ach / peaks[key], 4)
             return d
+        pmc = None
         s = events.summary()
         if s is not None:
             avg_ms, avg_bytes, n = s
             ach = avg_bytes / (avg_ms * 1e-3) / 1e9
             traffic = None
-            try:  # HBM bytes per launch from this round's PMC passes of the same command (profiles/r02_pmc_traffic.json)
+            try:  # HBM bytes per launch from this round's PMC passes of the same command (profiles/r03_pmc_traffic.json)
                 pmc_file = "r03_pmc_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) else "r02_pmc_traffic.json"
                 pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
                 if args.batch == 32 and args.seconds == 15.0 and args.preset == "medium":
@@ -469,7 +470,9 @@ def main():
             avg = sum(ms_l) / len(ms_l)
             tf = fl / (avg * 1e-3) / 1e12
             out["roofline_mfma"] = {"kernel": "joint_dh_fused_kernel", "bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TFS,
-                                    "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TFS, 4), "traffic": None, "launches": len(ms_l),
+                                    "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TFS, 4),
+                                    "traffic": (pmc or {}).get("kernels", {}).get("joint_dh_fused_kernel", {}).get("hbm_bytes_per_launch"),
+                                    "launches": len(ms_l),
                                     "avg_launch_ms": round(avg, 4), "algorithmic_flops_per_launch": int(fl),
                                     "frac_of": frac_vs(tf, "mfma_bf16_TFs", MFMA_BF16_PEAK_TFS)}
         # per-kernel table of this round's committed profile passes (tools/make_rooflines.py: share of the step, bound, achieved,
