@@ -296,6 +296,14 @@ int ia_subsample_conv1(const float* feats, int B, int Fm, int Tm, int C, const f
                        ia_stream_t stream);
 int ia_subsample_conv2(const void* in_cl, int B, int T1, int F1, int C, const void* w2r, const float* b2, int N, void* out,
                        ia_stream_t stream);
+/* ia_gemm_bf16_ln: projection into the residual stream + LayerNorm of the updated rows in one launch (N == 256: a workgroup of
+ * the 64 x 256-tile kernel owns whole rows):  x = R + alpha * dropout(A @ W^T + bias) -> outF (may alias R),
+ * LN(x) * ln_g + ln_b -> outH (bf16).  The attention's out-projection followed by the convolution module's LayerNorm
+ * (conformer_modules.py:171-186).  Same operands, dropout mask and summation order as ia_gemm_bf16 + ia_layernorm. */
+int ia_gemm_bf16_ln_supported(int N, int K);
+int ia_gemm_bf16_ln(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const float* bias, float dropout_p,
+                    unsigned seed, float alpha, const float* R, int ldr, float* outF, int ldof, const float* ln_g,
+                    const float* ln_b, float ln_eps, void* outH, int ldoh, ia_stream_t stream);
 int ia_layernorm(const float* x, int ldx, int N, int d, const float* g1, const float* b1, float eps, float* outF,
                  int ldf, const float* g2, const float* b2, void* outH, int ldh, ia_stream_t stream);
 int ia_glu_dwconv(const void* x2, const int64_t* lens, int B, int T, int d, int ksz, const float* w, const float* bias,

@@ -114,6 +114,8 @@ SIGNATURES = {
     "ia_joint_dw_fused_supported": (_i, [_i, _i, _i]),
     "ia_joint_dw_fused_scratch_elems": (_i64, [_i, _i, _i, _i, _i]),
     "ia_joint_dw_fused": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _c.c_uint, _vp, _vp, _vp]),
+    "ia_gemm_bf16_ln_supported": (_i, [_i, _i]),
+    "ia_gemm_bf16_ln": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _f, _c.c_uint, _f, _vp, _i, _vp, _i, _vp, _vp, _f, _vp, _i, _vp]),
     "ia_joint_dw_fused_ex": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _c.c_uint, _vp, _vp, _vp]),
     "ia_gemm_bf16": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _f, _c.c_uint, _f, _vp, _i, _vp, _i, _vp, _i, _vp]),
     "ia_gemm_bf16_ex": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _f, _c.c_uint, _f, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp]),

@@ -136,9 +136,16 @@ extern "C" int ia_conformer_prefix_fwd_seg(const ia_block_params* layers, int n_
             IA_TRY(ia_relpos_attention_flash(qkv, plu, L.pos_u, L.pos_v, lens, B, T, H, dk, patt, seed + 7, ctx, stream));
         else
             IA_TRY(ia_relpos_attention(qkv, plu, L.pos_u, L.pos_v, lens, B, T, H, dk, patt, seed + 7, vt, ctx, stream));
-        IA_TRY(ia_gemm_bf16(ctx, d, L.w_out, d, N, d, d, L.b_out, 0, p, seed + 3, 1.f, x, d, x, d, nullptr, 0, stream));
-        // convolution module
-        IA_TRY(ia_layernorm(x, d, N, d, L.ln_conv_g, L.ln_conv_b, L.ln_eps, nullptr, 0, nullptr, nullptr, y, d, stream));
+        // out-projection (+ residual) and the convolution module's LayerNorm: one launch at d_model = 256 (64 x 256 tiles own
+        // whole rows), two otherwise
+        static const bool ln_in_gemm = [] { const char* e = getenv("IA_LN_IN_GEMM"); return !(e && e[0] == '0'); }();
+        if (ln_in_gemm && ia_gemm_bf16_ln_supported(d, d)) {
+            IA_TRY(ia_gemm_bf16_ln(ctx, d, L.w_out, d, N, d, d, L.b_out, p, seed + 3, 1.f, x, d, x, d, L.ln_conv_g, L.ln_conv_b, L.ln_eps, y, d,
+                                   stream));
+        } else {
+            IA_TRY(ia_gemm_bf16(ctx, d, L.w_out, d, N, d, d, L.b_out, 0, p, seed + 3, 1.f, x, d, x, d, nullptr, 0, stream));
+            IA_TRY(ia_layernorm(x, d, N, d, L.ln_conv_g, L.ln_conv_b, L.ln_eps, nullptr, 0, nullptr, nullptr, y, d, stream));
+        }
         if (bn_fixed && glu_in_gemm && L.w_pw1_glu && L.b_pw1_glu) {
             // GLU in the epilogue of pointwise_conv1 (weight rows regrouped by the caller: value | gate halves per 128-column
             // tile): the [N,2d] tensor is never written, the depthwise conv reads the gated [N,d] bf16 rows (half the loads,

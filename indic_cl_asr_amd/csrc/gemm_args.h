@@ -23,6 +23,9 @@ struct GemmArgs {
     // implicit-GEMM mode (CONV): A is a channels-last image [cB, cT1, cF1, cC]; row m = (b, t2, f2) of the 3x3 / stride-2 /
     // pad-1 convolution output [cB, cT2, cF2, N]; k = tap*cC + ci.
     int cT1, cF1, cC, cT2, cF2;
+    // LayerNorm of the finished row (64 x 256 tiles, N == 256 only: a workgroup owns whole rows): outF keeps the updated
+    // residual, outH receives LN(row) * ln_g + ln_b as bf16 -- the next projection's operand
+    const float* ln_g; const float* ln_b; float ln_eps;
 };
 
 // 8 consecutive output columns gn .. gn+7 of row gm: v = the accumulated products.  bias -> (outPre) -> activation ->
@@ -72,7 +75,7 @@ __device__ __forceinline__ void gemm_epilogue8(const GemmArgs& a, int gm, int gn
         *reinterpret_cast<float4*>(a.outF + (size_t)gm * a.ldof + gn) = make_float4(v[0], v[1], v[2], v[3]);
         *reinterpret_cast<float4*>(a.outF + (size_t)gm * a.ldof + gn + 4) = make_float4(v[4], v[5], v[6], v[7]);
     }
-    if (a.outH) {
+    if (a.outH && !a.ln_g) {
         if (a.out_f16) {
             union { uint4 u; _Float16 h[8]; } o;
 #pragma unroll

@@ -30,6 +30,16 @@ constexpr int G_ROWB = G_BK * 2 + 16;  // LDS bytes per tile row (padded)
 constexpr int G_THREADS = 256;
 
 
+// sum over the 32 lanes of a half wave (as csrc/ffn_fused.hip): every lane of the half wave gets the total
+__device__ __forceinline__ float gemm_half_wave_sum(float v) {
+    v += IA_DPP_F(0.f, v, 0xB1, 0xF);    // quad_perm xor 1
+    v += IA_DPP_F(0.f, v, 0x4E, 0xF);    // quad_perm xor 2
+    v += IA_DPP_F(0.f, v, 0x141, 0xF);   // row_half_mirror
+    v += IA_DPP_F(0.f, v, 0x140, 0xF);   // row_mirror
+    v += __shfl_xor(v, 16, 64);
+    return v;
+}
+
 __device__ __forceinline__ unsigned g_hash32(unsigned x) {
     x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
     return x;
@@ -49,13 +59,13 @@ __device__ __forceinline__ uint4 conv_a_load(const GemmArgs& a, const ConvRow& r
 }
 
 template <int BM, int BN, bool CONV = false>
-__global__ __launch_bounds__(G_THREADS, (BM == 128 ? 3 : 4)) void gemm_bf16_nt_kernel(GemmArgs a) {
+__global__ __launch_bounds__(G_THREADS, (BN == 256 ? 2 : (BM == 128 ? 3 : 4))) void gemm_bf16_nt_kernel(GemmArgs a) {
     static_assert(BM == 64 || BM == 96 || BM == 128, "row tiles of 64, 96 or 128");
     constexpr int WM = BM / 2, WN = BN / 2, TI = WM / 16, TJ = WN / 16;
     constexpr int A_BYTES = BM * G_ROWB;
     constexpr int AV = BM * 8 / G_THREADS, BV = BN * 8 / G_THREADS;  // 16-byte vectors per thread per stage
     constexpr int LDC = BN + 4;                                        // fp32 epilogue row stride (floats)
-    constexpr int EP_ROWS = (BM == 96) ? 48 : 64;                      // tile rows per epilogue pass through LDS
+    constexpr int EP_ROWS = (BN == 256) ? 32 : ((BM == 96) ? 48 : 64); // tile rows per epilogue pass through LDS
     static_assert(BM % EP_ROWS == 0 && (EP_ROWS % WM == 0 || WM % EP_ROWS == 0), "epilogue passes cover whole wave rows");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -70,7 +80,7 @@ __global__ __launch_bounds__(G_THREADS, (BM == 128 ? 3 : 4)) void gemm_bf16_nt_k
     if (mt * BM >= a.M) return;  // padding workgroups of the last group of 8 row tiles (uniform)
     const int m0 = mt * BM, n0 = (slot % ntn) * BN;
 
-    static_assert(BV == 4 && (AV == 2 || AV == 3 || AV == 4), "staging registers are named (arrays end up in scratch)");
+    static_assert((BV == 4 || BV == 8) && (AV == 2 || AV == 3 || AV == 4), "staging registers are named (arrays end up in scratch)");
     ConvRow crow[4];
     if constexpr (CONV) {
 #pragma unroll
@@ -81,6 +91,7 @@ __global__ __launch_bounds__(G_THREADS, (BM == 128 ? 3 : 4)) void gemm_bf16_nt_k
         }
     }
     uint4 ra0, ra1, ra2 = make_uint4(0, 0, 0, 0), ra3 = make_uint4(0, 0, 0, 0), rb0, rb1, rb2, rb3;
+    uint4 rb4 = make_uint4(0, 0, 0, 0), rb5 = rb4, rb6 = rb4, rb7 = rb4;   // BN = 256
     // 16-byte vector at column k_ of a K-contiguous row; columns >= K read as zero (K % 8 == 0: d_model = 144 -> K = 144 is two
     // 64-wide k-tiles and a 16-wide tail).  The address is clamped, the select applied to the value: no branch around the load.
 #define G_LDK(rowp_, k_) ([&]() { const int kk_ = (k_); const uint4 v_ = *reinterpret_cast<const uint4*>((rowp_) + (kk_ < a.K ? kk_ : 0)); \
@@ -99,6 +110,12 @@ __global__ __launch_bounds__(G_THREADS, (BM == 128 ? 3 : 4)) void gemm_bf16_nt_k
         { const int idx_ = tid + 1 * G_THREADS, row_ = idx_ >> 3, kv_ = idx_ & 7; const int gr_ = (n0 + row_ < a.N) ? (n0 + row_) : (a.N - 1); rb1 = G_LDK(a.W + (size_t)gr_ * a.ldw, (k0_) + kv_ * 8); } \
         { const int idx_ = tid + 2 * G_THREADS, row_ = idx_ >> 3, kv_ = idx_ & 7; const int gr_ = (n0 + row_ < a.N) ? (n0 + row_) : (a.N - 1); rb2 = G_LDK(a.W + (size_t)gr_ * a.ldw, (k0_) + kv_ * 8); } \
         { const int idx_ = tid + 3 * G_THREADS, row_ = idx_ >> 3, kv_ = idx_ & 7; const int gr_ = (n0 + row_ < a.N) ? (n0 + row_) : (a.N - 1); rb3 = G_LDK(a.W + (size_t)gr_ * a.ldw, (k0_) + kv_ * 8); } \
+        if constexpr (BV == 8) { \
+        { const int idx_ = tid + 4 * G_THREADS, row_ = idx_ >> 3, kv_ = idx_ & 7; const int gr_ = (n0 + row_ < a.N) ? (n0 + row_) : (a.N - 1); rb4 = G_LDK(a.W + (size_t)gr_ * a.ldw, (k0_) + kv_ * 8); } \
+        { const int idx_ = tid + 5 * G_THREADS, row_ = idx_ >> 3, kv_ = idx_ & 7; const int gr_ = (n0 + row_ < a.N) ? (n0 + row_) : (a.N - 1); rb5 = G_LDK(a.W + (size_t)gr_ * a.ldw, (k0_) + kv_ * 8); } \
+        { const int idx_ = tid + 6 * G_THREADS, row_ = idx_ >> 3, kv_ = idx_ & 7; const int gr_ = (n0 + row_ < a.N) ? (n0 + row_) : (a.N - 1); rb6 = G_LDK(a.W + (size_t)gr_ * a.ldw, (k0_) + kv_ * 8); } \
+        { const int idx_ = tid + 7 * G_THREADS, row_ = idx_ >> 3, kv_ = idx_ & 7; const int gr_ = (n0 + row_ < a.N) ? (n0 + row_) : (a.N - 1); rb7 = G_LDK(a.W + (size_t)gr_ * a.ldw, (k0_) + kv_ * 8); } \
+        } \
     } while (0)
 #define G_STORE(buf_) \
     do { \
@@ -116,6 +133,12 @@ __global__ __launch_bounds__(G_THREADS, (BM == 128 ? 3 : 4)) void gemm_bf16_nt_k
         { const int idx_ = tid + 1 * G_THREADS; *reinterpret_cast<uint4*>(sb_ + (idx_ >> 3) * G_ROWB + (idx_ & 7) * 16) = rb1; } \
         { const int idx_ = tid + 2 * G_THREADS; *reinterpret_cast<uint4*>(sb_ + (idx_ >> 3) * G_ROWB + (idx_ & 7) * 16) = rb2; } \
         { const int idx_ = tid + 3 * G_THREADS; *reinterpret_cast<uint4*>(sb_ + (idx_ >> 3) * G_ROWB + (idx_ & 7) * 16) = rb3; } \
+        if constexpr (BV == 8) { \
+        { const int idx_ = tid + 4 * G_THREADS; *reinterpret_cast<uint4*>(sb_ + (idx_ >> 3) * G_ROWB + (idx_ & 7) * 16) = rb4; } \
+        { const int idx_ = tid + 5 * G_THREADS; *reinterpret_cast<uint4*>(sb_ + (idx_ >> 3) * G_ROWB + (idx_ & 7) * 16) = rb5; } \
+        { const int idx_ = tid + 6 * G_THREADS; *reinterpret_cast<uint4*>(sb_ + (idx_ >> 3) * G_ROWB + (idx_ & 7) * 16) = rb6; } \
+        { const int idx_ = tid + 7 * G_THREADS; *reinterpret_cast<uint4*>(sb_ + (idx_ >> 3) * G_ROWB + (idx_ & 7) * 16) = rb7; } \
+        } \
     } while (0)
     // (rows past M / N are clamped to the last valid row: their products land in output rows/columns that the
     //  epilogue never stores)
@@ -203,13 +226,35 @@ __global__ __launch_bounds__(G_THREADS, (BM == 128 ? 3 : 4)) void gemm_bf16_nt_k
         const float4 x1 = *reinterpret_cast<const float4*>(sc + row * LDC + cv * 8 + 4);
         v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
         gemm_epilogue8(a, gm, gn, v);
+        if constexpr (BN == 256) {
+            // LayerNorm of the finished row: its 256 columns are the 32 lanes of this half wave (8 columns each; rows beyond M
+            // skip the whole half wave above), two DPP / shuffle reductions, bf16 store of the normalised row
+            if (a.ln_g) {
+                float s1 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s1 += v[j];
+                const float mean = gemm_half_wave_sum(s1) * (1.f / 256.f);
+                float s2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { v[j] -= mean; s2 += v[j] * v[j]; }
+                const float rstd = rsqrtf(gemm_half_wave_sum(s2) * (1.f / 256.f) + a.ln_eps);
+                const float4 g0 = *reinterpret_cast<const float4*>(a.ln_g + gn), g1 = *reinterpret_cast<const float4*>(a.ln_g + gn + 4);
+                const float4 c0 = *reinterpret_cast<const float4*>(a.ln_b + gn), c1 = *reinterpret_cast<const float4*>(a.ln_b + gn + 4);
+                const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+                const float bb[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+                union { uint4 u; __bf16 h[8]; } o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o.h[j] = (__bf16)(v[j] * rstd * gg[j] + bb[j]);
+                *reinterpret_cast<uint4*>(a.outH + (size_t)gm * a.ldoh + gn) = o.u;
+            }
+        }
     }
     }
 }
 
 template <int BM, int BN, bool CONV = false>
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
-    constexpr int STAGE = (BM + BN) * G_ROWB, EPI = (BM == 96 ? 48 : 64) * (BN + 4) * 4;
+    constexpr int STAGE = (BM + BN) * G_ROWB, EPI = (BN == 256 ? 32 : (BM == 96 ? 48 : 64)) * (BN + 4) * 4;
     const size_t lds = STAGE > EPI ? STAGE : EPI;
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
     const int grid = 8 * ((ntm + 7) / 8) * ntn;  // row tiles padded to a multiple of the 8 XCDs (see the kernel's tile order)
@@ -262,6 +307,7 @@ extern "C" int ia_gemm_bf16_ex2(const void* A, int lda, const void* W, int ldw, 
     a.thr = (unsigned)(dropout_p * 256.f + 0.5f);
     a.keep_scale = a.thr > 0 ? 256.f / (256.f - (float)a.thr) : 1.f;
     a.cT1 = a.cF1 = a.cC = a.cT2 = a.cF2 = 0;
+    a.ln_g = a.ln_b = nullptr; a.ln_eps = 0.f;
     hipStream_t st = (hipStream_t)stream;
     // Row-tile choice (128, 96 or 64 rows x 128 columns).  The result does not depend on it: every output element sums its
     // k-steps in the same order.  In isolation the tile sizes are within ~10 % of each other at the encoder's shapes
@@ -283,6 +329,34 @@ extern "C" int ia_gemm_bf16_ex2(const void* A, int lda, const void* W, int ldw, 
     if (best == 128) return launch_gemm<128, 128>(a, st);
     if (best == 96) return launch_gemm<96, 128>(a, st);
     return launch_gemm<64, 128>(a, st);
+}
+
+// Projection into the residual stream + LayerNorm of the updated rows in ONE launch (d_model = 256):
+//   x = R + alpha * dropout(A @ W^T + bias)  -> outF (may alias R),   LN(x) * ln_g + ln_b -> outH (bf16)
+// -- the out-projection of the attention followed by the convolution module's LayerNorm (conformer_modules.py:171-186), or any
+// other N = 256 projection in front of a LayerNorm.  64 x 256 tiles: a workgroup owns whole rows, the row statistics are two
+// half-wave reductions in the epilogue; saves the LayerNorm launch and its 12 MB read of the rows just written.
+extern "C" int ia_gemm_bf16_ln_supported(int N, int K) { return (N == 256 && K % 8 == 0 && K >= 8) ? 1 : 0; }
+
+extern "C" int ia_gemm_bf16_ln(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const float* bias, float dropout_p,
+                               unsigned seed, float alpha, const float* R, int ldr, float* outF, int ldof, const float* ln_g,
+                               const float* ln_b, float ln_eps, void* outH, int ldoh, ia_stream_t stream) {
+    if (!A || !W || !outF || !outH || !ln_g || !ln_b || M <= 0) return IA_INVALID_VALUE;
+    if (!ia_gemm_bf16_ln_supported(N, K) || lda % 8 != 0 || ldw % 8 != 0 || (R && ldr % 4 != 0) || ldof % 4 != 0 || ldoh % 8 != 0) return IA_UNSUPPORTED;
+    if (!ia_is_aligned(A, 16) || !ia_is_aligned(W, 16) || (bias && !ia_is_aligned(bias, 16)) || (R && !ia_is_aligned(R, 16)) ||
+        !ia_is_aligned(outF, 16) || !ia_is_aligned(outH, 16) || !ia_is_aligned(ln_g, 16) || !ia_is_aligned(ln_b, 16) ||
+        dropout_p < 0.f || dropout_p >= 1.f)
+        return IA_INVALID_VALUE;
+    GemmArgs a;
+    a.A = (const __bf16*)A; a.W = (const __bf16*)W; a.bias = bias; a.R = R; a.outF = outF; a.outH = (__bf16*)outH;
+    a.outPre = nullptr; a.aux = nullptr; a.ldpre = 0; a.ldaux = 0;
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldr = ldr; a.ldof = ldof; a.ldoh = ldoh;
+    a.act = 0; a.alpha = alpha; a.seed = seed; a.out_f16 = 0;
+    a.thr = (unsigned)(dropout_p * 256.f + 0.5f);
+    a.keep_scale = a.thr > 0 ? 256.f / (256.f - (float)a.thr) : 1.f;
+    a.cT1 = a.cF1 = a.cC = a.cT2 = a.cF2 = 0;
+    a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = ln_eps;
+    return launch_gemm<64, 256>(a, (hipStream_t)stream);
 }
 
 // ---- ConvSubsampling ('striding', x4): A/parts/submodules/subsampling.py:217-253,385-437 --------------------------
@@ -369,5 +443,6 @@ extern "C" int ia_subsample_conv2(const void* in_cl, int B, int T1, int F1, int 
     a.cT1 = T1; a.cF1 = F1; a.cC = C; a.cT2 = (T1 - 1) / 2 + 1; a.cF2 = (F1 - 1) / 2 + 1;
     a.M = B * a.cT2 * a.cF2; a.N = N; a.K = 9 * C; a.lda = 0; a.ldw = 9 * C; a.ldr = 0; a.ldof = 0; a.ldoh = N;
     a.act = 2; a.alpha = 1.f; a.seed = 0; a.thr = 0; a.keep_scale = 1.f; a.out_f16 = 0;
+    a.ln_g = a.ln_b = nullptr; a.ln_eps = 0.f;
     return launch_gemm<128, 128, true>(a, (hipStream_t)stream);
 }
