@@ -50,6 +50,36 @@ __device__ __forceinline__ bf8 tn_join(bf4 lo, bf4 hi) {
     return o;
 }
 
+// XCD-aware workgroup order shared by both kernels.  All output tiles of one split read the same rows of dY and X (an
+// [rps x (n + k)] slice, streamed 64 rows at a time in lock step); workgroup ids go round-robin over the 8 XCDs, so the ids
+// of a split's tiles are made CONGRUENT mod 8: they run on one XCD (S >= 8; for S = 1, 2, 4 on 8 / S XCDs that share the
+// tiles), next to each other in its dispatch order, and the slice comes into that L2 once.  The split counts are rounded to
+// {1, 2, 4} or multiples of 8 by the planners, so every XCD gets the same number of splits.  local = id - first id of the
+// problem (a multiple of 8); returns false for padding ids.
+__device__ __forceinline__ bool tn_map(int local, int tiles, int S, int* tile, int* split) {
+    const int xcd = local & 7, slot = local >> 3;
+    if (S >= 8) {
+        *split = (slot / tiles) * 8 + xcd; *tile = slot % tiles;
+        return *split < S;
+    }
+    const int G = 8 / S;                    // XCDs per split
+    *split = xcd % S; *tile = slot * G + xcd / S;
+    return *tile < tiles;
+}
+inline int tn_round_splits(int s) { return s >= 8 ? s / 8 * 8 : (s >= 4 ? 4 : (s >= 2 ? 2 : 1)); }
+// rows per split (a multiple of the 64-row step) and the resulting split count, kept in {1, 2, 4} or >= 8 (see tn_map)
+inline int tn_plan_splits(int M, int wanted, int* rps_out) {
+    int S = tn_round_splits(wanted < 1 ? 1 : wanted);
+    for (;;) {
+        int rps = (M + S - 1) / S;
+        rps = (rps + TN_MS - 1) / TN_MS * TN_MS;
+        const int Seff = (M + rps - 1) / rps;
+        if (Seff >= 8 || Seff == tn_round_splits(Seff)) { *rps_out = rps; return Seff; }
+        S = tn_round_splits(Seff);
+    }
+}
+inline int tn_wgs(int tiles, int S) { return S >= 8 ? 8 * ((S + 7) / 8) * tiles : 8 * ((tiles + 8 / S - 1) / (8 / S)); }
+
 // one [128 x 128] output tile of one split: the body shared by the single-problem and the grouped kernel
 __device__ __forceinline__ void tn_tile_body(const __bf16* __restrict__ dY, int ldy, const __bf16* __restrict__ X, int ldx, int M,
                                              int n, int k, int rows_per_split, float* __restrict__ part,
@@ -162,7 +192,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const __bf16* __restric
                                                          float* __restrict__ part, float* __restrict__ part_b,
                                                          size_t row_stride) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TN_TILE];  // dY tile | X tile
-    tn_tile_body(dY, ldy, X, ldx, M, n, k, rows_per_split, part, part_b, row_stride, blockIdx.x, blockIdx.y, smem);
+    const int tiles = ((n + TN_BN - 1) / TN_BN) * ((k + TN_BK - 1) / TN_BK);
+    const int S = (M + rows_per_split - 1) / rows_per_split;
+    int tile, split;
+    if (!tn_map((int)blockIdx.x, tiles, S, &tile, &split)) return;
+    tn_tile_body(dY, ldy, X, ldx, M, n, k, rows_per_split, part, part_b, row_stride, tile, split, smem);
 }
 
 // Several weight gradients in ONE launch (a trainable block's five / four projections): the single-problem launches are
@@ -182,8 +216,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(TnGroup g) {
         if (i < g.count && (int)blockIdx.x >= g.p[i].wg_begin) pi = i;
     pi = __builtin_amdgcn_readfirstlane(pi);
     const TnProblem& P = g.p[pi];
-    const int local = blockIdx.x - P.wg_begin;
-    tn_tile_body(P.dY, P.ldy, P.X, P.ldx, P.M, P.n, P.k, P.rps, P.part, P.part_b, P.row_stride, local % P.tiles, local / P.tiles, smem);
+    int tile, split;
+    if (!tn_map((int)blockIdx.x - P.wg_begin, P.tiles, P.S, &tile, &split)) return;
+    tn_tile_body(P.dY, P.ldy, P.X, P.ldx, P.M, P.n, P.k, P.rps, P.part, P.part_b, P.row_stride, tile, split, smem);
 }
 
 // out[e] = sum over the problem's splits of its partial rows, for every problem of the group: element e of the
@@ -228,16 +263,14 @@ extern "C" int ia_gemm_tn_bf16(const void* dY, int ldy, const void* X, int ldx, 
                                float* scratch, ia_stream_t stream) {
     if (!dY || !X || !dW || !scratch || M <= 0 || n <= 0 || k <= 0) return IA_INVALID_VALUE;
     if (n % 8 != 0 || k % 8 != 0 || ldy % 8 != 0 || ldx % 8 != 0 || !ia_is_aligned(dY, 16) || !ia_is_aligned(X, 16)) return IA_UNSUPPORTED;
-    const int S = tn_splits(M, n, k);
-    int rps = (M + S - 1) / S;
-    rps = (rps + TN_MS - 1) / TN_MS * TN_MS;
-    const int Seff = (M + rps - 1) / rps;
+    int rps;
+    const int Seff = tn_plan_splits(M, tn_splits(M, n, k), &rps);
     // partial row of one split = [n*k tile values | n bias sums]: when db directly follows dW in memory one pass finishes both
     const size_t row_stride = (size_t)n * k + n;
     float* part = scratch;
     float* part_b = db ? scratch + (size_t)n * k : nullptr;
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid(((n + TN_BN - 1) / TN_BN) * ((k + TN_BK - 1) / TN_BK), Seff), blk(256);
+    const dim3 grid(tn_wgs(((n + TN_BN - 1) / TN_BN) * ((k + TN_BK - 1) / TN_BK), Seff)), blk(256);
     hipLaunchKernelGGL(gemm_tn_kernel, grid, blk, 0, st, (const __bf16*)dY, ldy, (const __bf16*)X, ldx, M, n, k, rps, part, part_b,
                        row_stride);
     IA_RETURN_IF_LAUNCH_FAILED();
@@ -276,16 +309,14 @@ inline int tn_group_plan(const ia_tn_problem* pr, int count, TnGroup* g, int64_t
         const ia_tn_problem& q = pr[i];
         TnProblem& P = g->p[i];
         const int cap = (q.M + TN_MS - 1) / TN_MS;
-        int S = S0 > cap ? cap : S0;
-        int rps = (q.M + S - 1) / S;
-        rps = (rps + TN_MS - 1) / TN_MS * TN_MS;
-        S = (q.M + rps - 1) / rps;
+        int rps;
+        const int S = tn_plan_splits(q.M, S0 > cap ? cap : S0, &rps);
         P.dY = (const __bf16*)q.dY; P.X = (const __bf16*)q.X; P.ldy = q.ldy; P.ldx = q.ldx; P.M = q.M; P.n = q.n; P.k = q.k;
         P.rps = rps; P.S = S; P.tiles = ((q.n + TN_BN - 1) / TN_BN) * ((q.k + TN_BK - 1) / TN_BK);
         P.row_stride = (size_t)q.n * q.k + q.n;
         P.part = nullptr; P.part_b = nullptr;                // filled by the caller from `so`
         P.dW = q.dW; P.db = q.db;
-        P.wg_begin = wg; wg += P.tiles * S;
+        P.wg_begin = wg; wg += tn_wgs(P.tiles, S);   // a multiple of 8: see tn_map
         P.out_begin = oo; oo += (int64_t)P.row_stride;
         P.part = reinterpret_cast<float*>(so * sizeof(float));   // offset for now
         so += (int64_t)S * (int64_t)P.row_stride;
