@@ -109,6 +109,80 @@ __device__ __forceinline__ void tn_tile_body(const __bf16* __restrict__ dY, int 
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.f;
 
+    // One k-step pair of a staged 64-row step out of the stage at LDS address lY (dY tile) / lX (X tile): all 16 transposed
+    // reads of a k-step in flight, ONE wait that the fragment registers are tied to (the compiler does not know that the asm
+    // reads LDS asynchronously: without the tie it may consume them early)
+    auto multiply_stage = [&](unsigned lY, unsigned lX) {
+#pragma unroll
+        for (int ks = 0; ks < TN_MS / 32; ++ks) {
+            bf4 alo[4], ahi[4], blo[4], bhi[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                unsigned a0, a1;
+                tn_frag_addr(lY, ks * 32 + q4 * 8, wn * 64 + i * 16, lane, &a0, &a1);
+                alo[i] = tn_tr_read(a0); ahi[i] = tn_tr_read(a1);
+                tn_frag_addr(lX, ks * 32 + q4 * 8, wk * 64 + i * 16, lane, &a0, &a1);
+                blo[i] = tn_tr_read(a0); bhi[i] = tn_tr_read(a1);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(alo[0]), "+v"(alo[1]), "+v"(alo[2]), "+v"(alo[3]), "+v"(ahi[0]), "+v"(ahi[1]), "+v"(ahi[2]),
+                           "+v"(ahi[3]), "+v"(blo[0]), "+v"(blo[1]), "+v"(blo[2]), "+v"(blo[3]), "+v"(bhi[0]), "+v"(bhi[1]),
+                           "+v"(bhi[2]), "+v"(bhi[3])
+                         :
+                         : "memory");
+            bf8 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { af[i] = tn_join(alo[i], ahi[i]); bfr[i] = tn_join(blo[i], bhi[i]); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                if (do_bias) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, accb[i], 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- interior tiles over whole 64-row steps (every projection of the encoder): the two operand tiles go global -> LDS
+    // directly (global_load_lds_dwordx4: no staging registers, no ds_write, no branch per vector), two stages, ONE barrier per
+    // step, the next step in flight under the current one's MFMAs.  One instruction fills 1 KB = 4 tile rows x 16 chunks with
+    // lane l at position l, so the XOR swizzle of tn_off is applied on the source side: lane l of block blk fetches, for row
+    // 4 blk + (l >> 4), the logical chunk (l & 15) ^ (((l >> 4) << 2) | (blk & 3)).  Wave w issues blocks 4 w .. 4 w + 3 of both tiles.
+    const bool dma_path = n0 + TN_BN <= n && k0 + TN_BK <= k && (m_end - m_beg) % TN_MS == 0 && m_end > m_beg;
+    if (dma_path) {
+        const unsigned char* gy = reinterpret_cast<const unsigned char*>(dY + (size_t)m_beg * ldy + n0);
+        const unsigned char* gx = reinterpret_cast<const unsigned char*>(X + (size_t)m_beg * ldx + k0);
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        unsigned oy[4], ox[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 4 * (wv * 4 + i) + (lane >> 4);
+            const unsigned ch = (unsigned)((lane & 15) ^ (((lane >> 4) << 2) | i));
+            oy[i] = (unsigned)row * (unsigned)(ldy * 2) + ch * 16u;
+            ox[i] = (unsigned)row * (unsigned)(ldx * 2) + ch * 16u;
+        }
+        auto issue = [&](int st, int buf) {
+            const unsigned char* py = gy + (size_t)st * TN_MS * ldy * 2;
+            const unsigned char* px = gx + (size_t)st * TN_MS * ldx * 2;
+            unsigned char* dy_ = smem + buf * 2 * TN_TILE + wv * 4096;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(py + oy[i]),
+                                                 (__attribute__((address_space(3))) void*)(dy_ + i * 1024), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(px + ox[i]),
+                                                 (__attribute__((address_space(3))) void*)(dy_ + TN_TILE + i * 1024), 16, 0, 0);
+        };
+        const int nst = (m_end - m_beg) / TN_MS;
+        issue(0, 0);
+        for (int st = 0; st < nst; ++st) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of step st has landed ...
+            __builtin_amdgcn_s_barrier();                      // ... everybody's has, and nobody reads the other stage any more
+            if (st + 1 < nst) issue(st + 1, (st + 1) & 1);
+            const unsigned base = ldsY + (unsigned)((st & 1) * 2 * TN_TILE);
+            multiply_stage(base, base + TN_TILE);
+        }
+    } else {
     // loader: 64 rows x 16 chunks per tile = 1024 chunks -> 4 per thread per tile
     uint4 ry[4], rx[4];
 #define TN_LOAD(m0_)                                                                                               \
@@ -137,36 +211,9 @@ __device__ __forceinline__ void tn_tile_body(const __bf16* __restrict__ dY, int 
         TN_STORE();
         __syncthreads();
         if (m0 + TN_MS < m_end) TN_LOAD(m0 + TN_MS);
-#pragma unroll
-        for (int ks = 0; ks < TN_MS / 32; ++ks) {
-            // all 16 transposed reads of the k-step in flight, ONE wait that the fragment registers are tied to (the
-            // compiler does not know the asm reads LDS asynchronously: without the tie it may consume them early)
-            bf4 alo[4], ahi[4], blo[4], bhi[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                unsigned a0, a1;
-                tn_frag_addr(ldsY, ks * 32 + q4 * 8, wn * 64 + i * 16, lane, &a0, &a1);
-                alo[i] = tn_tr_read(a0); ahi[i] = tn_tr_read(a1);
-                tn_frag_addr(ldsX, ks * 32 + q4 * 8, wk * 64 + i * 16, lane, &a0, &a1);
-                blo[i] = tn_tr_read(a0); bhi[i] = tn_tr_read(a1);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(alo[0]), "+v"(alo[1]), "+v"(alo[2]), "+v"(alo[3]), "+v"(ahi[0]), "+v"(ahi[1]), "+v"(ahi[2]),
-                           "+v"(ahi[3]), "+v"(blo[0]), "+v"(blo[1]), "+v"(blo[2]), "+v"(blo[3]), "+v"(bhi[0]), "+v"(bhi[1]),
-                           "+v"(bhi[2]), "+v"(bhi[3])
-                         :
-                         : "memory");
-            bf8 af[4], bfr[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { af[i] = tn_join(alo[i], ahi[i]); bfr[i] = tn_join(blo[i], bhi[i]); }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-                if (do_bias) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, accb[i], 0, 0, 0);
-            }
-        }
+        multiply_stage(ldsY, ldsX);
     }
+    }   // register path
 #undef TN_LOAD
 #undef TN_STORE
     // partial tile: C layout lane = (col = k index c, rows = n index 4*q4 + r)
@@ -191,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const __bf16* __restric
                                                          int ldx, int M, int n, int k, int rows_per_split,
                                                          float* __restrict__ part, float* __restrict__ part_b,
                                                          size_t row_stride) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TN_TILE];  // dY tile | X tile
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TN_TILE];  // 2 stages x [dY tile | X tile]
     const int tiles = ((n + TN_BN - 1) / TN_BN) * ((k + TN_BK - 1) / TN_BK);
     const int S = (M + rows_per_split - 1) / rows_per_split;
     int tile, split;
@@ -209,7 +256,7 @@ struct TnProblem {
 struct TnGroup { TnProblem p[TN_MAX_GROUP]; int count; };
 
 __global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(TnGroup g) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TN_TILE];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TN_TILE];
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < TN_MAX_GROUP; ++i)
