@@ -29,6 +29,8 @@ WORK = [
                           "paced by 1 MB of weights per workgroup through LDS")),
     ("gemm_bf16_nt_kernel<128, 128, true>", ("subsampling conv2 as implicit GEMM", "mfma", 2.0 * (B * 376 * 20) * 256 * 2304, "flop", "")),
     ("gemm_bf16_nt_kernel<96, 128", ("subsampling Linear [N x 5120] x [256 x 5120]", "mfma", 2.0 * N * 256 * 5120, "flop", "")),
+    ("gemm_bf16_nt_kernel<64, 256", ("attention out-projection + residual + LayerNorm of the convolution module in one launch", "hbm",
+                                     2.0 * N * d + 4.0 * N * d + 4.0 * N * d + 2.0 * N * d, "byte", "1.6 GFLOP; latency-bound at this size")),
     ("gemm_bf16_nt_kernel<64, 128", ("projections of the blocks / heads (K = 256 .. 1024, mixed shapes)", "mfma", 361e9 / 95.0, "flop",
                                      "average over the step's ~95 launches (361 GFLOP per step)")),
     ("relpos_flash_fwd_kernel", ("rel-pos attention forward, key-tiled", "mfma", 7.0e9, "flop", "latency / VALU (exp, band strip) at T' = 376")),
