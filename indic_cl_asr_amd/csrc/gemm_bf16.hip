@@ -58,13 +58,98 @@ __device__ __forceinline__ uint4 conv_a_load(const GemmArgs& a, const ConvRow& r
     return *reinterpret_cast<const uint4*>(a.A + (((size_t)r.b * a.cT1 + t1) * a.cF1 + f1) * a.cC + c0);
 }
 
+// The tile epilogue shared by the projection kernels of this file: accumulators -> LDS (fp32, row-major, EP_ROWS tile rows per
+// pass) -> row-major elementwise pass with 16-byte accesses (GLU / LayerNorm variants included).  Called by ALL threads of the
+// workgroup once the stages in `smem` are free; acc = the 2 x 2 waves' [TI][TJ] 16x16 accumulator tiles.
+template <int BM, int BN>
+__device__ __forceinline__ void gemm_tile_epilogue(const GemmArgs& a, f4 (&acc)[BM / 32][BN / 32], unsigned char* smem, int m0, int n0) {
+    constexpr int WM = BM / 2, WN = BN / 2, TI = WM / 16, TJ = WN / 16;
+    constexpr int LDC = BN + 4;
+    constexpr int EP_ROWS = (BN == 256) ? 32 : ((BM == 96) ? 48 : 64);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    // ---- epilogue: accumulators -> LDS (fp32, row-major, EP_ROWS tile rows per pass) -> row-major elementwise pass with
+    // 16-byte accesses.  One LDS stage + a 64-row epilogue tile keep the workgroup at 37 KB: four workgroups per CU.
+    float* sc = reinterpret_cast<float*>(smem);
+    constexpr int VEC_PER_ROW = BN / 8;
+    for (int pass = 0; pass < BM / EP_ROWS; ++pass) {
+    if (pass > 0) __syncthreads();
+    if ((wm * WM) / EP_ROWS == pass) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    sc[(wm * WM - pass * EP_ROWS + i * 16 + q * 4 + r) * LDC + wn * WN + j * 16 + c] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (a.act == 4) {
+        // GLU over the tile's column halves (weight rows regrouped by the caller: columns [0,64) of a 128-column tile are value
+        // channels, [64,128) their gates): out[gm][n0/2 + c] = (v + b) * sigmoid(g + b'), bf16, N/2 columns wide.  Thread = 4
+        // channels of one row: float4 reads of both halves, one 8-byte store, every thread busy.
+        if constexpr (BN == 128) {
+            for (int it = tid; it < EP_ROWS * 16; it += G_THREADS) {
+                const int row = it >> 4, cg = it & 15;
+                const int gm = m0 + pass * EP_ROWS + row, gc = n0 + cg * 4;
+                if (gm >= a.M) continue;
+                float4 vv = *reinterpret_cast<const float4*>(sc + row * LDC + cg * 4);
+                float4 gg = *reinterpret_cast<const float4*>(sc + row * LDC + 64 + cg * 4);
+                if (a.bias) {
+                    const float4 bv = *reinterpret_cast<const float4*>(a.bias + gc), bg = *reinterpret_cast<const float4*>(a.bias + gc + 64);
+                    vv.x += bv.x; vv.y += bv.y; vv.z += bv.z; vv.w += bv.w;
+                    gg.x += bg.x; gg.y += bg.y; gg.z += bg.z; gg.w += bg.w;
+                }
+                union { uint2 u; __bf16 h[4]; } o;
+                o.h[0] = (__bf16)(vv.x * ia_sigmoid_fast(gg.x)); o.h[1] = (__bf16)(vv.y * ia_sigmoid_fast(gg.y));
+                o.h[2] = (__bf16)(vv.z * ia_sigmoid_fast(gg.z)); o.h[3] = (__bf16)(vv.w * ia_sigmoid_fast(gg.w));
+                *reinterpret_cast<uint2*>(a.outH + (size_t)gm * a.ldoh + (n0 >> 1) + cg * 4) = o.u;
+            }
+        }
+        continue;   // next epilogue pass
+    }
+    for (int it = tid; it < EP_ROWS * VEC_PER_ROW; it += G_THREADS) {
+        const int row = it / VEC_PER_ROW, cv = it - row * VEC_PER_ROW;
+        const int gm = m0 + pass * EP_ROWS + row, gn = n0 + cv * 8;
+        if (gm >= a.M || gn >= a.N) continue;
+        float v[8];
+        const float4 x0 = *reinterpret_cast<const float4*>(sc + row * LDC + cv * 8);
+        const float4 x1 = *reinterpret_cast<const float4*>(sc + row * LDC + cv * 8 + 4);
+        v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+        gemm_epilogue8(a, gm, gn, v);
+        if constexpr (BN == 256) {
+            // LayerNorm of the finished row: its 256 columns are the 32 lanes of this half wave (8 columns each; rows beyond M
+            // skip the whole half wave above), two DPP / shuffle reductions, bf16 store of the normalised row
+            if (a.ln_g) {
+                float s1 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s1 += v[j];
+                const float mean = gemm_half_wave_sum(s1) * (1.f / 256.f);
+                float s2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { v[j] -= mean; s2 += v[j] * v[j]; }
+                const float rstd = rsqrtf(gemm_half_wave_sum(s2) * (1.f / 256.f) + a.ln_eps);
+                const float4 g0 = *reinterpret_cast<const float4*>(a.ln_g + gn), g1 = *reinterpret_cast<const float4*>(a.ln_g + gn + 4);
+                const float4 c0 = *reinterpret_cast<const float4*>(a.ln_b + gn), c1 = *reinterpret_cast<const float4*>(a.ln_b + gn + 4);
+                const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+                const float bb[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+                union { uint4 u; __bf16 h[8]; } o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o.h[j] = (__bf16)(v[j] * rstd * gg[j] + bb[j]);
+                *reinterpret_cast<uint4*>(a.outH + (size_t)gm * a.ldoh + gn) = o.u;
+            }
+        }
+    }
+    }
+}
+
 template <int BM, int BN, bool CONV = false>
 __global__ __launch_bounds__(G_THREADS, (BN == 256 ? 2 : (BM == 128 ? 3 : 4))) void gemm_bf16_nt_kernel(GemmArgs a) {
     static_assert(BM == 64 || BM == 96 || BM == 128, "row tiles of 64, 96 or 128");
     constexpr int WM = BM / 2, WN = BN / 2, TI = WM / 16, TJ = WN / 16;
     constexpr int A_BYTES = BM * G_ROWB;
     constexpr int AV = BM * 8 / G_THREADS, BV = BN * 8 / G_THREADS;  // 16-byte vectors per thread per stage
-    constexpr int LDC = BN + 4;                                        // fp32 epilogue row stride (floats)
     constexpr int EP_ROWS = (BN == 256) ? 32 : ((BM == 96) ? 48 : 64); // tile rows per epilogue pass through LDS
     static_assert(BM % EP_ROWS == 0 && (EP_ROWS % WM == 0 || WM % EP_ROWS == 0), "epilogue passes cover whole wave rows");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -177,79 +262,105 @@ __global__ __launch_bounds__(G_THREADS, (BN == 256 ? 2 : (BM == 128 ? 3 : 4))) v
         }
     }
 
-    // ---- epilogue: accumulators -> LDS (fp32, row-major, EP_ROWS tile rows per pass) -> row-major elementwise pass with
-    // 16-byte accesses.  One LDS stage + a 64-row epilogue tile keep the workgroup at 37 KB: four workgroups per CU.
-    float* sc = reinterpret_cast<float*>(smem);
-    constexpr int VEC_PER_ROW = BN / 8;
-    for (int pass = 0; pass < BM / EP_ROWS; ++pass) {
-    if (pass > 0) __syncthreads();
-    if ((wm * WM) / EP_ROWS == pass) {
+    gemm_tile_epilogue<BM, BN>(a, acc, smem, m0, n0);
+}
+
+// K-pipelined variant for the long-K projections (K >= 512: feed-forward W2 forward, the data gradients through W1 / QKV /
+// pointwise_conv1).  With N = 256 outputs these launches have 384 workgroups of 16 k-steps each, and a k-step's MFMAs take
+// 0.1 us while its operands take ~0.9 us to arrive: the register-staged kernel above, one step ahead, is a chain of 16 load
+// latencies per workgroup (22 us for 3.2 GFLOP).  Here the operand tiles go global -> LDS directly (global_load_lds_dwordx4,
+// swizzle on the source side) into a ring of THREE stages, two of them always in flight, one barrier per k-step, counted
+// vmcnt waits; fragment reads are inline asm (a compiler-visible LDS read while LDS-DMA is in flight draws vmcnt(0)).
+// Same tile shape, same MFMA order per output element and the same epilogue as gemm_bf16_nt_kernel<64, 128>: bit-identical.
+constexpr int GD_STAGES = 3;
+template <int BM, int BN>
+__global__ __launch_bounds__(G_THREADS, 2) void gemm_bf16_nt_dma_kernel(GemmArgs a) {
+    static_assert(BM == 64 && BN == 128, "issue shares below are written for 64 x 128 tiles");
+    constexpr int A_ST = BM * 128, B_ST = BN * 128, STAGE = A_ST + B_ST;   // 8 KB + 16 KB per 64-deep k-step
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, q = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = (a.N + BN - 1) / BN;
+    const int xcd = blockIdx.x & 7, slot_id = blockIdx.x >> 3;
+    const int mt = xcd + 8 * (slot_id / ntn);
+    if (mt * BM >= a.M) return;
+    const int m0 = mt * BM, n0 = (slot_id % ntn) * BN;
+
+    // one LDS-DMA instruction = 8 rows x 8 chunks of 16 B, lane l at position l: lane l fetches row 8 blk + (l >> 3), logical
+    // chunk (l & 7) ^ (l >> 3).  Wave w issues A blocks 2 w, 2 w + 1 and B blocks 4 w .. 4 w + 3.  Rows past M / N: clamped.
+    const int lrow = lane >> 3;
+    const unsigned lsw = (unsigned)(((lane & 7) ^ lrow) * 16);
+    unsigned aoff[2], boff[4];
 #pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-            for (int j = 0; j < TJ; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    sc[(wm * WM - pass * EP_ROWS + i * 16 + q * 4 + r) * LDC + wn * WN + j * 16 + c] = acc[i][j][r];
+    for (int i = 0; i < 2; ++i) {
+        int r = m0 + (wave * 2 + i) * 8 + lrow; r = r < a.M ? r : a.M - 1;
+        aoff[i] = (unsigned)r * (unsigned)(a.lda * 2) + lsw;
     }
-    __syncthreads();
-    if (a.act == 4) {
-        // GLU over the tile's column halves (weight rows regrouped by the caller: columns [0,64) of a 128-column tile are value
-        // channels, [64,128) their gates): out[gm][n0/2 + c] = (v + b) * sigmoid(g + b'), bf16, N/2 columns wide.  Thread = 4
-        // channels of one row: float4 reads of both halves, one 8-byte store, every thread busy.
-        if constexpr (BN == 128) {
-            for (int it = tid; it < EP_ROWS * 16; it += G_THREADS) {
-                const int row = it >> 4, cg = it & 15;
-                const int gm = m0 + pass * EP_ROWS + row, gc = n0 + cg * 4;
-                if (gm >= a.M) continue;
-                float4 vv = *reinterpret_cast<const float4*>(sc + row * LDC + cg * 4);
-                float4 gg = *reinterpret_cast<const float4*>(sc + row * LDC + 64 + cg * 4);
-                if (a.bias) {
-                    const float4 bv = *reinterpret_cast<const float4*>(a.bias + gc), bg = *reinterpret_cast<const float4*>(a.bias + gc + 64);
-                    vv.x += bv.x; vv.y += bv.y; vv.z += bv.z; vv.w += bv.w;
-                    gg.x += bg.x; gg.y += bg.y; gg.z += bg.z; gg.w += bg.w;
-                }
-                union { uint2 u; __bf16 h[4]; } o;
-                o.h[0] = (__bf16)(vv.x * ia_sigmoid_fast(gg.x)); o.h[1] = (__bf16)(vv.y * ia_sigmoid_fast(gg.y));
-                o.h[2] = (__bf16)(vv.z * ia_sigmoid_fast(gg.z)); o.h[3] = (__bf16)(vv.w * ia_sigmoid_fast(gg.w));
-                *reinterpret_cast<uint2*>(a.outH + (size_t)gm * a.ldoh + (n0 >> 1) + cg * 4) = o.u;
-            }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int r = n0 + (wave * 4 + i) * 8 + lrow; r = r < a.N ? r : a.N - 1;
+        boff[i] = (unsigned)r * (unsigned)(a.ldw * 2) + lsw;
+    }
+    const unsigned char* Ab = reinterpret_cast<const unsigned char*>(a.A);
+    const unsigned char* Wb = reinterpret_cast<const unsigned char*>(a.W);
+    auto issue = [&](int kt, int slot) {
+        const unsigned char* ak = Ab + (size_t)kt * 128;
+        const unsigned char* wk = Wb + (size_t)kt * 128;
+        unsigned char* dA = smem + slot * STAGE + wave * 2048;
+        unsigned char* dB = smem + slot * STAGE + A_ST + wave * 4096;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ak + aoff[i]),
+                                             (__attribute__((address_space(3))) void*)(dA + i * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wk + boff[i]),
+                                             (__attribute__((address_space(3))) void*)(dB + i * 1024), 16, 0, 0);
+    };
+
+    f4 acc[BM / 32][BN / 32];
+#pragma unroll
+    for (int i = 0; i < BM / 32; ++i)
+#pragma unroll
+        for (int j = 0; j < BN / 32; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+    // fragment addresses: lane (row c of a 16-row tile, k group q) reads logical chunk 4 ks + q, stored at (4 ks + q) ^ (c & 7)
+    const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
+    const unsigned fA = lds0 + (unsigned)((wm * 32 + c) * 128 + ((q ^ (c & 7)) * 16));
+    const unsigned fB = lds0 + (unsigned)(A_ST + (wn * 64 + c) * 128 + ((q ^ (c & 7)) * 16));
+    auto compute = [&](int slot) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const unsigned pa = (fA + (unsigned)(slot * STAGE)) ^ (unsigned)(ks * 64), pb = (fB + (unsigned)(slot * STAGE)) ^ (unsigned)(ks * 64);
+            bf8 af[2], bfr[4];
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:2048" : "=&v"(af[0]), "=&v"(af[1]) : "v"(pa));
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:2048\n\tds_read_b128 %2, %4 offset:4096\n\t"
+                         "ds_read_b128 %3, %4 offset:6144"
+                         : "=&v"(bfr[0]), "=&v"(bfr[1]), "=&v"(bfr[2]), "=&v"(bfr[3]) : "v"(pb));
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(bfr[0]), "+v"(bfr[1]), "+v"(bfr[2]), "+v"(bfr[3]));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
-        continue;   // next epilogue pass
+    };
+
+    const int nk = a.K / G_BK;
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    int slot = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        // this wave issued 6 instructions per stage; stage kt + 1 (if any) may stay in flight
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // everybody's share of stage kt has landed; nobody reads stage kt - 1 any more
+        if (kt + 2 < nk) issue(kt + 2, slot == 0 ? 2 : slot - 1);   // ring slot of stage kt - 1 = (kt + 2) mod 3
+        compute(slot);
+        slot = slot == 2 ? 0 : slot + 1;
     }
-    for (int it = tid; it < EP_ROWS * VEC_PER_ROW; it += G_THREADS) {
-        const int row = it / VEC_PER_ROW, cv = it - row * VEC_PER_ROW;
-        const int gm = m0 + pass * EP_ROWS + row, gn = n0 + cv * 8;
-        if (gm >= a.M || gn >= a.N) continue;
-        float v[8];
-        const float4 x0 = *reinterpret_cast<const float4*>(sc + row * LDC + cv * 8);
-        const float4 x1 = *reinterpret_cast<const float4*>(sc + row * LDC + cv * 8 + 4);
-        v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
-        gemm_epilogue8(a, gm, gn, v);
-        if constexpr (BN == 256) {
-            // LayerNorm of the finished row: its 256 columns are the 32 lanes of this half wave (8 columns each; rows beyond M
-            // skip the whole half wave above), two DPP / shuffle reductions, bf16 store of the normalised row
-            if (a.ln_g) {
-                float s1 = 0.f;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) s1 += v[j];
-                const float mean = gemm_half_wave_sum(s1) * (1.f / 256.f);
-                float s2 = 0.f;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { v[j] -= mean; s2 += v[j] * v[j]; }
-                const float rstd = rsqrtf(gemm_half_wave_sum(s2) * (1.f / 256.f) + a.ln_eps);
-                const float4 g0 = *reinterpret_cast<const float4*>(a.ln_g + gn), g1 = *reinterpret_cast<const float4*>(a.ln_g + gn + 4);
-                const float4 c0 = *reinterpret_cast<const float4*>(a.ln_b + gn), c1 = *reinterpret_cast<const float4*>(a.ln_b + gn + 4);
-                const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-                const float bb[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-                union { uint4 u; __bf16 h[8]; } o;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) o.h[j] = (__bf16)(v[j] * rstd * gg[j] + bb[j]);
-                *reinterpret_cast<uint4*>(a.outH + (size_t)gm * a.ldoh + gn) = o.u;
-            }
-        }
-    }
-    }
+    __syncthreads();   // the stages become the epilogue's fp32 tile
+    gemm_tile_epilogue<BM, BN>(a, acc, smem, m0, n0);
 }
 
 template <int BM, int BN, bool CONV = false>
@@ -326,6 +437,19 @@ extern "C" int ia_gemm_bf16_ex2(const void* A, int lda, const void* W, int ldw, 
         else if (tiles96 >= 240) best = 96;
     }
     if (forced == 128 || forced == 96 || forced == 64) best = forced;
+    static const int dma_min_k = [] { const char* e = getenv("IA_GEMM_DMA_MINK"); return e ? atoi(e) : 512; }();   // (A/B switch)
+    if (best == 64 && K % G_BK == 0 && K >= dma_min_k && (long long)M * lda * 2 < (1ll << 32) && (long long)N * ldw * 2 < (1ll << 32)) {
+        const char* e_dma = getenv("IA_GEMM_DMA");   // (read per call: tests compare the two kernels inside one process)
+        const bool no_dma = e_dma && e_dma[0] == '0';
+        if (!no_dma) {
+            constexpr int LDS = GD_STAGES * (64 + 128) * 128;
+            const int ntm = (M + 63) / 64, ntn2 = (N + 127) / 128;
+            IA_SET_MAX_LDS_ONCE((gemm_bf16_nt_dma_kernel<64, 128>), LDS);
+            hipLaunchKernelGGL((gemm_bf16_nt_dma_kernel<64, 128>), dim3(8 * ((ntm + 7) / 8) * ntn2), dim3(G_THREADS), LDS, st, a);
+            IA_RETURN_IF_LAUNCH_FAILED();
+            return IA_OK;
+        }
+    }
     if (best == 128) return launch_gemm<128, 128>(a, st);
     if (best == 96) return launch_gemm<96, 128>(a, st);
     return launch_gemm<64, 128>(a, st);

@@ -63,3 +63,32 @@ def test_projection_with_layernorm_epilogue_matches_the_two_launches(M, K, p):
     assert torch.equal(xa, xb)
     assert (ya.float() - yb.float()).abs().max().item() <= 2.0 ** -7 * ya.float().abs().max().item()
     assert (ya != yb).float().mean().item() < 0.02
+
+
+@pytest.mark.parametrize("M,N,K", [(12032, 256, 1024), (777, 264, 512), (3000, 768, 768), (130, 128, 1536)])
+def test_k_pipelined_projection_kernel_is_bit_identical_to_the_register_staged_one(M, N, K):
+    """gemm_bf16_nt_dma_kernel (operands by LDS-DMA into a three-stage ring, chosen for K >= 512 with 64-row tiles) against
+    gemm_bf16_nt_kernel<64, 128>: same tile shape, same MFMA order, same epilogue -- identical bits, ragged M / N included."""
+    from indic_cl_asr_amd.ops import fast
+    g = torch.Generator(device="cuda").manual_seed(K + M)
+    a = (torch.randn(M, K, device="cuda", generator=g) * 0.5).bfloat16()
+    w = (torch.randn(N, K, device="cuda", generator=g) * 0.05).bfloat16()
+    bias = torch.randn(N, device="cuda", generator=g)
+    res = torch.randn(M, N, device="cuda", generator=g)
+    outs = []
+    try:
+        for mode in ("0", "1"):
+            os.environ["IA_GEMM_DMA"] = mode
+            os.environ["IA_GEMM_BM"] = "64"
+            of, oh = fast.gemm(a, w, bias, act=1, dropout_p=0.1, seed=3, alpha=0.5, residual=res, out_f32=torch.empty_like(res))
+            outs.append((of, oh))
+    finally:
+        os.environ.pop("IA_GEMM_DMA", None)
+        os.environ.pop("IA_GEMM_BM", None)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    ref = a.double() @ w.double().t() + bias.double()
+    ref = ref * torch.sigmoid(ref)
+    keep = outs[1][0] != res
+    got = (outs[1][0].double() - res.double()) / (0.5 / 0.8984375)
+    assert ((got - ref).abs() * keep).max().item() <= 4e-3 * ref.abs().max().item()
