@@ -272,8 +272,12 @@ __global__ __launch_bounds__(G_THREADS, (BN == 256 ? 2 : (BM == 128 ? 3 : 4))) v
 // swizzle on the source side) into a ring of THREE stages, two of them always in flight, one barrier per k-step, counted
 // vmcnt waits; fragment reads are inline asm (a compiler-visible LDS read while LDS-DMA is in flight draws vmcnt(0)).
 // Same tile shape, same MFMA order per output element and the same epilogue as gemm_bf16_nt_kernel<64, 128>: bit-identical.
+// CONV (the subsampling's second convolution as implicit GEMM, C % 64 == 0: every 64-deep k-step lies inside one tap): the A
+// tile is gathered by the same instructions with per-lane pixel addresses; taps that fall into the zero padding (and rows past
+// M) read a 128-byte page of zeros instead -- an address select per lane and k-step, no branch, no masking of loaded data.
 constexpr int GD_STAGES = 3;
-template <int BM, int BN>
+__device__ __attribute__((aligned(128))) uint4 ia_gemm_zero_page[8];   // zero-initialised
+template <int BM, int BN, bool CONV = false>
 __global__ __launch_bounds__(G_THREADS, 2) void gemm_bf16_nt_dma_kernel(GemmArgs a) {
     static_assert(BM == 64 && BN == 128, "issue shares below are written for 64 x 128 tiles");
     constexpr int A_ST = BM * 128, B_ST = BN * 128, STAGE = A_ST + B_ST;   // 8 KB + 16 KB per 64-deep k-step
@@ -293,10 +297,27 @@ __global__ __launch_bounds__(G_THREADS, 2) void gemm_bf16_nt_dma_kernel(GemmArgs
     const int lrow = lane >> 3;
     const unsigned lsw = (unsigned)(((lane & 7) ^ lrow) * 16);
     unsigned aoff[2], boff[4];
+    unsigned avalid[2] = {0u, 0u};   // CONV: bits 0-2 = tap rows dt in bounds, bits 3-5 = tap columns df in bounds (0 for rows past M)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        int r = m0 + (wave * 2 + i) * 8 + lrow; r = r < a.M ? r : a.M - 1;
-        aoff[i] = (unsigned)r * (unsigned)(a.lda * 2) + lsw;
+        int r = m0 + (wave * 2 + i) * 8 + lrow;
+        if constexpr (CONV) {
+            const bool rv = r < a.M;
+            r = rv ? r : a.M - 1;
+            const int f2 = r % a.cF2, bt = r / a.cF2, t2 = bt % a.cT2, b = bt / a.cT2;
+            const int t1 = 2 * t2 - 1, f1 = 2 * f2 - 1;   // tap (0, 0)
+            aoff[i] = (unsigned)((((long long)b * a.cT1 + t1) * a.cF1 + f1) * a.cC * 2) + lsw;   // (wraps for t1 / f1 = -1: only used when valid)
+            unsigned v = 0;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                if (t1 + d >= 0 && t1 + d < a.cT1) v |= 1u << d;
+                if (f1 + d >= 0 && f1 + d < a.cF1) v |= 8u << d;
+            }
+            avalid[i] = rv ? v : 0u;
+        } else {
+            r = r < a.M ? r : a.M - 1;
+            aoff[i] = (unsigned)r * (unsigned)(a.lda * 2) + lsw;
+        }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -305,15 +326,31 @@ __global__ __launch_bounds__(G_THREADS, 2) void gemm_bf16_nt_dma_kernel(GemmArgs
     }
     const unsigned char* Ab = reinterpret_cast<const unsigned char*>(a.A);
     const unsigned char* Wb = reinterpret_cast<const unsigned char*>(a.W);
+    const unsigned char* zpage = reinterpret_cast<const unsigned char*>(ia_gemm_zero_page) + lsw;
+    const int ksteps_per_tap = CONV ? a.cC / G_BK : 1;
     auto issue = [&](int kt, int slot) {
-        const unsigned char* ak = Ab + (size_t)kt * 128;
+        const unsigned char* ak;
+        unsigned tapbits = 0;
+        if constexpr (CONV) {
+            const int tap = kt / ksteps_per_tap, c0 = (kt - tap * ksteps_per_tap) * G_BK;
+            const int dt = tap / 3, df = tap - dt * 3;
+            ak = Ab + ((size_t)(dt * a.cF1 + df) * a.cC + c0) * 2;
+            tapbits = (1u << dt) | (8u << df);
+        } else {
+            ak = Ab + (size_t)kt * 128;
+        }
         const unsigned char* wk = Wb + (size_t)kt * 128;
         unsigned char* dA = smem + slot * STAGE + wave * 2048;
         unsigned char* dB = smem + slot * STAGE + A_ST + wave * 4096;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ak + aoff[i]),
+        for (int i = 0; i < 2; ++i) {
+            // (CONV: the tap (0, 0) pixel lies one row / column in front of the output pixel's window -- a NEGATIVE offset for the
+            // first row / column: signed 32-bit, the image is < 2 GB)
+            const unsigned char* src = CONV ? ak + (long long)(int)aoff[i] : ak + aoff[i];
+            if constexpr (CONV) src = ((avalid[i] & tapbits) == tapbits) ? src : zpage;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(dA + i * 1024), 16, 0, 0);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wk + boff[i]),
@@ -568,5 +605,20 @@ extern "C" int ia_subsample_conv2(const void* in_cl, int B, int T1, int F1, int 
     a.M = B * a.cT2 * a.cF2; a.N = N; a.K = 9 * C; a.lda = 0; a.ldw = 9 * C; a.ldr = 0; a.ldof = 0; a.ldoh = N;
     a.act = 2; a.alpha = 1.f; a.seed = 0; a.thr = 0; a.keep_scale = 1.f; a.out_f16 = 0;
     a.ln_g = a.ln_b = nullptr; a.ln_eps = 0.f;
+    {   // K-pipelined LDS-DMA variant (C % 64 == 0), opt-in with IA_CONV_DMA=1: bit-identical, and measured at the SAME step
+        // time as the register-staged 128 x 128 kernel below (8.36 / 8.38 against 8.36 / 8.32 ms): its 64-row tiles read the
+        // weight fragments twice as often, which costs what the pipelining gains
+        const char* e = getenv("IA_CONV_DMA");
+        const bool dma = (e && e[0] == '1') && C % G_BK == 0 && (long long)B * T1 * F1 * C * 2 < (1ll << 31) && (long long)N * 9 * C * 2 < (1ll << 32);
+        if (dma) {
+            constexpr int LDS = GD_STAGES * (64 + 128) * 128;
+            const int ntm = (a.M + 63) / 64, ntn2 = (N + 127) / 128;
+            IA_SET_MAX_LDS_ONCE((gemm_bf16_nt_dma_kernel<64, 128, true>), LDS);
+            hipLaunchKernelGGL((gemm_bf16_nt_dma_kernel<64, 128, true>), dim3(8 * ((ntm + 7) / 8) * ntn2), dim3(G_THREADS), LDS,
+                               (hipStream_t)stream, a);
+            IA_RETURN_IF_LAUNCH_FAILED();
+            return IA_OK;
+        }
+    }
     return launch_gemm<128, 128, true>(a, (hipStream_t)stream);
 }

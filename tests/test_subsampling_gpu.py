@@ -49,3 +49,32 @@ def test_conv_subsampling_hip_matches_reference_file_outputs(tag):
     assert err <= 2e-2 * want.abs().max().item(), (err, want.abs().max().item())   # bf16 operands (see the test above)
     lens = torch.tensor(Z[f"sub/{tag}/lens"])
     assert torch.equal(subsampled_length(lens), torch.tensor(Z[f"sub/{tag}/ylen"]).long())
+
+
+def test_k_pipelined_implicit_gemm_convolution_is_bit_identical_to_the_register_staged_one():
+    """ia_subsample_conv2 on the LDS-DMA kernel (C % 64 == 0: padding taps read a page of zeros through an address select)
+    against the register-staged implicit GEMM: same products in the same order."""
+    import os
+    from indic_cl_asr_amd import _lib
+    L = _lib.lib()
+    B, T1, F1, C, N = 3, 151, 40, 256, 256
+    g = torch.Generator(device="cuda").manual_seed(4)
+    x = (torch.randn(B, T1, F1, C, device="cuda", generator=g) * 0.5).bfloat16()
+    w = (torch.randn(N, 9 * C, device="cuda", generator=g) * 0.02).bfloat16()
+    b = torch.randn(N, device="cuda", generator=g)
+    T2, F2 = (T1 - 1) // 2 + 1, (F1 - 1) // 2 + 1
+    outs = []
+    try:
+        for mode in ("0", "1"):
+            os.environ["IA_CONV_DMA"] = mode
+            o = torch.empty(B * T2 * F2, N, dtype=torch.bfloat16, device="cuda")
+            _lib.check(L.ia_subsample_conv2(_lib.ptr(x), B, T1, F1, C, _lib.ptr(w), _lib.ptr(b), N, _lib.ptr(o), _lib.stream_ptr()), "conv2")
+            outs.append(o)
+    finally:
+        os.environ.pop("IA_CONV_DMA", None)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    # and against ATen on the same bf16 operands
+    ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.float().view(N, 3, 3, C).permute(0, 3, 1, 2), b, stride=2, padding=1)
+    ref = torch.relu(ref).permute(0, 2, 3, 1).reshape(B * T2 * F2, N)
+    assert (outs[1].float() - ref).abs().max().item() <= 1e-2 * ref.abs().max().item()
