@@ -29,6 +29,8 @@ WORK = [
                           "paced by 1 MB of weights per workgroup through LDS")),
     ("gemm_bf16_nt_kernel<128, 128, true>", ("subsampling conv2 as implicit GEMM", "mfma", 2.0 * (B * 376 * 20) * 256 * 2304, "flop", "")),
     ("gemm_bf16_nt_kernel<96, 128", ("subsampling Linear [N x 5120] x [256 x 5120]", "mfma", 2.0 * N * 256 * 5120, "flop", "")),
+    ("gemm_bf16_nt_dma_kernel", ("long-K projections (K >= 512: feed-forward W2, data gradients), K-pipelined by LDS-DMA", "mfma", 2.0 * N * 256 * 1024, "flop",
+                                 "[12032 x 1024] x [1024 x 256] is the most frequent shape (12 of ~18 launches)")),
     ("gemm_bf16_nt_kernel<64, 256", ("attention out-projection + residual + LayerNorm of the convolution module in one launch", "hbm",
                                      2.0 * N * d + 4.0 * N * d + 4.0 * N * d + 2.0 * N * d, "byte", "1.6 GFLOP; latency-bound at this size")),
     ("gemm_bf16_nt_kernel<64, 128", ("projections of the blocks / heads (K = 256 .. 1024, mixed shapes)", "mfma", 361e9 / 95.0, "flop",
