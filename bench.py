@@ -473,7 +473,8 @@ def main():
             tf = fl / (avg * 1e-3) / 1e12
             out["roofline_mfma"] = {"kernel": "joint_dh_fused_kernel", "bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TFS,
                                     "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TFS, 4),
-                                    "traffic": (pmc or {}).get("kernels", {}).get("joint_dh_fused_kernel", {}).get("hbm_bytes_per_launch"),
+                                    "traffic": ((pmc or {}).get("kernels", {}).get("joint_dh_fused_kernel", {}).get("hbm_bytes_per_launch")
+                                                if (args.batch == 32 and args.seconds == 15.0 and args.preset == "medium") else None),
                                     "launches": len(ms_l),
                                     "avg_launch_ms": round(avg, 4), "algorithmic_flops_per_launch": int(fl),
                                     "frac_of": frac_vs(tf, "mfma_bf16_TFs", MFMA_BF16_PEAK_TFS)}
