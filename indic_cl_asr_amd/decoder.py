@@ -222,8 +222,13 @@ class RNNTJoint(nn.Module):
         from .ops.joint import fused_joint_supported
         lk = self._loss._loss
         H, V = self.cfg.joint_hidden, self.cfg.vocab_per_lang + 1
+        # several languages in one batch (the reference picks the head per sample, A/modules/rnnt.py:1632-1640): the fused
+        # kernels take ONE head, so _forward_fused runs them once per language over that language's utterances -- unless
+        # the MAS / LwF stash is requested (its sub-batch boxes are defined on the batch order)
+        mixed = language_ids is not None and len(set(language_ids)) > 1
         ok = (self.use_fused and self.cfg.compute_dtype == "bf16"
-              and language_ids is not None and len(set(language_ids)) == 1 and lk.clamp <= 0.0
+              and language_ids is not None and lk.clamp <= 0.0
+              and not (mixed and (self.store_sub_enc or self.store_sub_logits or self._loss.reduction != 'mean_batch'))
               and fused_joint_supported(H, V, enc.device))
         if ok and (self.store_sub_enc or self.store_sub_logits):
             # the stash of the MAS / LwF passes stays on the lattice (ops.joint.LatticeStash); its terms' gradient needs the
@@ -234,6 +239,43 @@ class RNNTJoint(nn.Module):
         return ok
 
     def _forward_fused(self, enc, dec, encoder_lengths, transcripts, transcript_lengths, language_ids, h_enc, h_tgt):
+        if len(set(language_ids)) > 1:
+            return self._forward_fused_mixed(enc, dec, encoder_lengths, transcripts, transcript_lengths, language_ids, h_enc, h_tgt)
+        return self._forward_fused_one(enc, dec, encoder_lengths, transcripts, transcript_lengths, language_ids, h_enc, h_tgt)
+
+    def _forward_fused_mixed(self, enc, dec, encoder_lengths, transcripts, transcript_lengths, language_ids, h_enc, h_tgt):
+        """Mixed-language batch: one fused joint + loss pass per language over that language's utterances (gathered with
+        index_select: autograd scatters their gradients back), the per-utterance costs returned to batch order.  The mean over
+        the batch does not depend on the order the utterances were scored in."""
+        B = len(language_ids)
+        order = []
+        for lang in language_ids:
+            if lang not in order:
+                order.append(lang)
+        keep_rc, keep_seed = self.return_costs, self.dropout_seed
+        costs = None
+        self.return_costs = True
+        try:
+            for gi, lang in enumerate(order):
+                idx_h = [i for i in range(B) if language_ids[i] == lang]
+                idx = torch.tensor(idx_h, dtype=torch.long, device=enc.device)
+                self.dropout_seed = (keep_seed + 0x9E3779B1 * gi) & 0xFFFFFFFF   # unrelated masks per group
+                self.last_costs = None
+                self._forward_fused_one(enc.index_select(0, idx), dec.index_select(0, idx), encoder_lengths.index_select(0, idx),
+                                        transcripts.index_select(0, idx), transcript_lengths.index_select(0, idx), [lang] * len(idx_h),
+                                        [h_enc[i] for i in idx_h], [h_tgt[i] for i in idx_h])
+                c = self.last_costs
+                costs = c.new_zeros(B) if costs is None else costs
+                costs = costs.index_copy(0, idx, c)
+        finally:
+            self.return_costs, self.dropout_seed = keep_rc, keep_seed
+        if self.return_costs and self._loss.reduction == 'mean_batch':
+            self.last_costs = costs
+            return None
+        self.last_costs = None
+        return self._loss.reduce([costs], [transcript_lengths])
+
+    def _forward_fused_one(self, enc, dec, encoder_lengths, transcripts, transcript_lengths, language_ids, h_enc, h_tgt):
         from .ops.joint import fused_joint_rnnt
         max_t, max_u = max(h_enc), max(h_tgt)
         req = None

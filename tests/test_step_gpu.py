@@ -484,3 +484,35 @@ def test_side_streams_do_not_change_the_step():
     for n in g0:   # the modules that only run our own (deterministic) kernels or plain ATen GEMMs
         if n.startswith(("ctc_decoder.", "joint.joint_net.")):
             assert torch.equal(g0[n], g1[n]), n
+
+
+def test_mixed_language_batch_runs_the_fused_joint_per_language_and_matches_the_aten_path():
+    """A batch with two languages (the reference picks the joint head per sample, A/modules/rnnt.py:1632-1640): the fused joint +
+    loss runs once per language over that language's utterances; loss and every gradient -- the two heads' included -- against the
+    ATen composition on the same bf16 model (which materialises the [B,T,U,H] hidden tensor)."""
+    from indic_cl_asr_amd.config import model_config
+    from indic_cl_asr_amd.model import EncDecHybridRNNTCTCModel
+    torch.manual_seed(0)
+    cfg = model_config('tiny', d_model=64, n_layers=2, pred_hidden=64, joint_hidden=64, compute_dtype='bf16', dither=0.0)
+    m = EncDecHybridRNNTCTCModel(cfg).disable_dropout().cuda().train()
+    m.spec_augment_enabled = False
+    batch = tuple(t.cuda() for t in _batch(B=6))
+    langs = ['hi', 'ta', 'hi', 'hi', 'ta', 'ta']
+    out = {}
+    for fused in (True, False):
+        m.joint.use_fused = fused
+        m.zero_grad(set_to_none=True)
+        loss, mon = m.training_step(batch, langs)
+        loss.backward()
+        torch.cuda.synchronize()
+        out[fused] = (float(loss.detach()), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+    m.joint.use_fused = True
+    assert abs(out[True][0] - out[False][0]) <= 2e-3 * abs(out[False][0]), (out[True][0], out[False][0])
+    heads = [n for n in out[False][1] if n.startswith('joint.joint_net.2.')]
+    assert any('.hi.' in n for n in heads) and any('.ta.' in n for n in heads)
+    for n, gref in out[False][1].items():
+        if _structural_zero(n) or gref.abs().max().item() == 0.0:
+            continue
+        g = out[True][1][n]
+        rel = (g - gref).norm().item() / gref.norm().item()
+        assert rel <= 0.06, (n, rel)
