@@ -64,6 +64,28 @@ class WER:
         return wer, self.scores, self.words
 
 
+class PendingHyps:
+    """Hypotheses whose device work and device->host copies have been ENQUEUED (on the stream that was current at the call);
+    `result()` waits for the copies' event and builds the token lists.  training_step(compute_wer=True) holds two of them
+    (transducer + CTC) in the monitor, so the decode runs beside the rest of the step instead of in front of it."""
+
+    def __init__(self, finish):
+        self._finish, self._res = finish, None
+
+    def result(self) -> List[List[int]]:
+        if self._finish is not None:
+            self._res = self._finish()
+            self._finish = None
+        return self._res
+
+
+def _pinned_async(t):
+    """Asynchronous device->host copy of `t` into pinned memory on the current stream."""
+    h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    h.copy_(t, non_blocking=True)
+    return h
+
+
 @torch.no_grad()
 def greedy_rnnt_decode(model, encoded, encoded_len, language_ids, max_symbols: Optional[int] = 10) -> List[List[int]]:
     """encoded [B,d,T'] (encoder output), encoded_len [B] -> per-utterance language-local token ids."""
@@ -81,7 +103,7 @@ def device_decode_supported(model) -> bool:
 
 
 @torch.no_grad()
-def greedy_rnnt_decode_device(model, encoded, encoded_len, language_ids, max_symbols: Optional[int] = 10) -> List[List[int]]:
+def greedy_rnnt_decode_device(model, encoded, encoded_len, language_ids, max_symbols: Optional[int] = 10, defer: bool = False):
     """The same decode in ONE launch (csrc/greedy_decode.hip).  Setup on the HIP fp32 GEMM: the joint's encoder projection of
     all frames and the table EW = W_ih embedding[row] + b_ih + b_hh over the 257 rows the loop can feed the prediction
     network (the language's labels by their ids as decoding.greedy_rnnt_decode_host feeds them, the blank / padding row, the
@@ -121,13 +143,32 @@ def greedy_rnnt_decode_device(model, encoded, encoded_len, language_ids, max_sym
     counts = torch.zeros(B, dtype=torch.int32, device=dev)
     overflow = torch.zeros(1, dtype=torch.int32, device=dev)
     out_len = encoded_len.to(dev).long().contiguous()
-    Whh = lstm.weight_hh_l0.float().contiguous()
-    Wp, bp = joint.pred.weight.float().contiguous(), joint.pred.bias.float().contiguous()
-    Wh, bh = head.weight.float().contiguous(), head.bias.float().contiguous()
+    def snap(p):   # fp32 contiguous image; with `defer` a private COPY: the optimizer may rewrite the weights while the loop runs
+        t = p.detach().float().contiguous()
+        return t.clone() if (defer and t.data_ptr() == p.data_ptr()) else t
+
+    Whh = snap(lstm.weight_hh_l0)
+    Wp, bp = snap(joint.pred.weight), snap(joint.pred.bias)
+    Wh, bh = snap(head.weight), snap(head.bias)
     st = L.ia_greedy_rnnt_decode(_lib.ptr(f_all), _lib.ptr(out_len), _lib.ptr(EW), _lib.ptr(Whh), _lib.ptr(Wp), _lib.ptr(bp),
                                  _lib.ptr(Wh), _lib.ptr(bh), B, T, Hp, Hj, V, blank, blank, V, ms, _lib.ptr(tokens), cap,
                                  _lib.ptr(counts), _lib.ptr(overflow), _lib.stream_ptr())
     _lib.check(st, "ia_greedy_rnnt_decode")
+    if defer:
+        h_tok, h_n, h_ovf = _pinned_async(tokens), _pinned_async(counts), _pinned_async(overflow)
+        ev = torch.cuda.Event()
+        ev.record()
+        keep = [tokens, counts, overflow, f_all, EW, Whh, Wp, bp, Wh, bh, out_len]   # alive until the kernel has run
+
+        def finish():
+            ev.synchronize()
+            keep.clear()
+            if int(h_ovf[0]):
+                raise RuntimeError("greedy_rnnt_decode: an utterance emitted more symbols than the output buffer holds "
+                                   f"({cap} per utterance); pass a finite max_symbols")
+            n = h_n.tolist()
+            return [h_tok[b, :n[b]].tolist() for b in range(B)]
+        return PendingHyps(finish)
     host_tok, host_n, ovf = tokens.cpu(), counts.cpu().tolist(), int(overflow.item())
     if ovf:
         raise RuntimeError("greedy_rnnt_decode: an utterance emitted more symbols than the output buffer holds "
@@ -186,13 +227,23 @@ def greedy_rnnt_decode_host(model, encoded, encoded_len, language_ids, max_symbo
 
 
 @torch.no_grad()
-def greedy_ctc_decode(log_probs, lengths, blank: Optional[int] = None) -> List[List[int]]:
-    """log_probs [B,T,V] (language-restricted), lengths [B] -> collapsed token ids (repeats merged, blanks removed)."""
+def greedy_ctc_decode(log_probs, lengths, blank: Optional[int] = None, defer: bool = False):
+    """log_probs [B,T,V] (language-restricted), lengths [B] -> collapsed token ids (repeats merged, blanks removed).
+    defer (CUDA): PendingHyps -- argmax / collapse mask enqueued, one asynchronous copy, lists built on result()."""
     B, T, V = log_probs.shape
     blank = V - 1 if blank is None else blank
     k = log_probs.argmax(-1)                                                  # [B,T]
     valid = torch.arange(T, device=k.device)[None, :] < lengths.to(k.device)[:, None]
     prev = torch.cat([torch.full((B, 1), -1, dtype=k.dtype, device=k.device), k[:, :-1]], 1)
     keep = valid & (k != blank) & (k != prev)
+    if defer and k.is_cuda:
+        h = _pinned_async(torch.where(keep, k, torch.full_like(k, -1)).to(torch.int32))
+        ev = torch.cuda.Event()
+        ev.record()
+
+        def finish():
+            ev.synchronize()
+            return [[v for v in row if v >= 0] for row in h.tolist()]
+        return PendingHyps(finish)
     host_k, host_keep = k.tolist(), keep.tolist()
     return [[v for v, m in zip(r, mk) if m] for r, mk in zip(host_k, host_keep)]

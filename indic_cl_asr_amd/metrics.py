@@ -97,6 +97,21 @@ class WER(nn.Module):
         self.scores = torch.tensor(s, device=self.scores.device, dtype=self.scores.dtype)
         self.words = torch.tensor(w, device=self.words.device, dtype=self.words.dtype)
 
+    @torch.no_grad()
+    def update_from_ids(self, hyp_ids: List[List[int]], ref_ids: List[List[int]], lang_ids: Optional[List[str]] = None):
+        """`update` with the hypotheses' and references' token ids already on the host (the deferred in-step path)."""
+        B = len(ref_ids)
+        langs = lang_ids if lang_ids is not None else [None] * B
+        references = [self.decode_tokens_to_str(r, langs[i]) for i, r in enumerate(ref_ids)]
+        hyps = [self.decode_tokens_to_str(h, langs[i]) for i, h in enumerate(hyp_ids)]
+        if self.log_prediction and B:
+            logging.info("\n")
+            logging.info(f"reference:{references[0]}")
+            logging.info(f"predicted:{hyps[0]}")
+        s_, w_ = self.score(hyps, references)
+        self.scores = torch.tensor(s_, device=self.scores.device, dtype=self.scores.dtype)
+        self.words = torch.tensor(w_, device=self.words.device, dtype=self.words.dtype)
+
     def compute(self):
         pair = torch.stack([self.scores.detach(), self.words.detach()])
         dist = _dist_world() if self.dist_sync_on_step else None

@@ -60,6 +60,7 @@ class StepMonitor(dict):
     def __init__(self, static, keys=(), device_values=None):
         super().__init__(static)
         self._pending = None
+        self._deferred = []   # callables that fill further keys on first access (the in-step WERs: decode enqueued, scored on read)
         if device_values is not None and device_values.is_cuda:
             host = torch.empty(device_values.shape, dtype=device_values.dtype, pin_memory=True)
             host.copy_(device_values, non_blocking=True)
@@ -73,7 +74,16 @@ class StepMonitor(dict):
             for k, v in zip(keys, device_values.tolist()):
                 super().__setitem__(k, v)
 
+    def defer(self, fn):
+        """fn(monitor_dict_setter) runs once, on the first read of any key."""
+        self._deferred.append(fn)
+
     def _resolve(self):
+        if self._deferred:
+            fns, self._deferred = self._deferred, []
+            for fn in fns:
+                for k, v in fn().items():
+                    super().__setitem__(k, v)
         if self._pending is not None:
             keys, host, ev = self._pending
             self._pending = None
@@ -139,6 +149,7 @@ class EncDecHybridRNNTCTCModel(TranscriptionMixin, nn.Module):
         self.dither_enabled = True
         self.overlap_decoder = True      # prediction network on a side HIP stream (training_step)
         self.overlap_ctc = True          # CTC head + CTC loss on a second side stream, under the joint (training_step)
+        self.defer_wer = True            # compute_wer: decode on a third side stream, scored when the monitor is read
 
     @staticmethod
     def _side_stream(device, which=0):
@@ -230,6 +241,49 @@ class EncDecHybridRNNTCTCModel(TranscriptionMixin, nn.Module):
         self.ctc_wer.reset()
         return wer, ctc_wer.item()
 
+    def wer_decode_begin(self, encoded, encoded_len, transcript, language_ids, enc_ready, stream):
+        """First half of the deferred in-step WER (training_step, compute_wer): right behind the encoder output `enc_ready` the
+        greedy transducer decode (one persistent workgroup per utterance for ~8 ms at 32 x 15 s) and the copy of the references
+        are ENQUEUED on `stream`.  The decode reads private copies of the weights it needs, so the optimizer may update them
+        meanwhile; the returned event marks the point behind which those copies (and the setup GEMMs) have been issued."""
+        from .decoding import _pinned_async, greedy_rnnt_decode_device
+        stream.wait_event(enc_ready)
+        with torch.cuda.stream(stream):
+            refs_h = _pinned_async(transcript)
+            hyps_p = greedy_rnnt_decode_device(self, encoded.detach(), encoded_len, language_ids, 10, defer=True)
+            snap = torch.cuda.Event()
+            snap.record(stream)
+        for t in (encoded, encoded_len, transcript):
+            t.record_stream(stream)
+        return {"refs": refs_h, "hyps": hyps_p, "snap": snap, "stream": stream}
+
+    def wer_decode_finish(self, pend, ctc_logits, encoded_len, language_ids, host_tgt_lens, ctc_ready):
+        """Second half: the CTC head's greedy path (argmax, collapse mask, one copy) joins the same stream behind `ctc_ready`;
+        returns fn() -> {'training_batch_wer', 'training_batch_wer_ctc'}, which waits for the copies and scores on the host --
+        the monitor calls it on its first read (the CL loops read it after the optimizer step, R/cl_baseline_ewc.py:258-260)."""
+        from .decoding import greedy_ctc_decode
+        self.wer.bind(self); self.ctc_wer.bind(self)
+        stream = pend["stream"]
+        stream.wait_event(ctc_ready)
+        with torch.cuda.stream(stream):
+            ctc_p = greedy_ctc_decode(ctc_logits.detach(), encoded_len, defer=True)
+            done = torch.cuda.Event()
+            done.record(stream)
+        ctc_logits.record_stream(stream)
+        lens = [int(n) for n in host_tgt_lens]
+        group = max(1, int(self.joint.fused_batch_size))
+        refs_h, hyps_p = pend["refs"], pend["hyps"]
+
+        def fn():
+            done.synchronize()
+            refs = [row[:n] for row, n in zip(refs_h.tolist(), lens)]
+            wer, _, _ = self.wer.grouped(hyps_p.result(), refs, language_ids, group)
+            self.ctc_wer.update_from_ids(ctc_p.result(), refs, language_ids)
+            ctc_wer, _, _ = self.ctc_wer.compute()
+            self.ctc_wer.reset()
+            return {'training_batch_wer': wer, 'training_batch_wer_ctc': ctc_wer.item()}
+        return fn
+
     # ------------------------------------------------------------------ training_step (:859-930)
     def training_step(self, batch, lang_ids, return_probs=False, host_lengths=None, compute_wer=False):
         """batch = (signal [B,L] f32, signal_len [B] i64, transcript [B,U] i64, transcript_len [B] i64), all on the
@@ -318,6 +372,14 @@ class EncDecHybridRNNTCTCModel(TranscriptionMixin, nn.Module):
                 log_probs, ctc_loss = ctc_branch()
             for t in (encoded, encoded_len, transcript, transcript_len):
                 t.record_stream(side2)
+        wer_pend = None
+        if want_wer and signal.is_cuda and self.defer_wer and len(set(language_ids)) == 1:
+            from .decoding import device_decode_supported
+            if device_decode_supported(self):
+                main_ = torch.cuda.current_stream(signal.device)
+                ready_ = torch.cuda.Event()
+                ready_.record(main_)
+                wer_pend = self.wer_decode_begin(encoded, encoded_len, transcript, language_ids, ready_, self._side_stream(signal.device, 2))
         self.joint.loss_scale_hint = (1.0 - self.ctc_loss_weight) / max(1, signal.shape[0])
         self.joint.dropout_seed = (self.seed * 2654435761 + self._step * 40503) & 0x7FFFFFFF
         self.joint.return_costs = bool(signal.is_cuda)     # per-utterance costs: the combination kernel forms the means
@@ -365,8 +427,17 @@ class EncDecHybridRNNTCTCModel(TranscriptionMixin, nn.Module):
         if want_wer:
             if log_probs is None:   # greedy CTC reads the raw logits: argmax over the valid columns == argmax of the log-probs
                 log_probs = ctc_keep["logits"][:, :, :ctc_keep["V"]]
-            wer, wer_ctc = self.batch_wer(encoded, encoded_len, log_probs, transcript, transcript_len, language_ids)
-            monitor['training_batch_wer'], monitor['training_batch_wer_ctc'] = wer, wer_ctc
+            if wer_pend is not None and isinstance(monitor, StepMonitor):
+                # decode + scoring off the step's critical path: the transducer decode was enqueued on a third side stream right
+                # behind the encoder output; the CTC argmax joins it here, the scores are formed when the monitor is read
+                main = torch.cuda.current_stream(signal.device)
+                ctc_ready = torch.cuda.Event()
+                ctc_ready.record(main)      # (side2 -- the CTC branch -- was joined into the main stream above)
+                monitor.defer(self.wer_decode_finish(wer_pend, log_probs, encoded_len, language_ids, h_tgt, ctc_ready))
+                main.wait_event(wer_pend["snap"])   # the optimizer step that follows must not overtake the decode's weight copies
+            else:
+                wer, wer_ctc = self.batch_wer(encoded, encoded_len, log_probs, transcript, transcript_len, language_ids)
+                monitor['training_batch_wer'], monitor['training_batch_wer_ctc'] = wer, wer_ctc
         self._step += 1
         if return_probs:
             return loss_value, monitor, log_probs

@@ -92,6 +92,15 @@ def test_training_step_monitor_carries_batch_wer_when_asked():
         assert float(mon[key]) >= 0.0 and float(mon[key]) == float(mon[key])
     loss2, mon2 = m.training_step(batch, ['hi'] * 3)
     assert mon2['training_batch_wer_ctc'] != mon2['training_batch_wer_ctc']     # NaN when not requested
+    # the deferred form (decode enqueued on a side stream behind the encoder output, scored on the monitor's first read) and the
+    # synchronous one give the same numbers
+    res = {}
+    for deferred in (True, False):
+        m.defer_wer = deferred
+        _, mon3 = m.training_step(batch, ['hi'] * 3, compute_wer=True)
+        res[deferred] = (float(mon3['training_batch_wer']), float(mon3['training_batch_wer_ctc']), float(mon3['train_loss']))
+    m.defer_wer = True
+    assert res[True] == res[False]
 
 
 def test_wer_metric_objects_follow_the_reference_surface():
