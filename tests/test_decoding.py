@@ -94,6 +94,7 @@ def test_training_step_monitor_carries_batch_wer_when_asked():
     assert mon2['training_batch_wer_ctc'] != mon2['training_batch_wer_ctc']     # NaN when not requested
     # the deferred form (decode enqueued on a side stream behind the encoder output, scored on the monitor's first read) and the
     # synchronous one give the same numbers
+    m.disable_dropout()
     res = {}
     for deferred in (True, False):
         m.defer_wer = deferred
