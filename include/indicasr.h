@@ -281,6 +281,13 @@ int ia_greedy_rnnt_decode(const float* f_all, const int64_t* out_len, const floa
                           const float* bpred, const float* Whead, const float* bhead, int B, int T, int Hp, int Hj, int V,
                           int blank, int row_blank, int row_sos, int max_symbols, int* tokens, int cap, int* counts,
                           int* overflow, ia_stream_t stream);
+/* The same loop with W_hh, W_pred and the head as row-major bf16 (the images the training step multiplies with; Hp, Hj
+ * multiples of 8): half the bytes per emitted symbol of a loop that is bound by the CU's L2 bandwidth.  Activations, the EW
+ * table, biases and every accumulation stay fp32. */
+int ia_greedy_rnnt_decode_bf16w(const float* f_all, const int64_t* out_len, const float* EW, const void* Whh_bf16,
+                                const void* Wpred_bf16, const float* bpred, const void* Whead_bf16, const float* bhead, int B, int T,
+                                int Hp, int Hj, int V, int blank, int row_blank, int row_sos, int max_symbols, int* tokens, int cap,
+                                int* counts, int* overflow, ia_stream_t stream);
 
 /* fp8 (OCP e4m3) projections of the frozen prefix (csrc/gemm_fp8.hip; BASELINE configs[4] "fp8 MFMA"; no reference
  * semantics -- tolerance vs the fp32 oracle stated in tests/test_fp8_gpu.py):

@@ -23,24 +23,42 @@ constexpr int GD_WAVES = GD_THREADS / 64;
 
 struct GdArgs {
     const float* f_all; const int64_t* out_len;
-    const float* EW; const float* Whh; const float* Wpred; const float* bpred; const float* Whead; const float* bhead;
+    const float* EW; const void* Whh; const void* Wpred; const float* bpred; const void* Whead; const float* bhead;   // W*: float or bf16 (kernel template)
     int* tokens; int* counts; int* overflow;
     int B, T, Hp, Hj, V, blank, row_blank, row_sos, max_symbols, cap;
 };
 
-// y[r] = bias[r] + sum_k W[r][k] x[k] for r in [0, N): wave-per-row dot products, x in LDS, 4 rows in flight per wave
-__device__ __forceinline__ void gd_gemv(const float* __restrict__ W, const float* __restrict__ bias, const float* x, float* y,
+// y[r] = bias[r] + sum_k W[r][k] x[k] for r in [0, N): wave-per-row dot products, x in LDS, 4 rows in flight per wave.
+// WT = float, or __bf16 (the bf16 images of the weights the training step multiplies with: half the bytes per emitted symbol --
+// the loop is bound by the CU's L2 bandwidth; activations and accumulation stay fp32)
+template <typename WT>
+__device__ __forceinline__ void gd_gemv(const void* __restrict__ Wv, const float* __restrict__ bias, const float* x, float* y,
                                         int N, int K, int wave, int lane) {
-    const int kv = K / 4;   // float4 chunks per row
+    constexpr int EPC = sizeof(WT) == 2 ? 8 : 4;   // elements per 16-byte chunk
+    const WT* W = static_cast<const WT*>(Wv);
+    const int kv = K / EPC;
     for (int r0 = wave * 4; r0 < N; r0 += GD_WAVES * 4) {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         for (int v = lane; v < kv; v += 64) {
-            const float4 xv = *reinterpret_cast<const float4*>(x + v * 4);
+            float xs[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; e += 4) {
+                const float4 xv = *reinterpret_cast<const float4*>(x + v * EPC + e);
+                xs[e] = xv.x; xs[e + 1] = xv.y; xs[e + 2] = xv.z; xs[e + 3] = xv.w;
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int r = (r0 + j < N) ? (r0 + j) : (N - 1);
-                const float4 w = *reinterpret_cast<const float4*>(W + (size_t)r * K + v * 4);
-                acc[j] += w.x * xv.x + w.y * xv.y + w.z * xv.z + w.w * xv.w;
+                const uint4 raw = *reinterpret_cast<const uint4*>(W + (size_t)r * K + v * EPC);
+                if constexpr (sizeof(WT) == 2) {
+                    const unsigned u[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)   // bf16 -> fp32: the 16 bits are the upper half of the float
+                        acc[j] += __uint_as_float(u[e] << 16) * xs[2 * e] + __uint_as_float(u[e] & 0xFFFF0000u) * xs[2 * e + 1];
+                } else {
+                    acc[j] += __uint_as_float(raw.x) * xs[0] + __uint_as_float(raw.y) * xs[1] + __uint_as_float(raw.z) * xs[2] +
+                              __uint_as_float(raw.w) * xs[3];
+                }
             }
         }
 #pragma unroll
@@ -51,6 +69,40 @@ __device__ __forceinline__ void gd_gemv(const float* __restrict__ W, const float
     }
 }
 
+// bf16 weights: 16 lanes per row (lane l16 takes the 16-byte chunks l16, l16 + 16, ...), 8 rows per wave pass -- with one
+// 64-lane wave per row a K = 640 row is 80 chunks = 1.25 wave-loads, a third of the lanes idle and too few bytes in flight
+// (the first bf16 version of this loop was SLOWER than the fp32 one: 17.5 against 14.6 ms per step with the in-step WER)
+template <>
+__device__ __forceinline__ void gd_gemv<__bf16>(const void* __restrict__ Wv, const float* __restrict__ bias, const float* x, float* y,
+                                                int N, int K, int wave, int lane) {
+    const unsigned short* W = static_cast<const unsigned short*>(Wv);
+    const int kv = K / 8, l16 = lane & 15, sub = lane >> 4;
+    for (int r0 = wave * 8; r0 < N; r0 += GD_WAVES * 8) {
+        const int ra_ = r0 + sub, rb_ = r0 + 4 + sub;
+        const int ra = ra_ < N ? ra_ : N - 1, rb = rb_ < N ? rb_ : N - 1;
+        float acc_a = 0.f, acc_b = 0.f;
+        for (int v = l16; v < kv; v += 16) {
+            const float4 x0 = *reinterpret_cast<const float4*>(x + v * 8), x1 = *reinterpret_cast<const float4*>(x + v * 8 + 4);
+            const float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+            const uint4 wa = *reinterpret_cast<const uint4*>(W + (size_t)ra * K + v * 8);
+            const uint4 wb = *reinterpret_cast<const uint4*>(W + (size_t)rb * K + v * 8);
+            const unsigned ua[4] = {wa.x, wa.y, wa.z, wa.w}, ub[4] = {wb.x, wb.y, wb.z, wb.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {   // bf16 -> fp32: the 16 bits are the upper half of the float
+                acc_a += __uint_as_float(ua[e] << 16) * xs[2 * e] + __uint_as_float(ua[e] & 0xFFFF0000u) * xs[2 * e + 1];
+                acc_b += __uint_as_float(ub[e] << 16) * xs[2 * e] + __uint_as_float(ub[e] & 0xFFFF0000u) * xs[2 * e + 1];
+            }
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { acc_a += __shfl_xor(acc_a, o, 64); acc_b += __shfl_xor(acc_b, o, 64); }   // 16-lane sums
+        if (l16 == 0) {
+            if (ra_ < N) y[ra_] = acc_a + (bias ? bias[ra_] : 0.f);
+            if (rb_ < N) y[rb_] = acc_b + (bias ? bias[rb_] : 0.f);
+        }
+    }
+}
+
+template <typename WT>
 __global__ __launch_bounds__(GD_THREADS, 1) void greedy_decode_kernel(GdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int Hp = a.Hp, Hj = a.Hj, V = a.V;
@@ -74,7 +126,7 @@ __global__ __launch_bounds__(GD_THREADS, 1) void greedy_decode_kernel(GdArgs a) 
 
     // pending = LSTM(EW[row], (h, c)); g_proj from its output
     auto pending = [&](int row) {
-        gd_gemv(a.Whh, nullptr, h, gates, 4 * Hp, Hp, wave, lane);
+        gd_gemv<WT>(a.Whh, nullptr, h, gates, 4 * Hp, Hp, wave, lane);
         __syncthreads();
         const float* ew = a.EW + (size_t)row * 4 * Hp;
         for (int u = tid; u < Hp; u += GD_THREADS) {   // torch.nn.LSTM gate order i, f, g, o
@@ -87,7 +139,7 @@ __global__ __launch_bounds__(GD_THREADS, 1) void greedy_decode_kernel(GdArgs a) 
             hn[u] = go * tanhf(cc);
         }
         __syncthreads();
-        gd_gemv(a.Wpred, a.bpred, hn, gproj, Hj, Hp, wave, lane);
+        gd_gemv<WT>(a.Wpred, a.bpred, hn, gproj, Hj, Hp, wave, lane);
         __syncthreads();
     };
 
@@ -98,7 +150,7 @@ __global__ __launch_bounds__(GD_THREADS, 1) void greedy_decode_kernel(GdArgs a) 
         for (int s = 0; s < a.max_symbols; ++s) {
             for (int i = tid; i < Hj; i += GD_THREADS) act[i] = fmaxf(f[i] + gproj[i], 0.f);
             __syncthreads();
-            gd_gemv(a.Whead, a.bhead, act, logit, V, Hj, wave, lane);
+            gd_gemv<WT>(a.Whead, a.bhead, act, logit, V, Hj, wave, lane);
             __syncthreads();
             if (wave == 0) {   // argmax, first maximum
                 float best = -3.4e38f; int bi = 0;
@@ -147,14 +199,14 @@ extern "C" int ia_greedy_decode_lds_bytes(int Hp, int Hj, int V) {
     return (int)((size_t)(8 * Hp + 2 * Hj + V + 16) * sizeof(float));
 }
 
-extern "C" int ia_greedy_rnnt_decode(const float* f_all, const int64_t* out_len, const float* EW, const float* Whh,
-                                     const float* Wpred, const float* bpred, const float* Whead, const float* bhead, int B, int T,
-                                     int Hp, int Hj, int V, int blank, int row_blank, int row_sos, int max_symbols, int* tokens,
-                                     int cap, int* counts, int* overflow, ia_stream_t stream) {
+namespace {
+int gd_launch(const float* f_all, const int64_t* out_len, const float* EW, const void* Whh, const void* Wpred, const float* bpred,
+              const void* Whead, const float* bhead, int B, int T, int Hp, int Hj, int V, int blank, int row_blank, int row_sos,
+              int max_symbols, int* tokens, int cap, int* counts, int* overflow, bool bf16_weights, ia_stream_t stream) {
     if (!f_all || !out_len || !EW || !Whh || !Wpred || !bpred || !Whead || !bhead || !tokens || !counts || !overflow || B <= 0 ||
         T <= 0 || V <= 0 || cap <= 0 || max_symbols <= 0 || blank < 0 || blank >= V)
         return IA_INVALID_VALUE;
-    if (Hp % 4 != 0 || Hj % 4 != 0) return IA_UNSUPPORTED;
+    if (Hp % 4 != 0 || Hj % 4 != 0 || (bf16_weights && (Hp % 8 != 0 || Hj % 8 != 0))) return IA_UNSUPPORTED;
     if (!ia_is_aligned(f_all, 16) || !ia_is_aligned(EW, 16) || !ia_is_aligned(Whh, 16) || !ia_is_aligned(Wpred, 16) ||
         !ia_is_aligned(Whead, 16))
         return IA_INVALID_VALUE;
@@ -164,8 +216,32 @@ extern "C" int ia_greedy_rnnt_decode(const float* f_all, const int64_t* out_len,
     a.f_all = f_all; a.out_len = out_len; a.EW = EW; a.Whh = Whh; a.Wpred = Wpred; a.bpred = bpred; a.Whead = Whead; a.bhead = bhead;
     a.tokens = tokens; a.counts = counts; a.overflow = overflow; a.B = B; a.T = T; a.Hp = Hp; a.Hj = Hj; a.V = V; a.blank = blank;
     a.row_blank = row_blank; a.row_sos = row_sos; a.max_symbols = max_symbols; a.cap = cap;
-    IA_SET_MAX_LDS_ONCE(greedy_decode_kernel, lds);
-    hipLaunchKernelGGL(greedy_decode_kernel, dim3(B), dim3(GD_THREADS), lds, (hipStream_t)stream, a);
+    if (bf16_weights) {
+        IA_SET_MAX_LDS_ONCE(greedy_decode_kernel<__bf16>, lds);
+        hipLaunchKernelGGL(greedy_decode_kernel<__bf16>, dim3(B), dim3(GD_THREADS), lds, (hipStream_t)stream, a);
+    } else {
+        IA_SET_MAX_LDS_ONCE(greedy_decode_kernel<float>, lds);
+        hipLaunchKernelGGL(greedy_decode_kernel<float>, dim3(B), dim3(GD_THREADS), lds, (hipStream_t)stream, a);
+    }
     IA_RETURN_IF_LAUNCH_FAILED();
     return IA_OK;
+}
+}  // namespace
+
+extern "C" int ia_greedy_rnnt_decode(const float* f_all, const int64_t* out_len, const float* EW, const float* Whh,
+                                     const float* Wpred, const float* bpred, const float* Whead, const float* bhead, int B, int T,
+                                     int Hp, int Hj, int V, int blank, int row_blank, int row_sos, int max_symbols, int* tokens,
+                                     int cap, int* counts, int* overflow, ia_stream_t stream) {
+    return gd_launch(f_all, out_len, EW, Whh, Wpred, bpred, Whead, bhead, B, T, Hp, Hj, V, blank, row_blank, row_sos, max_symbols, tokens,
+                     cap, counts, overflow, false, stream);
+}
+
+// The same loop on the bf16 images of W_hh [4 Hp, Hp], W_pred [Hj, Hp] and the head [V, Hj] (row-major bf16; Hp, Hj multiples
+// of 8): the decode of a model that trains in bf16.
+extern "C" int ia_greedy_rnnt_decode_bf16w(const float* f_all, const int64_t* out_len, const float* EW, const void* Whh_bf16,
+                                           const void* Wpred_bf16, const float* bpred, const void* Whead_bf16, const float* bhead,
+                                           int B, int T, int Hp, int Hj, int V, int blank, int row_blank, int row_sos,
+                                           int max_symbols, int* tokens, int cap, int* counts, int* overflow, ia_stream_t stream) {
+    return gd_launch(f_all, out_len, EW, Whh_bf16, Wpred_bf16, bpred, Whead_bf16, bhead, B, T, Hp, Hj, V, blank, row_blank, row_sos,
+                     max_symbols, tokens, cap, counts, overflow, true, stream);
 }

@@ -143,16 +143,26 @@ def greedy_rnnt_decode_device(model, encoded, encoded_len, language_ids, max_sym
     counts = torch.zeros(B, dtype=torch.int32, device=dev)
     overflow = torch.zeros(1, dtype=torch.int32, device=dev)
     out_len = encoded_len.to(dev).long().contiguous()
-    def snap(p):   # fp32 contiguous image; with `defer` a private COPY: the optimizer may rewrite the weights while the loop runs
+    # a model that trains in bf16 decodes on the bf16 images of W_hh / W_pred / the head (what its training step multiplies
+    # with, kept current by the fused optimizer: ops/fast.bf16_shadow): half the bytes per emitted symbol of a loop bound by
+    # the CU's L2 bandwidth; an fp32 model decodes in fp32
+    w16 = model.cfg.compute_dtype == "bf16" and Hp % 8 == 0 and Hj % 8 == 0
+
+    def snap(p, image16=False):   # contiguous image; with `defer` a private COPY: the optimizer may rewrite the weights meanwhile
+        if image16:
+            from .ops import fast
+            t = fast.bf16_shadow(p)
+            return t.clone() if defer else t
         t = p.detach().float().contiguous()
         return t.clone() if (defer and t.data_ptr() == p.data_ptr()) else t
 
-    Whh = snap(lstm.weight_hh_l0)
-    Wp, bp = snap(joint.pred.weight), snap(joint.pred.bias)
-    Wh, bh = snap(head.weight), snap(head.bias)
-    st = L.ia_greedy_rnnt_decode(_lib.ptr(f_all), _lib.ptr(out_len), _lib.ptr(EW), _lib.ptr(Whh), _lib.ptr(Wp), _lib.ptr(bp),
-                                 _lib.ptr(Wh), _lib.ptr(bh), B, T, Hp, Hj, V, blank, blank, V, ms, _lib.ptr(tokens), cap,
-                                 _lib.ptr(counts), _lib.ptr(overflow), _lib.stream_ptr())
+    Whh = snap(lstm.weight_hh_l0, w16)
+    Wp, bp = snap(joint.pred.weight, w16), snap(joint.pred.bias)
+    Wh, bh = snap(head.weight, w16), snap(head.bias)
+    entry = L.ia_greedy_rnnt_decode_bf16w if w16 else L.ia_greedy_rnnt_decode
+    st = entry(_lib.ptr(f_all), _lib.ptr(out_len), _lib.ptr(EW), _lib.ptr(Whh), _lib.ptr(Wp), _lib.ptr(bp),
+               _lib.ptr(Wh), _lib.ptr(bh), B, T, Hp, Hj, V, blank, blank, V, ms, _lib.ptr(tokens), cap,
+               _lib.ptr(counts), _lib.ptr(overflow), _lib.stream_ptr())
     _lib.check(st, "ia_greedy_rnnt_decode")
     if defer:
         h_tok, h_n, h_ovf = _pinned_async(tokens), _pinned_async(counts), _pinned_async(overflow)
