@@ -288,6 +288,21 @@ int ia_greedy_rnnt_decode_bf16w(const float* f_all, const int64_t* out_len, cons
                                 const void* Wpred_bf16, const float* bpred, const void* Whead_bf16, const float* bhead, int B, int T,
                                 int Hp, int Hj, int V, int blank, int row_blank, int row_sos, int max_symbols, int* tokens, int cap,
                                 int* counts, int* overflow, ia_stream_t stream);
+/* The bf16 decode restructured (same reference loop, rnnt_greedy_decoding.py:711-909; Hj % 32 == 0, Hp % 8 == 0): the head is
+ * evaluated for 16 frames at once on the matrix cores (activations rounded to bf16 as the training step's joint does; blanks
+ * advance the frame, the first non-blank emits and the evaluation restarts there), and the per-symbol GEMVs are split over
+ * `cluster` workgroups per utterance that hand h' and g over through `scratch`.  ia_greedy_decode_cluster = the cluster size
+ * the library would pick (0: dimensions not taken, the GEMV loop of ia_greedy_rnnt_decode_bf16w decodes; Hp % (8 cluster) == 0,
+ * Hj % (4 cluster) == 0, 8 ceil(B / 8) cluster <= 256); scratch = ia_greedy_decode_scratch_bytes, 16-byte aligned (NULL allowed for
+ * cluster <= 1).  *overflow: bit 0 = an utterance emitted more than cap symbols, bit 1 = a cluster hand-off timed out.
+ * ia_greedy_rnnt_decode_bf16w itself runs this kernel with cluster = 1 when it takes the dimensions. */
+size_t ia_greedy_decode_scratch_bytes(int B, int Hp, int Hj);
+int ia_greedy_decode_cluster(int B, int Hp, int Hj);
+int ia_greedy_rnnt_decode_bf16w_ex(const float* f_all, const int64_t* out_len, const float* EW, const void* Whh_bf16,
+                                   const void* Wpred_bf16, const float* bpred, const void* Whead_bf16, const float* bhead, int B,
+                                   int T, int Hp, int Hj, int V, int blank, int row_blank, int row_sos, int max_symbols, int* tokens,
+                                   int cap, int* counts, int* overflow, int cluster, void* scratch, size_t scratch_bytes,
+                                   ia_stream_t stream);
 
 /* fp8 (OCP e4m3) projections of the frozen prefix (csrc/gemm_fp8.hip; BASELINE configs[4] "fp8 MFMA"; no reference
  * semantics -- tolerance vs the fp32 oracle stated in tests/test_fp8_gpu.py):

@@ -159,30 +159,42 @@ def greedy_rnnt_decode_device(model, encoded, encoded_len, language_ids, max_sym
     Whh = snap(lstm.weight_hh_l0, w16)
     Wp, bp = snap(joint.pred.weight, w16), snap(joint.pred.bias)
     Wh, bh = snap(head.weight, w16), snap(head.bias)
-    entry = L.ia_greedy_rnnt_decode_bf16w if w16 else L.ia_greedy_rnnt_decode
-    st = entry(_lib.ptr(f_all), _lib.ptr(out_len), _lib.ptr(EW), _lib.ptr(Whh), _lib.ptr(Wp), _lib.ptr(bp),
-               _lib.ptr(Wh), _lib.ptr(bh), B, T, Hp, Hj, V, blank, blank, V, ms, _lib.ptr(tokens), cap,
-               _lib.ptr(counts), _lib.ptr(overflow), _lib.stream_ptr())
+    args = (_lib.ptr(f_all), _lib.ptr(out_len), _lib.ptr(EW), _lib.ptr(Whh), _lib.ptr(Wp), _lib.ptr(bp),
+            _lib.ptr(Wh), _lib.ptr(bh), B, T, Hp, Hj, V, blank, blank, V, ms, _lib.ptr(tokens), cap,
+            _lib.ptr(counts), _lib.ptr(overflow))
+    scratch = None
+    if w16:
+        # head over 16 frames at once on the matrix cores, the per-symbol GEMVs split over a cluster of workgroups per utterance
+        nw = int(L.ia_greedy_decode_cluster(B, Hp, Hj))
+        scratch = torch.empty(int(L.ia_greedy_decode_scratch_bytes(B, Hp, Hj)), dtype=torch.uint8, device=dev) if nw > 1 else None
+        st = L.ia_greedy_rnnt_decode_bf16w_ex(*args, nw, _lib.ptr(scratch) if scratch is not None else None,
+                                              scratch.numel() if scratch is not None else 0, _lib.stream_ptr())
+    else:
+        st = L.ia_greedy_rnnt_decode(*args, _lib.stream_ptr())
     _lib.check(st, "ia_greedy_rnnt_decode")
+
+    def check_flags(ovf):
+        if ovf & 2:
+            raise RuntimeError("greedy_rnnt_decode: a hand-off between the workgroups of an utterance timed out (csrc/greedy_decode.hip); "
+                               "the hypotheses of this batch are not valid")
+        if ovf & 1:
+            raise RuntimeError("greedy_rnnt_decode: an utterance emitted more symbols than the output buffer holds "
+                               f"({cap} per utterance); pass a finite max_symbols")
     if defer:
         h_tok, h_n, h_ovf = _pinned_async(tokens), _pinned_async(counts), _pinned_async(overflow)
         ev = torch.cuda.Event()
         ev.record()
-        keep = [tokens, counts, overflow, f_all, EW, Whh, Wp, bp, Wh, bh, out_len]   # alive until the kernel has run
+        keep = [tokens, counts, overflow, f_all, EW, Whh, Wp, bp, Wh, bh, out_len, scratch]   # alive until the kernel has run
 
         def finish():
             ev.synchronize()
             keep.clear()
-            if int(h_ovf[0]):
-                raise RuntimeError("greedy_rnnt_decode: an utterance emitted more symbols than the output buffer holds "
-                                   f"({cap} per utterance); pass a finite max_symbols")
+            check_flags(int(h_ovf[0]))
             n = h_n.tolist()
             return [h_tok[b, :n[b]].tolist() for b in range(B)]
         return PendingHyps(finish)
     host_tok, host_n, ovf = tokens.cpu(), counts.cpu().tolist(), int(overflow.item())
-    if ovf:
-        raise RuntimeError("greedy_rnnt_decode: an utterance emitted more symbols than the output buffer holds "
-                           f"({cap} per utterance); pass a finite max_symbols")
+    check_flags(ovf)
     return [host_tok[b, :host_n[b]].tolist() for b in range(B)]
 
 
