@@ -304,6 +304,11 @@ int ia_greedy_rnnt_decode_bf16w_ex(const float* f_all, const int64_t* out_len, c
                                    int cap, int* counts, int* overflow, int cluster, void* scratch, size_t scratch_bytes,
                                    ia_stream_t stream);
 
+/* Host-side scoring of the step's monitor (csrc/host_metrics.hip, no device work): edit distances of n hypothesis / reference
+ * pairs, units as int32 ids (a[a_off[i] .. a_off[i+1]) against b[b_off[i] .. b_off[i+1])) -- editdistance.eval of
+ * A/metrics/wer.py:58-60, batched. */
+int ia_edit_distance_batch(const int32_t* a, const int64_t* a_off, const int32_t* b, const int64_t* b_off, int n, int64_t* out);
+
 /* fp8 (OCP e4m3) projections of the frozen prefix (csrc/gemm_fp8.hip; BASELINE configs[4] "fp8 MFMA"; no reference
  * semantics -- tolerance vs the fp32 oracle stated in tests/test_fp8_gpu.py):
  *   ia_quantize_fp8_rows   q [M, ldq] e4m3 = x / scale[m], scale[m] = amax(row m) / 448 (1 for a zero row); x bf16 or f32

@@ -94,6 +94,7 @@ SIGNATURES = {
     "ia_greedy_decode_lds_bytes": (_i, [_i, _i, _i]),
     "ia_greedy_rnnt_decode": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "ia_greedy_rnnt_decode_bf16w": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
+    "ia_edit_distance_batch": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     "ia_greedy_decode_scratch_bytes": (_sz, [_i, _i, _i]),
     "ia_greedy_decode_cluster": (_i, [_i, _i, _i]),
     "ia_greedy_rnnt_decode_bf16w_ex": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _sz, _vp]),

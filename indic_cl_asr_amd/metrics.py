@@ -21,7 +21,7 @@ from typing import Callable, List, Optional, Sequence
 import torch
 import torch.nn as nn
 
-from .decoding import _edit_distance
+from .decoding import _edit_distance, _edit_distances
 
 
 def _dist_world():
@@ -29,6 +29,17 @@ def _dist_world():
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         return dist
     return None
+
+
+def _sums_device(default):
+    """Where the (edits, units) sums of a host-scored update live.  They are born on the host; they only have to be on the
+    device for an RCCL exchange.  Everywhere else (one process, gloo) they stay host tensors: `torch.tensor(x, device=cuda)` is a
+    synchronous pageable copy on the compute stream, i.e. a wait for everything queued on it -- the whole training step, every
+    time the step's monitor is read."""
+    dist = _dist_world()
+    if dist is not None and dist.get_backend() == "nccl":
+        return default
+    return torch.device("cpu")
 
 
 class WER(nn.Module):
@@ -54,6 +65,11 @@ class WER(nn.Module):
         object.__setattr__(self, "_model", weakref.ref(model))
         return self
 
+    def _device(self):
+        m = self._model()
+        p = next(m.parameters(), None) if m is not None else None
+        return p.device if p is not None else self.scores.device
+
     # ------------------------------------------------------------------ strings
     def decode_tokens_to_str(self, tokens: Sequence[int], lang: Optional[str] = None) -> str:
         m = self._model()
@@ -64,12 +80,8 @@ class WER(nn.Module):
 
     def score(self, hypotheses: List[str], references: List[str]):
         """(sum of edit distances, number of reference units) of string pairs."""
-        scores = words = 0
-        for h, r in zip(hypotheses, references):
-            h_list, r_list = self._units(h), self._units(r)
-            words += len(r_list)
-            scores += _edit_distance(h_list, r_list)
-        return scores, words
+        pairs = [(self._units(h), self._units(r)) for h, r in zip(hypotheses, references)]
+        return sum(_edit_distances(pairs)), sum(len(r) for _, r in pairs)
 
     def hypotheses(self, predictions, predictions_lengths, lang_ids) -> List[List[int]]:
         m = self._model()
@@ -94,8 +106,9 @@ class WER(nn.Module):
             logging.info(f"reference:{references[0]}")
             logging.info(f"predicted:{hyps[0]}")
         s, w = self.score(hyps, references)
-        self.scores = torch.tensor(s, device=self.scores.device, dtype=self.scores.dtype)
-        self.words = torch.tensor(w, device=self.words.device, dtype=self.words.dtype)
+        dev = _sums_device(self._device())
+        self.scores = torch.tensor(s, device=dev, dtype=self.scores.dtype)
+        self.words = torch.tensor(w, device=dev, dtype=self.words.dtype)
 
     @torch.no_grad()
     def update_from_ids(self, hyp_ids: List[List[int]], ref_ids: List[List[int]], lang_ids: Optional[List[str]] = None):
@@ -109,8 +122,9 @@ class WER(nn.Module):
             logging.info(f"reference:{references[0]}")
             logging.info(f"predicted:{hyps[0]}")
         s_, w_ = self.score(hyps, references)
-        self.scores = torch.tensor(s_, device=self.scores.device, dtype=self.scores.dtype)
-        self.words = torch.tensor(w_, device=self.words.device, dtype=self.words.dtype)
+        dev = _sums_device(self._device())
+        self.scores = torch.tensor(s_, device=dev, dtype=self.scores.dtype)
+        self.words = torch.tensor(w_, device=dev, dtype=self.words.dtype)
 
     def compute(self):
         pair = torch.stack([self.scores.detach(), self.words.detach()])
@@ -139,7 +153,7 @@ class WER(nn.Module):
             logging.info(f"reference:{refs[0]}")
             logging.info(f"predicted:{hyps[0]}")
         table = [list(self.score(hyps[b0:b0 + group_size], refs[b0:b0 + group_size])) for b0 in range(0, B, group_size)]
-        t = torch.tensor(table, dtype=torch.int64, device=self.scores.device)
+        t = torch.tensor(table, dtype=torch.int64, device=_sums_device(self._device()))
         dist = _dist_world() if self.dist_sync_on_step else None
         if dist is not None:
             dist.all_reduce(t)

@@ -35,6 +35,21 @@ def test_edit_distance_and_wer_known_answers():
     assert m.compute()[0] == float("inf")
 
 
+def test_native_edit_distance_batch_equals_the_dynamic_programme():
+    """csrc/host_metrics.hip (the `editdistance` extension of wer.py:58-60, batched) against the plain two-row programme on
+    random token, word and character sequences, empty sides included."""
+    import random
+    from indic_cl_asr_amd.decoding import _edit_distance_py, _edit_distances
+    rnd = random.Random(3)
+    pairs = [([rnd.randint(0, 12) for _ in range(rnd.randint(0, 90))], [rnd.randint(0, 12) for _ in range(rnd.randint(0, 60))])
+             for _ in range(40)]
+    pairs += [([], [1, 2, 3]), ([4], []), ([], []), ([7] * 50, [7] * 50)]
+    words = "the cat sat on a mat with one red hat and two big dogs too".split()
+    pairs += [([rnd.choice(words) for _ in range(rnd.randint(5, 40))], [rnd.choice(words) for _ in range(rnd.randint(5, 40))]) for _ in range(10)]
+    pairs += [(list("kitten sitting on the mitten"), list("sitting kitten in the kitchen"))]
+    assert _edit_distances(pairs) == [_edit_distance_py(a, b) for a, b in pairs]
+
+
 def test_greedy_rnnt_matches_per_utterance_oracle_cpu():
     from indic_cl_asr_amd.decoding import greedy_rnnt_decode
     o, m = _models()
