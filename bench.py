@@ -221,7 +221,9 @@ def main():
                          "R/cl_baseline_mas.py:258-270); LwF teacher + student step (configs[3], R/cl_baseline_lwf.py:212-264)")
     ap.add_argument("--fp8-prefix", action="store_true", help="e4m3 projections in the frozen prefix (BASELINE configs[4]; never the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-wer-leg", action="store_true", help="skip the extra leg that decodes every batch for the monitor's WER")
+    ap.add_argument("--no-wer", action="store_true", help="timed steps WITHOUT the in-step greedy decode + WER of the reference's "
+                                                         "training_step (compute_wer = True there); default: with it, monitor read after every step")
+    ap.add_argument("--no-wer-leg", action="store_true", help="skip the extra leg that times the step the other way round (without / with the in-step WER)")
     ap.add_argument("--no-peaks", action="store_true", help="skip the on-box copy / MFMA peak microbenchmarks")
     ap.add_argument("--grad-exchange", default="fp32", choices=["fp32", "bf16"], help="dtype of the data-parallel gradient all-reduce")
     ap.add_argument("--cpu-sample-bs", type=int, default=4)
@@ -295,13 +297,23 @@ def main():
     teacher = cl.get_params_clone(model) if args.cl == "lwf" else None
     m_ = getattr(model, "module", model)
 
+    wer_on = args.cl == "ewc" and not args.no_wer
+    last_monitor = [None]
+    if wer_on:
+        m_.wer.log_prediction = False; m_.ctc_wer.log_prediction = False       # R/cl_baseline.py:127-128
+
     def step():
         opt.zero_grad()
         if args.cl == "ewc":
-            loss, monitor = model.training_step(batch, langs, host_lengths=host_lens)
+            # the reference's step decodes every training batch greedily for the monitor's two WERs (compute_wer = True,
+            # hybrid_rnnt_ctc_models.py:875) and its loops log the monitor after every optimizer step (R/cl_baseline.py:198-206)
+            loss, monitor = model.training_step(batch, langs, host_lengths=host_lens, compute_wer=wer_on)
             monitor['ewc_penalty'] = cl.ewc_penalty_into_grads(flat, fisher, checkpoint, e_lambda=10.0)
             loss.backward()
             opt.step()
+            if wer_on:
+                last_monitor[0] = monitor
+                _ = monitor["training_batch_wer"]
         elif args.cl == "mas_importance":   # the importance pass after a task: |d (logit L2 norms) / d theta| accumulated into omega
             m_.joint.store_sub_logits = True; m_.ctc_decoder.return_logits_ = True
             loss, monitor = model.training_step(batch, langs, host_lengths=host_lens)
@@ -347,27 +359,30 @@ def main():
                     "note": "one flat all-reduce per step on its own communicator, launched at optimizer.step() and waited for in "
                             "front of the first trainable module of the NEXT forward (under the frozen prefix); exposed = how long "
                             "the compute stream stalls there"}
-    # ---- the reference-complete step: every batch decoded greedily for the monitor's two WERs (compute_wer = True in
-    # hybrid_rnnt_ctc_models.py:875; device-resident decode + host edit distance + the 2-int cross-rank sums)
+    # ---- the step the other way round: without the in-step decode + WER when the timed steps have it (what it costs), with it
+    # when they were run with --no-wer
     wer_leg = None
     if args.cl == "ewc" and not args.no_wer_leg:
-        n3 = max(5, args.steps // 5)
+        other = not wer_on
+        n3 = max(5, args.steps // 2)
         m_.wer.log_prediction = False; m_.ctc_wer.log_prediction = False       # R/cl_baseline.py:127-128
-        for _ in range(2):
+
+        def other_step():
             opt.zero_grad()
-            l3, mon3 = model.training_step(batch, langs, host_lengths=host_lens, compute_wer=True)
+            l3, mon3 = model.training_step(batch, langs, host_lengths=host_lens, compute_wer=other)
             cl.ewc_penalty_into_grads(flat, fisher, checkpoint, e_lambda=10.0)
             l3.backward(); opt.step()
+            if other:
+                _ = mon3["training_batch_wer"]
+            return mon3
+        for _ in range(2):
+            other_step()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t3 = time.perf_counter()
         for _ in range(n3):
-            opt.zero_grad()
-            l3, mon3 = model.training_step(batch, langs, host_lengths=host_lens, compute_wer=True)
-            cl.ewc_penalty_into_grads(flat, fisher, checkpoint, e_lambda=10.0)
-            l3.backward(); opt.step()
-            _ = mon3["training_batch_wer"]     # the loops log the monitor after every optimizer step (R/cl_baseline.py:198-206)
+            mon3 = other_step()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -376,11 +391,10 @@ def main():
             t = torch.tensor([d3], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             d3 = float(t.item())
-        wer_leg = {"value": round(world * args.batch * n3 / d3, 1), "ms_per_step": round(d3 / n3 * 1e3, 3), "steps": n3,
-                   "training_batch_wer": float(mon3["training_batch_wer"]), "training_batch_wer_ctc": float(mon3["training_batch_wer_ctc"]),
-                   "note": "token-level rates on random-initialised weights (no tokenizer / checkpoint in the build); the greedy decode "
-                           "runs on a side stream beside the joint / backward / optimizer and is scored when the monitor is read, "
-                           "here after every optimizer step as the reference's loops do"}
+        wer_leg = {"in_step_wer": other, "value": round(world * args.batch * n3 / d3, 1), "ms_per_step": round(d3 / n3 * 1e3, 3), "steps": n3}
+        if other:
+            wer_leg["training_batch_wer"] = float(mon3["training_batch_wer"])
+            wer_leg["training_batch_wer_ctc"] = float(mon3["training_batch_wer_ctc"])
     # ---- the same step fed from pinned host memory (one batch ahead on a copy stream): PCIe-inclusive rate, never `value`
     h2d = None
     if world == 1 and args.cl == "ewc":
@@ -402,10 +416,12 @@ def main():
             for t in devb:
                 t.record_stream(torch.cuda.current_stream(dev))
             opt.zero_grad()
-            l2, mon2 = model.training_step(devb, langs, host_lengths=host_lens)
+            l2, mon2 = model.training_step(devb, langs, host_lengths=host_lens, compute_wer=wer_on)
             cl.ewc_penalty_into_grads(flat, fisher, checkpoint, e_lambda=10.0)
             l2.backward()
             opt.step()
+            if wer_on:
+                _ = mon2["training_batch_wer"]
         torch.cuda.synchronize()
         d2 = time.perf_counter() - t1
         h2d = {"value": round(args.batch * n2 / d2, 1), "ms_per_step": round(d2 / n2 * 1e3, 3), "steps": n2,
@@ -431,7 +447,16 @@ def main():
                        "global_batch": world * args.batch, "parallelism": f"dp{world}",
                        "final_loss": round(float(loss.item()), 4),
                        "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 3),
-                       "with_h2d_prefetch": h2d, "with_wer": wer_leg, "exchange": exchange},
+                       "in_step_wer": ({"enabled": True,
+                                        "training_batch_wer": float(last_monitor[0]["training_batch_wer"]),
+                                        "training_batch_wer_ctc": float(last_monitor[0]["training_batch_wer_ctc"]),
+                                        "note": "the timed steps are the reference-complete step: every batch decoded greedily "
+                                                "(compute_wer = True, hybrid_rnnt_ctc_models.py:875) on a side stream beside the joint / "
+                                                "backward / optimizer, both WERs scored when the monitor is read -- after every optimizer "
+                                                "step, as the reference's loops do; token-level rates on random-initialised weights (no "
+                                                "tokenizer / checkpoint in the build)"}
+                                       if (wer_on and last_monitor[0] is not None) else {"enabled": False}),
+                       "with_h2d_prefetch": h2d, ("without_wer" if wer_on else "with_wer"): wer_leg, "exchange": exchange},
         }
         peaks = None
         if not args.no_peaks:

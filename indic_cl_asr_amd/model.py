@@ -277,11 +277,18 @@ class EncDecHybridRNNTCTCModel(TranscriptionMixin, nn.Module):
         def fn():
             done.synchronize()
             refs = [row[:n] for row, n in zip(refs_h.tolist(), lens)]
-            wer, _, _ = self.wer.grouped(hyps_p.result(), refs, language_ids, group)
-            self.ctc_wer.update_from_ids(ctc_p.result(), refs, language_ids)
-            ctc_wer, _, _ = self.ctc_wer.compute()
-            self.ctc_wer.reset()
-            return {'training_batch_wer': wer, 'training_batch_wer_ctc': ctc_wer.item()}
+            # scored under the decode's stream: whatever device work the sums need (an RCCL exchange of the (edits, units) pairs
+            # over several ranks -- nothing in one process) then orders behind the decode only, not behind the training step
+            # queued on the compute stream
+            with torch.cuda.stream(stream):
+                wer, _, _ = self.wer.grouped(hyps_p.result(), refs, language_ids, group)
+                self.ctc_wer.update_from_ids(ctc_p.result(), refs, language_ids)
+                ctc_wer, _, _ = self.ctc_wer.compute()
+                self.ctc_wer.reset()
+                ctc_wer = ctc_wer.item()
+                if torch.is_tensor(wer) and wer.is_cuda:
+                    stream.synchronize()         # the caller reads it from another stream
+            return {'training_batch_wer': wer, 'training_batch_wer_ctc': ctc_wer}
         return fn
 
     # ------------------------------------------------------------------ training_step (:859-930)
