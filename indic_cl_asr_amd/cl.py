@@ -319,7 +319,7 @@ def lwf_teacher_forward(model, flat: FlatParams, teacher: FlatDict, batch, lang_
     with torch.no_grad(), flat.weights(teacher):
         m.joint.store_sub_enc, m.joint.detach_sub_enc = True, True
         step = m._step
-        _, _, prob_ = m.training_step(batch, lang_ids, return_probs=True, host_lengths=host_lengths)
+        _, _, prob_ = m.training_step(batch, lang_ids, return_probs=True, host_lengths=host_lengths, compute_wer=False)
         m._step = step  # same SpecAugment/dither draw for the student pass
         store_list = m.joint.store_list
     return prob_, store_list

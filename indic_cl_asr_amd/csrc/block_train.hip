@@ -163,6 +163,8 @@ BwdWs bwd_ws(int B, int T, int d, int d_ff, int ksz) {
                                      {nullptr, nullptr, nullptr, nullptr, d, d_ff, (int)N, d, d_ff},
                                      {nullptr, nullptr, nullptr, nullptr, d_ff, d, (int)N, d_ff, d}};
         scr = max3(scr, (size_t)ia_gemm_tn_grouped_scratch_elems(ga, 5), (size_t)ia_gemm_tn_grouped_scratch_elems(gb, 4));
+        // (with the side stream, part 2 launches its four as two groups of two: fewer problems per launch = more splits each)
+        scr = max3(scr, (size_t)ia_gemm_tn_grouped_scratch_elems(gb, 2), (size_t)ia_gemm_tn_grouped_scratch_elems(gb + 2, 2));
     }
     w.scr = o;  o = up256(o + scr * 4);
     w.total = o;
@@ -197,6 +199,44 @@ int linear_bwd_deferred(const void* dY, const void* X, const void* W, int M, int
     if (dX) IA_TRY(ia_gemm_bf16(dY, n, wt, n, M, k, n, nullptr, 0, 0.f, 0, 1.f, nullptr, 0, nullptr, 0, dX, k, stream));
     grp[*ngrp] = ia_tn_problem{dY, X, dW, db, n, k, M, n, k};
     ++*ngrp;
+    return IA_OK;
+}
+
+// ---- weight gradients beside the data-gradient chain.  A block's backward is a serial chain of small data-gradient launches
+// (LayerNorm backward, 384-workgroup GEMMs, ~10 us each: latency-bound, the GPU is far from full) with the weight-gradient work
+// hanging off it: the grouped split-K GEMMs + their finishing sums, the depthwise convolution's weight gradient, the LayerNorm
+// gamma / beta sums and the multi-tensor add -- a third of the block's launch time, none of it on the chain.  They run on ONE
+// internal side stream per device (in order among themselves, so they keep sharing the workspace's scratch), forked behind the
+// launch that produces their last operand and joined (i) before the chain overwrites an operand they read and (ii) at the end of
+// the second backward call, so that nothing outlives the call pair: callers see the same stream semantics as before.
+// MEASURED (round 3, bench step, A/B on one box): 8.58-8.60 ms with the side stream against 8.51 without -- the chain's launches
+// lose more to the weight-gradient workgroups that now sit on their CUs than the overlap returns (and a lowest-priority side
+// stream starves behind the persistent LSTM workgroups: 18 ms).  So it is OFF by default, IA_WGRAD_SIDE=1 switches it on; the
+// same gradients either way (tests/test_block_native_gpu.py).
+struct SideCtx {
+    hipStream_t s = nullptr;
+    hipEvent_t ev[8] = {};
+    bool ok = false, tried = false;
+    bool a_pending = false;   // part 1 left work on the side stream that part 2 has to join
+};
+SideCtx* side_ctx() {
+    static SideCtx ctx[16];
+    const char* e = getenv("IA_WGRAD_SIDE");   // (read per call: tests/test_block_native_gpu.py compares both ways in one process)
+    if (!(e && e[0] == '1')) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    SideCtx& c = ctx[dev];
+    if (!c.tried) {
+        c.tried = true;
+        bool ok = hipStreamCreateWithFlags(&c.s, hipStreamNonBlocking) == hipSuccess;
+        for (int i = 0; ok && i < 8; ++i) ok = hipEventCreateWithFlags(&c.ev[i], hipEventDisableTiming) == hipSuccess;
+        c.ok = ok;
+    }
+    return c.ok ? &c : nullptr;
+}
+// `to` continues behind everything issued on `from` so far
+int stream_after(hipStream_t from, hipStream_t to, hipEvent_t ev) {
+    if (hipEventRecord(ev, from) != hipSuccess || hipStreamWaitEvent(to, ev, 0) != hipSuccess) return IA_LAUNCH_FAILED;
     return IA_OK;
 }
 
@@ -345,14 +385,28 @@ extern "C" int ia_conformer_block_bwd_a_phase(const ia_block_params* Lp, const i
     // GLU -> depthwise conv backward: data gradient straight through the GLU backward, weight gradient on the regenerated
     // mask(GLU(c2)) -- two launches (+ the finishing sum) instead of four, no dG / G tensors
     IA_TRY(ia_dwconv_glu_bwd(dz, S.c2, lens, B, T, d, ksz, L.dw_w, dc2, stream));
-    IA_TRY(ia_dwconv_glu_wgrad(S.c2, lens, dz, B, T, d, ksz, G.dw_w, G.dw_b, scr, stream));
+    SideCtx* side = phase == 0 ? side_ctx() : nullptr;   // (the SyncBatchNorm phases keep one stream)
+    hipStream_t main = (hipStream_t)stream;
+    if (side) {   // dz and the scratch are free for the side stream from here on (the chain below touches neither)
+        IA_TRY(stream_after(main, side->s, side->ev[0]));
+        IA_TRY(ia_dwconv_glu_wgrad(S.c2, lens, dz, B, T, d, ksz, G.dw_w, G.dw_b, scr, (ia_stream_t)side->s));
+    } else {
+        IA_TRY(ia_dwconv_glu_wgrad(S.c2, lens, dz, B, T, d, ksz, G.dw_w, G.dw_b, scr, stream));
+    }
     IA_TRY(linear_bwd_deferred(dc2, S.y3, L.w_pw1, N, 2 * d, d, dy, G.w_pw1, G.b_pw1, wt_pw1, grp, &ngrp, stream));
     IA_TRY(ia_layernorm_bwd_drop(S.x2, d, nullptr, dy, d, N, d, L.ln_conv_g, L.ln_eps, dxb, dxa, d, nullptr, nullptr, 1.f, p,
                                  seed + 3, dB2, d, lnp + 2 * lnp_set, stream));  // d x2 -> dxa
     // linear_out
     IA_TRY(linear_bwd_deferred(dB2, S.ctxv, L.w_out, N, d, d, dctx, G.w_out, G.b_out, wt_out, grp, &ngrp, stream));
     // the five weight (+ bias) gradients of this half in one GEMM launch + one finishing launch
-    IA_TRY(flush_group(grp, ngrp, scr, stream));
+    if (side) {   // ... under the attention core's backward; part 2 joins before it overwrites dB / dhp
+        IA_TRY(stream_after(main, side->s, side->ev[1]));
+        IA_TRY(flush_group(grp, ngrp, scr, (ia_stream_t)side->s));
+        if (hipEventRecord(side->ev[2], side->s) != hipSuccess) return IA_LAUNCH_FAILED;
+        side->a_pending = true;
+    } else {
+        IA_TRY(flush_group(grp, ngrp, scr, stream));
+    }
     *dx2_out = dxa;
     *dctx_out = dctx;
     return IA_OK;
@@ -390,17 +444,42 @@ extern "C" int ia_conformer_block_bwd_b(const ia_block_params* Lp, const ia_bloc
         IA_TRY(tr_launch(tl, (hipStream_t)stream));
     }
     // q|k|v projection (dW rows q, k, v contiguous; bias likewise) and the bias-free position projection
+    SideCtx* side = side_ctx();
+    hipStream_t main = (hipStream_t)stream;
     IA_TRY(linear_bwd_deferred(dqkv, S.y2, L.w_qkv, N, 3 * d, d, dy, G.w_qkv, G.b_qkv, wt_qkv, grp, &ngrp, stream));
     grp[ngrp++] = ia_tn_problem{dpl, pos_emb, G.w_pos, nullptr, d, d, pos_rows, d, d};
+    if (side) {
+        // these two only need the attention backward's outputs: on the side stream (behind part 1's group) now, under the chain
+        IA_TRY(stream_after(main, side->s, side->ev[3]));
+        IA_TRY(flush_group(grp, ngrp, scr, (ia_stream_t)side->s));
+        ngrp = 0;
+        if (side->a_pending) {   // part 1's group (event recorded behind it) read dB / dhp, which the chain rewrites from here on
+            if (hipStreamWaitEvent(main, side->ev[2], 0) != hipSuccess) return IA_LAUNCH_FAILED;
+            side->a_pending = false;
+        }
+    }
     IA_TRY(ia_layernorm_bwd_drop(S.x1, d, nullptr, dy, d, N, d, L.ln_att_g, L.ln_eps, dxa, dxb, d, nullptr, nullptr, L.fc_factor,
                                  p, seed + 2, dB, d, lnp + 3 * lnp_set, stream));   // d x1 -> dxb
     // feed_forward1
     IA_TRY(ia_gemm_bf16_ex(dB, d, wt_ff1b, d, N, d_ff, d, nullptr, 3, pff, seed + 1, 1.f, nullptr, 0, nullptr, 0, dhp, d_ff, nullptr, 0,
                            S.h1p, d_ff, stream));
     IA_TRY(linear_bwd_deferred(dB, S.h1, L.w_ff1b, N, d, d_ff, nullptr, G.w_ff1b, G.b_ff1b, wt_ff1b, grp, &ngrp, stream));
-    IA_TRY(linear_bwd_deferred(dhp, S.y1, L.w_ff1a, N, d_ff, d, dy, G.w_ff1a, G.b_ff1a, wt_ff1a, grp, &ngrp, stream));
+    if (side) {   // dB and dhp are final: the feed-forward weight gradients run under the last two launches of the chain
+        grp[ngrp++] = ia_tn_problem{dhp, S.y1, G.w_ff1a, G.b_ff1a, d_ff, d, N, d_ff, d};
+        IA_TRY(stream_after(main, side->s, side->ev[4]));
+        IA_TRY(flush_group(grp, ngrp, scr, (ia_stream_t)side->s));
+        ngrp = 0;
+        IA_TRY(ia_gemm_bf16(dhp, d_ff, wt_ff1a, d_ff, N, d, d_ff, nullptr, 0, 0.f, 0, 1.f, nullptr, 0, nullptr, 0, dy, d, stream));
+    } else {
+        IA_TRY(linear_bwd_deferred(dhp, S.y1, L.w_ff1a, N, d_ff, d, dy, G.w_ff1a, G.b_ff1a, wt_ff1a, grp, &ngrp, stream));
+    }
     IA_TRY(ia_layernorm_bwd(x0, d, nullptr, dy, d, N, d, L.ln_ff1_g, L.ln_eps, dxb, dx0, d, nullptr, nullptr, lnp + 4 * lnp_set, stream));
-    IA_TRY(flush_group(grp, ngrp, scr, stream));   // the four weight gradients of this half, before the multi-tensor add
+    if (side) {   // the LayerNorm sums and the multi-tensor add follow the groups on the side stream; the caller's stream joins at the end
+        IA_TRY(stream_after(main, side->s, side->ev[5]));
+        stream = (ia_stream_t)side->s;
+    } else {
+        IA_TRY(flush_group(grp, ngrp, scr, stream));   // the four weight gradients of this half, before the multi-tensor add
+    }
     {   // d gamma | d beta of the block's five LayerNorms: one finishing launch
         const int rows = ia_layernorm_bwd_partial_rows(N);
         const ia_finish_job jobs[5] = {{lnp + 0 * lnp_set, rows, 2 * d, d, G.ln_out_g, G.ln_out_b},
@@ -415,5 +494,6 @@ extern "C" int ia_conformer_block_bwd_b(const ia_block_params* Lp, const ia_bloc
                            (const AddRow*)add_table, n_add);
         IA_RETURN_IF_LAUNCH_FAILED();
     }
+    if (side) IA_TRY(stream_after(side->s, main, side->ev[6]));   // nothing of this block is left in flight behind the caller's stream
     return IA_OK;
 }

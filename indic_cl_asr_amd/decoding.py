@@ -120,7 +120,20 @@ def _pinned_async(t):
 
 @torch.no_grad()
 def greedy_rnnt_decode(model, encoded, encoded_len, language_ids, max_symbols: Optional[int] = 10) -> List[List[int]]:
-    """encoded [B,d,T'] (encoder output), encoded_len [B] -> per-utterance language-local token ids."""
+    """encoded [B,d,T'] (encoder output), encoded_len [B] -> per-utterance language-local token ids.  A batch that mixes
+    languages is decoded language by language (every utterance goes through its own language's head, rnnt.py:1632-1640;
+    utterances decode independently of their neighbours)."""
+    langs = list(language_ids)
+    if len(set(langs)) > 1:
+        out = [None] * len(langs)
+        for lang in dict.fromkeys(langs):
+            idx = [i for i, l in enumerate(langs) if l == lang]
+            sel = torch.tensor(idx, device=encoded.device)
+            sub = greedy_rnnt_decode(model, encoded.index_select(0, sel), encoded_len.to(encoded.device).index_select(0, sel),
+                                     [lang] * len(idx), max_symbols)
+            for i, h in zip(idx, sub):
+                out[i] = h
+        return out
     if encoded.is_cuda and device_decode_supported(model):
         return greedy_rnnt_decode_device(model, encoded, encoded_len, language_ids, max_symbols)
     return greedy_rnnt_decode_host(model, encoded, encoded_len, language_ids, max_symbols)

@@ -138,8 +138,9 @@ class EncDecHybridRNNTCTCModel(TranscriptionMixin, nn.Module):
         from .metrics import WER
         self.wer = WER(self, "rnnt", log_prediction=True)
         self.ctc_wer = WER(self, "ctc", log_prediction=True)
-        # the reference decodes EVERY training batch for its monitor (compute_wer = True, hybrid_rnnt_ctc_models.py:875); here
-        # that is a switch: None -> follow the training_step argument (default off), True / False -> fixed
+        # the reference decodes EVERY training batch for its monitor (compute_wer = True, hybrid_rnnt_ctc_models.py:875), and so
+        # does training_step by default; this switch is for callers that cannot pass the argument: None -> on, True / False as set
+        # (an explicit training_step(compute_wer=...) wins)
         self.compute_wer_in_step = None
         self.cur_decoder = "rnnt"
         self.language_masks = self.ctc_decoder.language_masks
@@ -292,13 +293,14 @@ class EncDecHybridRNNTCTCModel(TranscriptionMixin, nn.Module):
         return fn
 
     # ------------------------------------------------------------------ training_step (:859-930)
-    def training_step(self, batch, lang_ids, return_probs=False, host_lengths=None, compute_wer=False):
+    def training_step(self, batch, lang_ids, return_probs=False, host_lengths=None, compute_wer=None):
         """batch = (signal [B,L] f32, signal_len [B] i64, transcript [B,U] i64, transcript_len [B] i64), all on the
         device.  `host_lengths` = (signal_len list, transcript_len list): optional host copies (the collate
         function has them) that remove the only device->host read the sub-batch loop needs.
-        `compute_wer`: the reference decodes every training batch greedily for its monitor (compute_wer = True,
-        hybrid_rnnt_ctc_models.py:877-912: one host-driven micro-step loop per frame); here it is opt-in and the monitor
-        carries NaN otherwise (token-level rates unless `self.detokenize` is set, decoding.py)."""
+        `compute_wer`: the reference decodes every training batch greedily for its monitor (compute_wer = True hard-wired,
+        hybrid_rnnt_ctc_models.py:877-912: one host-driven micro-step loop per frame) -- so does this step unless told otherwise
+        (compute_wer=False here, or `model.compute_wer_in_step = False` for callers that cannot pass it: the monitor then carries
+        NaN).  Word-level through `model.set_tokenizer`, token-level without one (decoding.py)."""
         signal, signal_len, transcript, transcript_len = batch
         language_ids = lang_ids
         if host_lengths is None:
@@ -356,7 +358,8 @@ class EncDecHybridRNNTCTCModel(TranscriptionMixin, nn.Module):
             enc_btd = encoded.transpose(1, 2)
             if enc_btd.is_contiguous() and enc_btd.dtype == torch.float32:
                 tail.share_bf16(enc_btd)      # (withdrawn below, once both heads have been issued)
-        want_wer = bool(self.compute_wer_in_step if self.compute_wer_in_step is not None else compute_wer)
+        want_wer = bool(compute_wer if compute_wer is not None else
+                        (self.compute_wer_in_step if self.compute_wer_in_step is not None else True))
         # the CTC head and loss as one node on raw logits (no log-prob tensor, no softmax backward) unless a caller needs the
         # log-probs themselves with a gradient path (LwF: return_probs) or the raw logits stash (MAS: return_logits_)
         ctc_fused = (signal.is_cuda and not return_probs and self.ctc_loss.config_reduction == 'mean_batch'

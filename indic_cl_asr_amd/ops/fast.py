@@ -64,7 +64,10 @@ def bf16_shadow(*params):
         ((WEIGHT_EPOCH,) if any(p.requires_grad for p in params) else ())
     hit = _SHADOW.get(key)
     if hit is not None and hit[0] == ver and _same(hit[2], params):
+        if len(hit) > 3:
+            _join_cast(hit[1], hit[3])
         return hit[1]
+    made = None
     with torch.no_grad():
         flat16 = [_flat_shadow(p) for p in params]
         if all(v is not None for v in flat16):  # emitted by ia_adamw_step: no cast kernels at all
@@ -79,8 +82,31 @@ def bf16_shadow(*params):
             w = torch.cat([p.detach().reshape(p.shape[0], -1) for p in params], 0) if len(params) > 1 \
                 else params[0].detach().reshape(params[0].shape[0], -1)
             w = w.to(torch.bfloat16).contiguous()
-    _SHADOW[key] = (ver, w, _refs(_SHADOW, key, params))
+            made = _cast_marker(w)
+    _SHADOW[key] = (ver, w, _refs(_SHADOW, key, params)) + ((made,) if made is not None else ())
     return w
+
+
+def _cast_marker(w):
+    """The image was made by a cast kernel on the CURRENT stream, and the step uses several (prediction network, CTC branch, the
+    deferred decode of the in-step WER each run on their own): a consumer on another stream that finds it in the cache has to wait
+    for that kernel -- a decode that asked for joint.pred.weight's image first, on its side stream, otherwise raced the joint's own
+    projection GEMM on the compute stream (first step after a weight load: 7e-4 off in the transducer loss at 32 x 15 s)."""
+    if not w.is_cuda:
+        return None
+    st = torch.cuda.current_stream(w.device)
+    ev = torch.cuda.Event()
+    ev.record(st)
+    return [st.cuda_stream, ev, set()]
+
+
+def _join_cast(w, made):
+    st = torch.cuda.current_stream(w.device)
+    sid = st.cuda_stream
+    if sid != made[0] and sid not in made[2]:
+        st.wait_event(made[1])
+        w.record_stream(st)          # (allocated from the casting stream's pool)
+        made[2].add(sid)
 
 
 def glu_regrouped(weight, bias):

@@ -50,6 +50,54 @@ def test_native_block_matches_python_node(d, heads, B, T, p):
         assert rel(a, b) < 3e-2, (n, rel(a, b))
 
 
+def test_weight_gradients_on_the_side_stream_change_nothing(monkeypatch):
+    """csrc/block_train.hip can run the block's weight-gradient launches on an internal side stream beside the data-gradient chain
+    (IA_WGRAD_SIDE=1; off by default: measured slower in the step)
+    (forked behind their last operand, joined before an operand is overwritten and at the end of the call pair): same kernels on
+    the same operands, so the gradients equal the single-stream order's (IA_WGRAD_SIDE=0; bit for bit wherever the launches are the same), at the bench's block size
+    (where the launches really overlap) and with back-to-back blocks sharing the workspace."""
+    from indic_cl_asr_amd.encoder import ConformerLayer
+    from indic_cl_asr_amd.ops import block
+    torch.manual_seed(5)
+    d, heads, B, T = 256, 4, 32, 376
+    layers = [ConformerLayer(d, 4 * d, heads, 31, 0.1, 0.1).cuda().train() for _ in range(2)]
+    lens = torch.tensor([T] + [max(1, T - 9 * (i + 1)) for i in range(B - 1)], device="cuda")
+    x = torch.randn(B * T, d, device="cuda")
+    pe = block.pad_pos_emb(torch.randn(1, 2 * T - 1, d, device="cuda") * 0.5, d)
+    R = torch.randn(B * T, d, device="cuda")
+    res = []
+    for side in ("0", "1", "1"):
+        monkeypatch.setenv("IA_WGRAD_SIDE", side)
+        for layer in layers:
+            for q in layer.parameters():
+                q.grad = torch.full_like(q, 0.125)
+            bn = layer.conv.batch_norm
+            bn.running_mean.zero_(); bn.running_var.fill_(1.0); bn.num_batches_tracked.zero_()
+        xg = x.clone().requires_grad_(True)
+        h = xg
+        for i, layer in enumerate(layers):
+            h = block.conformer_block(h, layer, lens, pe, B, T, 77 + i)
+        (h * R).sum().backward()
+        torch.cuda.synchronize()
+        res.append([("dx", xg.grad.clone())] + [(f"{i}.{n}", q.grad.clone()) for i, layer in enumerate(layers)
+                                                for n, q in layer.named_parameters()])
+    assert all(torch.isfinite(t).all() for _, t in res[0])
+    # two runs with the side stream: identical (a race would not repeat itself bit for bit)
+    assert all(torch.equal(a, b) for (_, a), (_, b) in zip(res[1], res[2]))
+    # against the single-stream order: the second call's four weight gradients go out as two grouped launches instead of one, so
+    # their split-K partial sums are cut differently (fp32 rounding); everything else is the same launch on the same operands
+    regrouped = ("linear_q", "linear_k", "linear_v", "linear_pos", "feed_forward1.linear")
+    worst = 0.0
+    for (n, a), (_, b) in zip(res[0], res[1]):
+        if any(r in n for r in regrouped):
+            e = ((a - b).norm() / (b.norm() + 1e-20)).item()
+            worst = max(worst, e)
+            assert e < 2e-6, (n, e)
+        else:
+            assert torch.equal(a, b), n
+    print("regrouped weight gradients: worst relative L2 difference", worst)
+
+
 def test_native_block_refuses_a_second_backward():
     from indic_cl_asr_amd.encoder import ConformerLayer
     from indic_cl_asr_amd.ops import block

@@ -64,6 +64,19 @@ def test_greedy_rnnt_matches_per_utterance_oracle_cpu():
         assert max(len(h) for h in hyp) <= 3 * 23
 
 
+def test_greedy_rnnt_of_a_mixed_language_batch_decodes_each_utterance_through_its_own_head():
+    from indic_cl_asr_amd.decoding import greedy_rnnt_decode
+    o, m = _models()
+    g = torch.Generator().manual_seed(4)
+    enc = torch.randn(4, 32, 19, generator=g)
+    lens = torch.tensor([19, 12, 7, 19])
+    langs = ['hi', 'ta', 'ta', 'hi']
+    hyp = greedy_rnnt_decode(m, enc, lens, langs, max_symbols=3)
+    for i, lang in enumerate(langs):
+        assert hyp[i] == S.greedy_rnnt_decode_ref(o, enc[i:i + 1], lens[i:i + 1], lang, max_symbols=3)[0]
+    assert any(len(h) > 0 for h in hyp)
+
+
 def test_greedy_ctc_collapse_rule():
     from indic_cl_asr_amd.decoding import greedy_ctc_decode
     g = torch.Generator().manual_seed(5)
@@ -105,8 +118,14 @@ def test_training_step_monitor_carries_batch_wer_when_asked():
     assert isinstance(mon['training_batch_wer_ctc'], float)
     for key in ('training_batch_wer', 'training_batch_wer_ctc'):
         assert float(mon[key]) >= 0.0 and float(mon[key]) == float(mon[key])
-    loss2, mon2 = m.training_step(batch, ['hi'] * 3)
-    assert mon2['training_batch_wer_ctc'] != mon2['training_batch_wer_ctc']     # NaN when not requested
+    loss2, mon2 = m.training_step(batch, ['hi'] * 3, compute_wer=False)
+    assert mon2['training_batch_wer_ctc'] != mon2['training_batch_wer_ctc']     # NaN when switched off
+    m.compute_wer_in_step = False                                                # ... by the attribute, for callers that cannot pass it
+    _, mon2b = m.training_step(batch, ['hi'] * 3)
+    assert mon2b['training_batch_wer_ctc'] != mon2b['training_batch_wer_ctc']
+    m.compute_wer_in_step = None
+    _, mon2c = m.training_step(batch, ['hi'] * 3)                                # the reference's call: both rates, as it computes them
+    assert float(mon2c['training_batch_wer']) >= 0.0 and mon2c['training_batch_wer_ctc'] == mon2c['training_batch_wer_ctc']
     # the deferred form (decode enqueued on a side stream behind the encoder output, scored on the monitor's first read) and the
     # synchronous one give the same numbers
     m.disable_dropout()
