@@ -471,7 +471,9 @@ extern "C" int ia_gemm_bf16_ex2(const void* A, int lda, const void* W, int ldw, 
     int best = 64;
     if (!(K <= 1024 && tiles64 <= 2048)) {
         if (tiles128 >= 256) best = 128;
-        else if (tiles96 >= 240) best = 96;
+        else if (tiles96 >= 240 && K < 2048) best = 96;
+        // (long K on few tiles -- the subsampling's output projection, 12032 x 256 x 5120 -- stays on 64 rows: 376 workgroups on
+        //  the K-pipelined LDS-DMA kernel below, 51 us against 70 us with 96-row tiles; tools/bench_gemm_tiles.py)
     }
     if (forced == 128 || forced == 96 || forced == 64) best = forced;
     static const int dma_min_k = [] { const char* e = getenv("IA_GEMM_DMA_MINK"); return e ? atoi(e) : 512; }();   // (A/B switch)

@@ -25,7 +25,7 @@ def main():
     from indic_cl_asr_amd.ops import fast
     shapes = [(12032, 256, 256), (12032, 512, 256), (12032, 768, 256), (12032, 1024, 256), (12032, 256, 1024),
               (24032, 512, 512), (24032, 1024, 512), (24032, 1536, 512), (24032, 2048, 512), (24032, 512, 2048),
-              (3008, 640, 256), (3392, 640, 640)]
+              (3008, 640, 256), (3392, 640, 640), (12032, 256, 5120)]
     for M, N, K in shapes:
         a = torch.randn(M, K, device="cuda").bfloat16()
         w = torch.nn.Parameter(torch.randn(N, K, device="cuda") * 0.1)

@@ -21,7 +21,7 @@ echo mfma done
 cd $ROOT
 T=$(find $OUT/trace -name "*kernel_trace.csv" | head -1)
 python3 tools/trace_timeline.py $T --skip-frac 0.5 > $OUT/timeline.txt 2>&1
-KS="joint_grad_h_db_kernel joint_dh_fused_kernel joint_dw_fused_kernel joint_fwd_kernel ffn_fused_kernel relpos_flash_fwd_kernel relpos_flash_bwd_q_kernel relpos_flash_bwd_kv_kernel gemm_bf16_nt_kernel<64 gemm_bf16_nt_kernel<96 gemm_bf16_nt_kernel<128 gemm_bnsilu_kernel gemm_tn_grouped_kernel gemm_tn_kernel dwconv_fwd_kernel lstm_fwd_kernel lstm_bwd_kernel adamw_seg_kernel cl_penalty_kernel layernorm_kernel layernorm_bwd_kernel conv1_relu_cl_kernel ctc_alpha_beta rnnt_alpha_beta"
+KS="joint_grad_h_db_kernel joint_dh_fused_kernel joint_dw_fused_kernel joint_fwd_kernel ffn_fused_kernel relpos_flash_fwd_kernel relpos_flash_bwd_q_kernel relpos_flash_bwd_kv_kernel gemm_bf16_nt_kernel<64 gemm_bf16_nt_dma_kernel greedy_decode_mfma_kernel gemm_bf16_nt_kernel<96 gemm_bf16_nt_kernel<128 gemm_bnsilu_kernel gemm_tn_grouped_kernel gemm_tn_kernel dwconv_fwd_kernel lstm_fwd_kernel lstm_bwd_kernel adamw_seg_kernel cl_penalty_kernel layernorm_kernel layernorm_bwd_kernel conv1_relu_cl_kernel ctc_alpha_beta rnnt_alpha_beta"
 python3 tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_traffic.json $KS > $OUT/pmc_traffic.txt 2>&1
 python3 tools/pmc_mfma.py $OUT/pmc_mfma $OUT/pmc_mfma.json $KS > $OUT/pmc_mfma.txt 2>&1
 # keep the returned payload small: the raw trace / counter CSVs are large
