@@ -53,6 +53,11 @@ WORK = [
     ("ctc_alpha_beta", ("CTC alpha / beta on raw logits", "latency", 0.0, "", "one wave per (utterance, direction), side stream")),
     ("ctc_grad_logits_kernel", ("CTC gradient -> bf16 GEMM operand", "hbm", 4.0 * N * 264 + 2.0 * N * 264, "byte", "side stream")),
     ("rnnt_alpha_beta", ("transducer alpha / beta wavefront", "latency", 0.0, "", "481 dependent diagonal steps")),
+    ("greedy_decode_mfma_kernel", ("greedy transducer decode of the in-step WER (one launch per step)", "latency", 0.0, "",
+                                   "side stream, 4 workgroups per utterance; a dependent chain of head evaluations and LSTM steps out of "
+                                   "L2 (36 us per emitted symbol, 10 us per 16 frames): the average is carried by the first ~5 steps of the "
+                                   "run, where the freshly initialised model emits max_symbols labels at every frame (100+ ms per launch); "
+                                   "~2 ms per launch afterwards, under the joint / backward")),
 ]
 
 
