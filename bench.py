@@ -316,13 +316,13 @@ def main():
                 _ = monitor["training_batch_wer"]
         elif args.cl == "mas_importance":   # the importance pass after a task: |d (logit L2 norms) / d theta| accumulated into omega
             m_.joint.store_sub_logits = True; m_.ctc_decoder.return_logits_ = True
-            loss, monitor = model.training_step(batch, langs, host_lengths=host_lens)
+            loss, monitor = model.training_step(batch, langs, host_lengths=host_lens, compute_wer=False)   # (non-headline recipes: timed without the in-step WER)
             cl.mas_importance_loss(model, 0.3).backward()
             cl.importance_accumulate(flat, omega)
         else:                                # LwF: teacher pass with the previous task's weights, student step with the KD terms
             prob_, store = cl.lwf_teacher_forward(model, flat, teacher, batch, langs, host_lengths=host_lens)
             m_.joint.store_sub_enc, m_.joint.detach_sub_enc = True, False
-            loss, monitor, prob = model.training_step(batch, langs, return_probs=True, host_lengths=host_lens)
+            loss, monitor, prob = model.training_step(batch, langs, return_probs=True, host_lengths=host_lens, compute_wer=False)
             loss, _, _ = cl.lwf_kd_loss(loss, prob, prob_, m_.joint.store_list, store, 0.1, 0.3)
             loss.backward()
             opt.step()
