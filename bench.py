@@ -516,6 +516,8 @@ def main():
             kw = dict(d_model=cfg.d_model, n_layers=cfg.n_layers, n_heads=cfg.n_heads, pred_hidden=cfg.pred_hidden,
                       joint_hidden=cfg.joint_hidden)
             out["cpu_baseline"] = cpu_baseline(args.seconds, kw, args.cpu_sample_bs, max(args.freeze, 0), device=dev)
+        else:
+            out["cpu_baseline"] = None       # (--no-cpu-baseline, or N > 1: rank 0 times it at N = 1 only)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
