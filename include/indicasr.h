@@ -562,6 +562,14 @@ int ia_ffn_fused(float* x, int N, int d, int d_ff, const float* ln_g, const floa
                  const float* b1, const void* W2, const float* b2, float alpha, float p_ff, unsigned seed_ff, float p_res,
                  unsigned seed_res, const float* ln2_g, const float* ln2_b, void* y_out, int ln2_to_y_only,
                  ia_stream_t stream);
+/* ... followed, in the same launch, by a projection of the LN2 rows (the q|k|v projection behind feed_forward1 + norm_self_att of a
+ * frozen block, multi_head_attention.py:77-96): t_out [N, nt] bf16 = LN2(x) Wt^T + bt, Wt [nt, d] bf16 row-major, nt % 64 == 0,
+ * bt [nt] f32 or NULL; ln2_g / ln2_b required, y_out may be NULL. */
+int ia_ffn_fused_tail_supported(int d, int d_ff, int nt);
+int ia_ffn_fused_tail(float* x, int N, int d, int d_ff, const float* ln_g, const float* ln_b, float eps, const void* W1,
+                      const float* b1, const void* W2, const float* b2, float alpha, float p_ff, unsigned seed_ff, float p_res,
+                      unsigned seed_res, const float* ln2_g, const float* ln2_b, void* y_out, int ln2_to_y_only, const void* Wt,
+                      const float* bt, void* t_out, int nt, ia_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Native executor of the no-autograd Conformer prefix (frozen blocks / teacher / eval): one call enqueues the 14

@@ -170,6 +170,9 @@ SIGNATURES = {
     "ia_gemm_tn_bf16": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ia_ffn_fused_supported": (_i, [_i, _i]),
     "ia_ffn_fused": (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _f, _f, _c.c_uint, _f, _c.c_uint, _vp, _vp, _vp, _i, _vp]),
+    "ia_ffn_fused_tail_supported": (_i, [_i, _i, _i]),
+    "ia_ffn_fused_tail": (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _f, _f, _c.c_uint, _f, _c.c_uint, _vp, _vp, _vp, _i,
+                               _vp, _vp, _vp, _i, _vp]),
     "ia_conformer_prefix_ws_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "ia_conformer_prefix_ws_sums_offset": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "ia_conformer_prefix_fwd_seg": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _c.c_uint, _c.c_uint, _i, _i, _i, _i, _vp, _sz, _vp]),

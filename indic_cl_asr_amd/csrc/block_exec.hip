@@ -115,7 +115,15 @@ extern "C" int ia_conformer_prefix_fwd_seg(const ia_block_params* layers, int n_
         const bool first_half = 2 * li >= seg_begin, second_half = 2 * li + 1 < seg_end;
         if (first_half) {
         // 1/2 feed-forward
-        if (ffn_fused) {
+        // (IA_FFN_TAIL=0: the q|k|v projection as a launch of its own; read per call, tests compare both in one process)
+        const char* tail_env = getenv("IA_FFN_TAIL");
+        const bool qkv_tail = ffn_fused && !(tail_env && tail_env[0] == '0') && ia_ffn_fused_tail_supported(d, d_ff, 3 * d);
+        if (qkv_tail) {
+            // ... norm_self_att of the updated residual AND the q|k|v projection of those rows in the same launch: the LayerNorm'd
+            // rows go from the epilogue into LDS, the 393 KB of W_qkv follow W1 / W2 through the ring (no y round trip, no launch)
+            IA_TRY(ia_ffn_fused_tail(x, N, d, d_ff, L.ln_ff1_g, L.ln_ff1_b, L.ln_eps, L.w_ff1a, L.b_ff1a, L.w_ff1b, L.b_ff1b, L.fc_factor,
+                                     pff, seed + 1, p, seed + 2, L.ln_att_g, L.ln_att_b, nullptr, 1, L.w_qkv, L.b_qkv, qkv, 3 * d, stream));
+        } else if (ffn_fused) {
             // (... and norm_self_att of the updated residual straight into y: no separate LayerNorm launch)
             IA_TRY(ia_ffn_fused(x, N, d, d_ff, L.ln_ff1_g, L.ln_ff1_b, L.ln_eps, L.w_ff1a, L.b_ff1a, L.w_ff1b, L.b_ff1b, L.fc_factor,
                                 pff, seed + 1, p, seed + 2, L.ln_att_g, L.ln_att_b, y, 1, stream));
@@ -126,7 +134,8 @@ extern "C" int ia_conformer_prefix_fwd_seg(const ia_block_params* layers, int n_
         // self-attention
         if (!ffn_fused)
             IA_TRY(ia_layernorm(x, d, N, d, L.ln_att_g, L.ln_att_b, L.ln_eps, nullptr, 0, nullptr, nullptr, y, d, stream));
-        IA_TRY(ia_gemm_bf16(y, d, L.w_qkv, d, N, 3 * d, d, L.b_qkv, 0, 0.f, 0, 1.f, nullptr, 0, nullptr, 0, qkv, 3 * d, stream));
+        if (!qkv_tail)
+            IA_TRY(ia_gemm_bf16(y, d, L.w_qkv, d, N, 3 * d, d, L.b_qkv, 0, 0.f, 0, 1.f, nullptr, 0, nullptr, 0, qkv, 3 * d, stream));
         const void* plu = L.pl_cached;   // frozen position projection: computed once per (layer, T) by the caller
         if (!plu) {
             IA_TRY(ia_gemm_bf16(pos_emb, d, L.w_pos, d, pos_rows, d, d, nullptr, 0, 0.f, 0, 1.f, nullptr, 0, nullptr, 0, pl, d, stream));

@@ -52,6 +52,9 @@ struct FfnArgs {
     __bf16* y_out;                             // optional bf16 copy of the result (operand of the next projection)
     int ln2_y_only;                            // 1: x keeps the un-normalised residual, LN2 goes to y_out only (next module's LayerNorm)
     int mode;                                  // diagnostics (tools/bench_ffn.py): bit 0 = no weight loads in the loop, bit 1 = no MFMAs
+    // optional tail projection of the LN2 rows (TAIL instantiation): t_out [N, nt] bf16 = LN2(x) Wt^T + bt, Wt [nt, D] bf16 -- the
+    // q|k|v projection behind feed_forward1 + norm_self_att of a frozen block, without a launch (and a y round trip) of its own
+    const __bf16* Wt; const float* bt; __bf16* t_out; int nt;
 };
 
 __device__ __forceinline__ float half_wave_sum(float v) {   // sum over the 32 lanes of a half wave (rows are half waves)
@@ -76,7 +79,7 @@ __device__ __forceinline__ float half_wave_sum(float v) {   // sum over the 32 l
 // and of a compiler-visible LDS read while LDS-DMA is in flight.
 // DIAG: the timing-only variants of tools/bench_ffn.py (a.mode) are compiled into a separate instantiation: their branches
 // would split the loop body into basic blocks, and the MFMA / VALU interleaving below only happens inside one block.
-template <int D, bool DROP_FF, bool DIAG>
+template <int D, bool DROP_FF, bool DIAG, bool TAIL = false>
 __global__ __launch_bounds__(FF_THREADS, 2) void ffn_fused_kernel(FfnArgs a) {
     const int mode = DIAG ? a.mode : 0;
     static_assert(D == 256, "wave decomposition below is written for d_model = 256");
@@ -430,16 +433,114 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ffn_fused_kernel(FfnArgs a) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = v[j] * rstd * gg[j] + bb[j];
         }
+        union { uint4 u; __bf16 h[8]; } ob;
+        if (TAIL || a.y_out) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ob.h[j] = (__bf16)v[j];
+        }
+        if (TAIL)   // operand tile of the tail projection: ring slot 3 (the epilogue tile ends inside slot 2), rows swizzled as sY
+            *reinterpret_cast<uint4*>(sY + r * YROW + ((vec & 16) | ((vec & 15) ^ (r & 15))) * 16) = ob.u;
         if (live) {
             if (!a.ln2_y_only) {
                 *reinterpret_cast<float4*>(a.x + (size_t)gm * D + vec * 8) = make_float4(v[0], v[1], v[2], v[3]);
                 *reinterpret_cast<float4*>(a.x + (size_t)gm * D + vec * 8 + 4) = make_float4(v[4], v[5], v[6], v[7]);
             }
-            if (a.y_out) {
-                union { uint4 u; __bf16 h[8]; } ob;
+            if (a.y_out) *reinterpret_cast<uint4*>(a.y_out + (size_t)gm * D + vec * 8) = ob.u;
+        }
+    }
+    if constexpr (TAIL) {
+        // ---- tail projection: t_out[64 frames][nt] = LN2 rows (ring slot 3) x Wt^T.  Wt streams through the ring, 64 rows
+        // (32 KB) per slot, three slots in flight; wave (cg = wave & 3, fh = wave >> 2) multiplies the slot's channels 16 cg .. + 15
+        // with frames 32 fh .. + 31 (two 16x16x32 tiles, K = 256 in eight steps, the frames' fragments stay in registers).
+        __syncthreads();   // the epilogue tile (slots 0..2) has been read, the operand tile is complete
+        const unsigned char* Wt = reinterpret_cast<const unsigned char*>(a.Wt);
+        const int nslots = a.nt / 64;
+        const int c16 = lane & 15, q4 = lane >> 4, cg = wave & 3, fh = wave >> 2;
+        // lane parts of the four request addresses of a slot (instruction 4 wv + i of the slot's 32: rows 2 n, 2 n + 1 (lane >> 5),
+        // physical chunk lane & 31 <- the logical chunk that lives there): loop-invariant registers + a uniform slot base, so that
+        // no address register is rewritten while requests that used it are in flight (hipcc drains vmcnt(0) in front of such a write)
+        unsigned toff[4];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) ob.h[j] = (__bf16)v[j];
-                *reinterpret_cast<uint4*>(a.y_out + (size_t)gm * D + vec * 8) = ob.u;
+        for (int i = 0; i < 4; ++i) {
+            const int row = 2 * (4 * wv + i) + (lane >> 5);
+            const int pc = lane & 31;
+            toff[i] = (unsigned)((row * D + ((pc & 16) | ((pc & 15) ^ (row & 15))) * 8) * 2);
+        }
+        auto issue_t = [&](int sl) {
+            unsigned char* dst = sRing + (sl & 3) * SLOT + wv * 4096;
+            const unsigned char* base = Wt + (size_t)sl * (64 * D * 2);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + toff[i]),
+                                                 (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+        };
+        // the projection's bias goes where b1 was (plain loads inside the loop would drain the request queue: vmcnt(0))
+        for (int i = tid; i < a.nt; i += FF_THREADS) sB1[i] = a.bt ? a.bt[i] : 0.f;
+        issue_t(0);
+        if (nslots > 1) issue_t(1);
+        if (nslots > 2) issue_t(2);
+        // this wave's 32 frames as fragments: lane (frame c16 of tile tl, k chunk q4): logical chunk 4 ks + q4 of the row
+        bf8 yt[2][8];
+        {
+            const unsigned ybase = (unsigned)(3 * SLOT) + (unsigned)((fh * 32 + c16) * YROW);
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const unsigned ad = ybase + (unsigned)(tl * 16 * YROW) + (unsigned)((((4 * ks + q4) & 16) | (((4 * ks + q4) & 15) ^ c16)) * 16);
+                    asm volatile("ds_read_b128 %0, %1" : "=&v"(yt[tl][ks]) : "v"(ad));
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(yt[0][0]), "+v"(yt[0][1]), "+v"(yt[0][2]), "+v"(yt[0][3]), "+v"(yt[0][4]), "+v"(yt[0][5]),
+                         "+v"(yt[0][6]), "+v"(yt[0][7]), "+v"(yt[1][0]), "+v"(yt[1][1]), "+v"(yt[1][2]), "+v"(yt[1][3]), "+v"(yt[1][4]),
+                         "+v"(yt[1][5]), "+v"(yt[1][6]), "+v"(yt[1][7]));
+        }
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        unsigned ooff[2];
+        bool olive[2];
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl) {
+            const int gm = m0 + fh * 32 + tl * 16 + c16;
+            olive[tl] = gm < a.N;
+            ooff[tl] = (unsigned)((olive[tl] ? gm : 0) * a.nt + cg * 16 + 4 * q4);   // elements; N * nt < 2^31 (checked by the launcher)
+        }
+        for (int sl = 0; sl < nslots; ++sl) {
+            // this wave's share of slot sl has landed (at most the two later slots' 8 requests -- and any output store, which only
+            // makes the wait longer -- stay in flight), then everybody's
+            const int later = nslots - 1 - sl;
+            if (later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            // ring of four: the slot read in the PREVIOUS iteration (for sl = 0: the operand tile, which lives in registers by now) is
+            // free once everybody is here -- it takes slot sl + 3; one rendezvous per slot
+            if (sl + 3 < nslots) issue_t(sl + 3);
+            const unsigned wbase = (unsigned)((sl & 3) * SLOT) + (unsigned)((cg * 16 + c16) * YROW);
+            bf8 wf[8];
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const unsigned ad = wbase + (unsigned)((((4 * ks + q4) & 16) | (((4 * ks + q4) & 15) ^ c16)) * 16);
+                asm volatile("ds_read_b128 %0, %1" : "=&v"(wf[ks]) : "v"(ad));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wf[0]), "+v"(wf[1]), "+v"(wf[2]), "+v"(wf[3]), "+v"(wf[4]), "+v"(wf[5]), "+v"(wf[6]), "+v"(wf[7]));
+            f4v t0 = {0.f, 0.f, 0.f, 0.f}, t1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], yt[0][ks], t0, 0, 0, 0);
+                t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], yt[1][ks], t1, 0, 0, 0);
+            }
+            // D[channel 4 q4 + r][frame c16]: four consecutive channels of one frame per lane
+            float4 bv;
+            {
+                const unsigned baddr = (unsigned)(4 * SLOT + FF_M * XROW) + (unsigned)((sl * 64 + cg * 16 + 4 * q4) * 4);
+                asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(bv) : "v"(baddr) : "memory");
+            }
+            __bf16* orow = a.t_out + (size_t)sl * 64;     // (uniform part of the output address; the lane part is loop-invariant)
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl) {
+                const f4v t = tl ? t1 : t0;
+                union { uint2 u; __bf16 h[4]; } pk;
+                pk.h[0] = (__bf16)(t[0] + bv.x); pk.h[1] = (__bf16)(t[1] + bv.y); pk.h[2] = (__bf16)(t[2] + bv.z); pk.h[3] = (__bf16)(t[3] + bv.w);
+                if (olive[tl]) *reinterpret_cast<uint2*>(orow + ooff[tl]) = pk.u;
             }
         }
     }
@@ -449,10 +550,42 @@ __global__ __launch_bounds__(FF_THREADS, 2) void ffn_fused_kernel(FfnArgs a) {
 
 extern "C" int ia_ffn_fused_supported(int d, int d_ff) { return (d == 256 && d_ff >= 2 * FF_JC && d_ff % FF_JC == 0 && d_ff <= 2048) ? 1 : 0; }   // the chunk pipeline needs two chunks
 
+namespace {
+int ffn_launch(float* x, int N, int d, int d_ff, const float* ln_g, const float* ln_b, float eps, const void* W1,
+               const float* b1, const void* W2, const float* b2, float alpha, float p_ff, unsigned seed_ff,
+               float p_res, unsigned seed_res, const float* ln2_g, const float* ln2_b, void* y_out,
+               int ln2_to_y_only, const void* Wt, const float* bt, void* t_out, int nt, ia_stream_t stream);
+}
+
 extern "C" int ia_ffn_fused(float* x, int N, int d, int d_ff, const float* ln_g, const float* ln_b, float eps, const void* W1,
                             const float* b1, const void* W2, const float* b2, float alpha, float p_ff, unsigned seed_ff,
                             float p_res, unsigned seed_res, const float* ln2_g, const float* ln2_b, void* y_out,
                             int ln2_to_y_only, ia_stream_t stream) {
+    return ffn_launch(x, N, d, d_ff, ln_g, ln_b, eps, W1, b1, W2, b2, alpha, p_ff, seed_ff, p_res, seed_res, ln2_g, ln2_b, y_out,
+                      ln2_to_y_only, nullptr, nullptr, nullptr, 0, stream);
+}
+
+// ... followed, in the same launch, by a projection of the LN2 rows: t_out [N, nt] bf16 = LN2(x) Wt^T + bt (Wt [nt, d] bf16 row-major,
+// nt a multiple of 64, bt [nt] f32 or NULL).  ln2_g / ln2_b are required; y_out may be NULL (the rows then never leave the CU).
+extern "C" int ia_ffn_fused_tail_supported(int d, int d_ff, int nt) { return (ia_ffn_fused_supported(d, d_ff) && nt > 0 && nt % 64 == 0) ? 1 : 0; }
+
+extern "C" int ia_ffn_fused_tail(float* x, int N, int d, int d_ff, const float* ln_g, const float* ln_b, float eps, const void* W1,
+                                 const float* b1, const void* W2, const float* b2, float alpha, float p_ff, unsigned seed_ff,
+                                 float p_res, unsigned seed_res, const float* ln2_g, const float* ln2_b, void* y_out,
+                                 int ln2_to_y_only, const void* Wt, const float* bt, void* t_out, int nt, ia_stream_t stream) {
+    if (!Wt || !t_out || !ln2_g || !ln2_b) return IA_INVALID_VALUE;
+    if (!ia_ffn_fused_tail_supported(d, d_ff, nt)) return IA_UNSUPPORTED;
+    if (!ia_is_aligned(Wt, 16) || !ia_is_aligned(t_out, 16) || (bt && !ia_is_aligned(bt, 16))) return IA_INVALID_VALUE;
+    if ((long long)N * nt >= (1ll << 31) || nt > d_ff) return IA_UNSUPPORTED;   // 32-bit output offsets; the bias reuses b1's LDS words
+    return ffn_launch(x, N, d, d_ff, ln_g, ln_b, eps, W1, b1, W2, b2, alpha, p_ff, seed_ff, p_res, seed_res, ln2_g, ln2_b, y_out,
+                      ln2_to_y_only, Wt, bt, t_out, nt, stream);
+}
+
+namespace {
+int ffn_launch(float* x, int N, int d, int d_ff, const float* ln_g, const float* ln_b, float eps, const void* W1,
+               const float* b1, const void* W2, const float* b2, float alpha, float p_ff, unsigned seed_ff,
+               float p_res, unsigned seed_res, const float* ln2_g, const float* ln2_b, void* y_out,
+               int ln2_to_y_only, const void* Wt, const float* bt, void* t_out, int nt, ia_stream_t stream) {
     if (!x || !ln_g || !ln_b || !W1 || !b1 || !W2 || !b2 || N <= 0 || (ln2_g && !ln2_b)) return IA_INVALID_VALUE;
     if (!ia_ffn_fused_supported(d, d_ff)) return IA_UNSUPPORTED;
     if (p_ff < 0.f || p_ff >= 1.f || p_res < 0.f || p_res >= 1.f) return IA_INVALID_VALUE;
@@ -467,14 +600,23 @@ extern "C" int ia_ffn_fused(float* x, int N, int d, int d_ff, const float* ln_g,
     a.ks_ff = a.thr_ff > 0 ? 256.f / (256.f - (float)a.thr_ff) : 1.f;
     a.thr_res = (unsigned)(p_res * 256.f + 0.5f); a.seed_res = seed_res;
     a.ks_res = a.thr_res > 0 ? 256.f / (256.f - (float)a.thr_res) : 1.f;
-    if (ln2_to_y_only && (!ln2_g || !y_out)) return IA_INVALID_VALUE;
+    if (ln2_to_y_only && (!ln2_g || (!y_out && !Wt))) return IA_INVALID_VALUE;
     a.ln2_g = ln2_g; a.ln2_b = ln2_b; a.y_out = (__bf16*)y_out; a.ln2_y_only = ln2_to_y_only ? 1 : 0;
+    a.Wt = (const __bf16*)Wt; a.bt = bt; a.t_out = (__bf16*)t_out; a.nt = nt;
     if (d_ff > 2048) return IA_UNSUPPORTED;                    // b1 is kept in LDS
     const int LDS = 4 * 32768 + FF_M * FF_JC * 2 + d_ff * 4;   // ring + X + b1 = 151 552 B at d_ff = 1024
     static_assert(FF_M * (256 * 4 + 16) <= 4 * 32768, "epilogue tile aliases the ring");
     { const char* e = getenv("IA_FFN_MODE"); a.mode = (e && *e) ? atoi(e) : 0; }   // diagnostics only
     const dim3 grid((N + FF_M - 1) / FF_M), blk(FF_THREADS);
-    if (a.mode) {   // (DROP_FF with threshold 0 keeps every unit at scale 1)
+    if (Wt) {
+        if (a.thr_ff > 0) {
+            IA_SET_MAX_LDS_ONCE((ffn_fused_kernel<256, true, false, true>), LDS);
+            hipLaunchKernelGGL((ffn_fused_kernel<256, true, false, true>), grid, blk, LDS, (hipStream_t)stream, a);
+        } else {
+            IA_SET_MAX_LDS_ONCE((ffn_fused_kernel<256, false, false, true>), LDS);
+            hipLaunchKernelGGL((ffn_fused_kernel<256, false, false, true>), grid, blk, LDS, (hipStream_t)stream, a);
+        }
+    } else if (a.mode) {   // (DROP_FF with threshold 0 keeps every unit at scale 1)
         IA_SET_MAX_LDS_ONCE((ffn_fused_kernel<256, true, true>), LDS);
         hipLaunchKernelGGL((ffn_fused_kernel<256, true, true>), grid, blk, LDS, (hipStream_t)stream, a);
     } else if (a.thr_ff > 0) {
@@ -487,3 +629,4 @@ extern "C" int ia_ffn_fused(float* x, int N, int d, int d_ff, const float* ln_g,
     IA_RETURN_IF_LAUNCH_FAILED();
     return IA_OK;
 }
+}  // namespace

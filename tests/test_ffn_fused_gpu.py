@@ -101,3 +101,43 @@ def test_ffn_fused_can_emit_the_next_modules_layernorm_without_touching_the_resi
     out_x = fast.ffn_fused(x.clone(), ln, l1, l2, 0.5, ln2=ln2, y_out=y, ln2_to_y_only=True)
     assert torch.equal(out_x, ref_x)
     assert (y.float() - ref_y.float()).abs().max().item() <= 2e-2 * ref_y.float().abs().max().item()
+
+
+@pytest.mark.parametrize("N,p_ff,p_res", [(12032, 0.0, 0.0), (1000, 0.1, 0.1), (77, 0.0, 0.25), (64, 0.0, 0.0)])
+def test_ffn_fused_tail_projection_equals_the_projection_as_a_launch_of_its_own(N, p_ff, p_res):
+    """ia_ffn_fused_tail: the q|k|v projection of the LN2 rows inside the feed-forward launch (rows from the epilogue into LDS, W_qkv
+    through the ring) against ia_ffn_fused + ia_gemm_bf16 on the rows it wrote out: same bf16 operands, fp32 accumulation in a
+    different k order -- equal up to one bf16 rounding of the output; the residual stream itself is bit-identical."""
+    from indic_cl_asr_amd import _lib
+    from indic_cl_asr_amd.ops import fast
+    L = _lib.lib()
+    ln, l1, l2, ln2 = _modules(seed=3)
+    torch.manual_seed(9)
+    qkv = torch.nn.Linear(256, 768).cuda()
+    x = (torch.randn(N, 256, generator=torch.Generator().manual_seed(N)) * 1.3).cuda()
+    w1, w2, wq = fast.bf16_shadow(l1.weight), fast.bf16_shadow(l2.weight), fast.bf16_shadow(qkv.weight)
+    thr = lambda p_: int(p_ * 256 + 0.5) / 256.0
+
+    def run(tail):
+        xa = x.clone()
+        y = torch.full((N, 256), float("nan"), dtype=torch.bfloat16, device="cuda")
+        out = torch.full((N, 768), float("nan"), dtype=torch.bfloat16, device="cuda")
+        common = (_lib.ptr(xa), N, 256, 1024, _lib.ptr(ln.weight), _lib.ptr(ln.bias), ln.eps, _lib.ptr(w1), _lib.ptr(l1.bias), _lib.ptr(w2),
+                  _lib.ptr(l2.bias), 0.5, thr(p_ff), 31, thr(p_res), 32, _lib.ptr(ln2.weight), _lib.ptr(ln2.bias))
+        if tail:
+            _lib.check(L.ia_ffn_fused_tail(*common, None, 1, _lib.ptr(wq), _lib.ptr(qkv.bias), _lib.ptr(out), 768, _lib.stream_ptr()), "ia_ffn_fused_tail")
+        else:
+            _lib.check(L.ia_ffn_fused(*common, _lib.ptr(y), 1, _lib.stream_ptr()), "ia_ffn_fused")
+            _lib.check(L.ia_gemm_bf16(_lib.ptr(y), 256, _lib.ptr(wq), 256, N, 768, 256, _lib.ptr(qkv.bias), 0, 0.0, 0, 1.0, None, 0, None, 0,
+                                      _lib.ptr(out), 768, _lib.stream_ptr()), "ia_gemm_bf16")
+        torch.cuda.synchronize()
+        return xa, out
+    assert int(L.ia_ffn_fused_tail_supported(256, 1024, 768)) == 1 and int(L.ia_ffn_fused_tail_supported(256, 1024, 100)) == 0
+    xa, oa = run(False)
+    xb, ob = run(True)
+    assert torch.equal(xa, xb)                                  # the residual stream does not know about the tail
+    assert torch.isfinite(ob.float()).all()
+    d = (oa.float() - ob.float()).abs()
+    tol = 2.0 ** -7 * oa.float().abs().clamp_min(1e-2)          # one bf16 step (8 bits of mantissa) of the value
+    assert (d <= tol).all(), (d.max().item(), (d > tol).sum().item())
+    assert (d == 0).float().mean().item() > 0.97                # ... and a rounding tie is rare
