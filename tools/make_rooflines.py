@@ -25,6 +25,9 @@ WORK = [
     ("joint_dw_fused_kernel", ("joint weight gradient dW = G^T hidden", "mfma", 2.0 * CELLS * LD * H, "flop", "")),
     ("joint_grad_h_db_kernel", ("transducer gradient, in place over the f16 lattice", "hbm", 2 * 2.0 * CELLS * 257 * LIVE, "byte",
                                 "touched cells only (bench.py roofline)")),
+    ("ffn_fused_kernel<256, true, false, true>", ("feed-forward module LN -> W1 -> SiLU -> W2 -> residual -> LN + the q|k|v projection as a tail phase",
+                                                  "mfma", 2.0 * 2 * N * d * 4 * d + 2.0 * N * d * 3 * d, "flop",
+                                                  "paced by 1.4 MB of weights per workgroup through LDS")),
     ("ffn_fused_kernel", ("feed-forward module LN -> W1 -> SiLU -> W2 -> residual", "mfma", 2.0 * 2 * N * d * 4 * d, "flop",
                           "paced by 1 MB of weights per workgroup through LDS")),
     ("gemm_bf16_nt_kernel<128, 128, true>", ("subsampling conv2 as implicit GEMM", "mfma", 2.0 * (B * 376 * 20) * 256 * 2304, "flop", "")),
