@@ -248,8 +248,6 @@ class EncDecHybridRNNTCTCModel(TranscriptionMixin, nn.Module):
         are ENQUEUED on `stream`.  The decode reads private copies of the weights it needs, so the optimizer may update them
         meanwhile; the returned event marks the point behind which those copies (and the setup GEMMs) have been issued."""
         from .decoding import _pinned_async, greedy_rnnt_decode_device
-        from . import cl
-        cl.flush_pending_updates()     # (on the compute stream: the decode below asks for it too, under its own stream -- a no-op then)
         stream.wait_event(enc_ready)
         with torch.cuda.stream(stream):
             refs_h = _pinned_async(transcript)
@@ -388,6 +386,8 @@ class EncDecHybridRNNTCTCModel(TranscriptionMixin, nn.Module):
         if want_wer and signal.is_cuda and self.defer_wer and len(set(language_ids)) == 1:
             from .decoding import device_decode_supported
             if device_decode_supported(self):
+                from . import cl as _cl
+                _cl.flush_pending_updates()   # (on the compute stream, in front of the event: the decode asks for it too, under its own stream -- a no-op then)
                 main_ = torch.cuda.current_stream(signal.device)
                 ready_ = torch.cuda.Event()
                 ready_.record(main_)
