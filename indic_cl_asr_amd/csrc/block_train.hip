@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void multi_add_kernel(const AddRow* __restrict
 }
 
 struct BwdWs {   // workspace of the two backward calls (offsets in bytes)
-    size_t dxa, dxb, dB, dB1, dB2, dh, dhp, dy, dc3, dz, dG, dc2, dctx, wt, scr, total;
+    size_t dxa, dxb, dB, dB1, dB2, dB3, dh, dhp, dy, dc3, dz, dG, dc2, dctx, wt, scr, total;
 };
 
 size_t max3(size_t a, size_t b, size_t c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
@@ -135,7 +135,8 @@ BwdWs bwd_ws(int B, int T, int d, int d_ff, int ksz) {
     w.dB = o;   o = up256(o + N * d * 2);          // gradients entering the branches (bf16): kept until the grouped
     w.dB1 = o;  o = up256(o + N * d * 2);          // weight-gradient launch at the end of each backward call
     w.dB2 = o;  o = up256(o + N * d * 2);
-    w.dh = o;   o = up256(o + N * d_ff * 2);
+    w.dB3 = o;  o = up256(o + N * d * 2);          // part 2's dB / dhp (dB3 / dh) when part 1's weight gradients wait for part 2's
+    w.dh = o;   o = up256(o + N * d_ff * 2);       // launch: their operands dB / dhp must survive
     w.dhp = o;  o = up256(o + N * d_ff * 2);
     w.dy = o;   o = up256(o + N * d * 2);
     w.dc3 = o;  o = up256(o + N * d * 2);
@@ -165,6 +166,11 @@ BwdWs bwd_ws(int B, int T, int d, int d_ff, int ksz) {
         scr = max3(scr, (size_t)ia_gemm_tn_grouped_scratch_elems(ga, 5), (size_t)ia_gemm_tn_grouped_scratch_elems(gb, 4));
         // (with the side stream, part 2 launches its four as two groups of two: fewer problems per launch = more splits each)
         scr = max3(scr, (size_t)ia_gemm_tn_grouped_scratch_elems(gb, 2), (size_t)ia_gemm_tn_grouped_scratch_elems(gb + 2, 2));
+        // (all nine of a block in one launch: merged_wgrads())
+        ia_tn_problem gall[9];
+        for (int i = 0; i < 5; ++i) gall[i] = ga[i];
+        for (int i = 0; i < 4; ++i) gall[5 + i] = gb[i];
+        scr = scr > (size_t)ia_gemm_tn_grouped_scratch_elems(gall, 9) ? scr : (size_t)ia_gemm_tn_grouped_scratch_elems(gall, 9);
     }
     w.scr = o;  o = up256(o + scr * 4);
     w.total = o;
@@ -234,6 +240,23 @@ SideCtx* side_ctx() {
     }
     return c.ok ? &c : nullptr;
 }
+// ---- one weight-gradient launch per block.  Part 1's five problems are not launched at its end but carried (host side) to part 2,
+// whose four join them: one grouped split-K GEMM + one finishing sum over nine problems instead of two + two (fewer, longer splits:
+// 96 tiles x 4 splits in one residency wave).  Part 2 then writes its dB / dhp into buffers of its own, the operands of the
+// pending problems stay intact.  IA_TN_MERGE=0: two launches as before (read per call).  Not with the side stream, not with the
+// SyncBatchNorm phases (those flush where they are).
+struct PendingGroup { ia_tn_problem grp[8]; int n = 0; const void* ws = nullptr; };
+PendingGroup* pending_group() {
+    static PendingGroup pg[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    return &pg[dev];
+}
+bool merged_wgrads() {
+    const char* e = getenv("IA_TN_MERGE");
+    return !(e && e[0] == '0') && tn_grouping_enabled();
+}
+
 // `to` continues behind everything issued on `from` so far
 int stream_after(hipStream_t from, hipStream_t to, hipEvent_t ev) {
     if (hipEventRecord(ev, from) != hipSuccess || hipStreamWaitEvent(to, ev, 0) != hipSuccess) return IA_LAUNCH_FAILED;
@@ -404,6 +427,10 @@ extern "C" int ia_conformer_block_bwd_a_phase(const ia_block_params* Lp, const i
         IA_TRY(flush_group(grp, ngrp, scr, (ia_stream_t)side->s));
         if (hipEventRecord(side->ev[2], side->s) != hipSuccess) return IA_LAUNCH_FAILED;
         side->a_pending = true;
+    } else if (phase == 0 && merged_wgrads() && pending_group()) {
+        PendingGroup* pg = pending_group();   // launched by part 2 together with its own four
+        for (int i = 0; i < ngrp; ++i) pg->grp[i] = grp[i];
+        pg->n = ngrp; pg->ws = workspace;
     } else {
         IA_TRY(flush_group(grp, ngrp, scr, stream));
     }
@@ -431,10 +458,16 @@ extern "C" int ia_conformer_block_bwd_b(const ia_block_params* Lp, const ia_bloc
     float *dxa = (float*)(ws + w.dxa), *dxb = (float*)(ws + w.dxb), *scr = (float*)(ws + w.scr);
     float* lnp = (float*)(ws + w.dG);   // (sets 0..2 were written by the first backward call)
     const size_t lnp_set = (size_t)ia_layernorm_bwd_scratch_elems(N, d);
-    void *dB = ws + w.dB, *dhp = ws + w.dhp, *dy = ws + w.dy, *wt = ws + w.wt;
+    PendingGroup* pg = pending_group();
+    const bool carried = pg && pg->n > 0 && pg->ws == workspace;
+    void *dB = ws + (carried ? w.dB3 : w.dB), *dhp = ws + (carried ? w.dh : w.dhp), *dy = ws + w.dy, *wt = ws + w.wt;
     const float p = L.p_drop, pff = L.p_ff;
-    ia_tn_problem grp[8];
+    ia_tn_problem grp[12];
     int ngrp = 0;
+    if (carried) {   // part 1's five problems first (their operands are untouched: this call writes dB3 / dh instead of dB / dhp)
+        for (int i = 0; i < pg->n; ++i) grp[ngrp++] = pg->grp[i];
+        pg->n = 0;
+    }
     // transposed weight images of this call's three data-gradient GEMMs (behind the five of part 1 in the workspace)
     char* wtb = (char*)wt + ((size_t)2 * d * d_ff + (size_t)4 * d * d) * 2;
     void *wt_qkv = wtb, *wt_ff1b = wtb + (size_t)3 * d * d * 2, *wt_ff1a = wtb + ((size_t)3 * d * d + (size_t)d * d_ff) * 2;
@@ -444,7 +477,7 @@ extern "C" int ia_conformer_block_bwd_b(const ia_block_params* Lp, const ia_bloc
         IA_TRY(tr_launch(tl, (hipStream_t)stream));
     }
     // q|k|v projection (dW rows q, k, v contiguous; bias likewise) and the bias-free position projection
-    SideCtx* side = side_ctx();
+    SideCtx* side = carried ? nullptr : side_ctx();
     hipStream_t main = (hipStream_t)stream;
     IA_TRY(linear_bwd_deferred(dqkv, S.y2, L.w_qkv, N, 3 * d, d, dy, G.w_qkv, G.b_qkv, wt_qkv, grp, &ngrp, stream));
     grp[ngrp++] = ia_tn_problem{dpl, pos_emb, G.w_pos, nullptr, d, d, pos_rows, d, d};

@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const __bf16* __restric
 
 // Several weight gradients in ONE launch (a trainable block's five / four projections): the single-problem launches are
 // latency-bound (16 us each for 1.6 .. 6.3 GFLOP), together they fill the GPU once.  Workgroup -> (problem, tile, split).
-constexpr int TN_MAX_GROUP = 8;
+constexpr int TN_MAX_GROUP = 12;
 struct TnProblem {
     const __bf16* dY; const __bf16* X; float* part; float* part_b; float* dW; float* db;
     size_t row_stride; int ldy, ldx, M, n, k, rps, S, tiles, wg_begin; int64_t out_begin;
