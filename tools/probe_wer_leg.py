@@ -67,6 +67,14 @@ def main():
             for i in range(len(marks)):
                 acc[i] += t[i + 1] - t[i]
 
+    if os.environ.get("IA_PROBE_PER_STEP"):      # wall clock of every step from the first one on (device synchronised after each)
+        ts = []
+        for _ in range(30):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            one(False)
+            torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
+        print("per-step ms:", " ".join(f"{t:.2f}" for t in ts), flush=True)
+        return
     for _ in range(5):
         one(False)
     torch.cuda.synchronize()
